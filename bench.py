@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""bench.py -- k-mers merged/sec of the glistcompare intersection hot path on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one complete two-list intersection (merge-path partition + merge kernel + totals
+read-back) over synthetic sorted lists that are already resident in HBM.  Workload at N=1 is
+BASELINE.json configs[1]: two 2x10^9-entry k=25 lists (~24 GB each), `glistcompare -i`.  With N>1
+every rank owns one key-range shard of the same shape (the set operations are key-local, SURVEY
+8e): no data-path collective, only the per-shard (n_words, total_count) header totals are
+all-gathered over RCCL; scaling is weak.
+
+Prints ONE JSON line on rank 0.  `roofline` is computed from the merge kernel's own HIP-event time
+(recorded by the library on the stream it launches on); `cpu_baseline` times the REFERENCE binary
+(oracle/_ref/glistcompare, `kind: reference`) or, when that is absent, the C oracle (`kind: port`)
+on a bounded prefix sample of the same lists.
+"""
+import argparse
+import json
+import os
+import shutil
+import statistics
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def build_lists(ctx, capi, n, k, seed_base):
+    """A = S u PA, B = S' u PB from three disjoint residue classes (mod 3): |A| = |B| = n,
+    |A n B| = |S| = n // 2 exactly; S' has S's keys with different counts."""
+    n_s = n // 2
+    n_p = n - n_s
+    s = ctx.alloc(n_s, k)
+    ctx.generate_ex(s, n_s, seed_base + 11, seed_base + 21, 8, 3, 0)
+    p = ctx.alloc(n_p, k)
+    ctx.generate_ex(p, n_p, seed_base + 12, seed_base + 23, 8, 3, 1)
+    _, out, _ = ctx.compare(s, p, capi.OP_UNION)
+    a = out[capi.OP_UNION]
+    ctx.generate_ex(s, n_s, seed_base + 11, seed_base + 22, 8, 3, 0)
+    ctx.generate_ex(p, n_p, seed_base + 13, seed_base + 24, 8, 3, 2)
+    _, out, _ = ctx.compare(s, p, capi.OP_UNION)
+    b = out[capi.OP_UNION]
+    s.free()
+    p.free()
+    assert a.n_words == n and b.n_words == n, (a.n_words, b.n_words, n)
+    return a, b
+
+
+def cpu_baseline(ctx, a, b, k, sample_records):
+    """Times the reference CPU path on a prefix sample covering the same key range of both lists."""
+    import numpy as np
+    from genometester4_amd.listio import write_list
+    m_a = min(sample_records, a.n_words)
+    last_key, _ = a.get_word(m_a - 1)
+    m_b = b.lower_bound(last_key + 1) if last_key < 0xFFFFFFFFFFFFFFFF else b.n_words
+    ha, hb = a.download_range(0, m_a), b.download_range(0, m_b)
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "glistcompare")
+    sample = "first %d + %d records of the same two lists (equal key range), -i --count_only, warm page cache" % (m_a, m_b)
+    if os.path.exists(ref_bin) and os.access(ref_bin, os.X_OK):
+        shm = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 13 * (m_a + m_b) else None
+        d = tempfile.mkdtemp(prefix="gt4bench_", dir=shm)
+        try:
+            write_list(os.path.join(d, "a.list"), ha, k)
+            write_list(os.path.join(d, "b.list"), hb, k)
+            times = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                r = subprocess.run([ref_bin, "a.list", "b.list", "-i", "--count_only"], cwd=d, capture_output=True)
+                times.append(time.perf_counter() - t0)
+                if r.returncode != 0:
+                    raise RuntimeError("reference glistcompare failed: %s" % r.stderr.decode())
+            t = statistics.median(times)
+            return dict(value=(m_a + m_b) / t, unit="k-mers/s", cores=3, kind="reference",
+                        sample=sample + "; reference glistcompare 4.2.16: 1 merge thread + 2 scout threads; median of 3 runs",
+                        stdout=r.stdout.decode().strip().replace("\n", " ").replace("\t", "="))
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        O.compare(ha, hb, O.OP_INTRSEC, count_only=True)
+        times.append(time.perf_counter() - t0)
+    return dict(value=(m_a + m_b) / statistics.median(times), unit="k-mers/s", cores=1, kind="port",
+                sample=sample + "; oracle/gt4_oracle.c scalar restatement, median of 3 runs")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=2_000_000_000, help="entries per list per GPU")
+    ap.add_argument("--k", type=int, default=25)
+    ap.add_argument("--cpu-sample", type=int, default=200_000_000, help="records per list timed on the CPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--two-pass", action="store_true", help="count+scan+write instead of single-pass look-back")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from genometester4_amd import capi
+    ctx = capi.Context(local_rank)
+    if args.two_pass:
+        ctx.set_option("two_pass", 1)
+    n = args.n
+    while True:
+        try:
+            a, b = build_lists(ctx, capi, n, args.k, 1000 * rank)
+            out = ctx.alloc(n, args.k)
+            break
+        except capi.Gt4HipError as e:
+            if e.code != capi.ENOMEM or n < 1_000_000:
+                raise
+            log("rank %d: %d entries per list do not fit (%s); halving" % (rank, n, e))
+            n //= 2
+    if world > 1:  # all ranks must run the same shape
+        t = torch.tensor([n], dtype=torch.int64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if int(t.item()) != n:
+            n = int(t.item())
+            a, b = a.slice(0, n), b.slice(0, n)
+    n_a, n_b = a.n_words, b.n_words
+
+    def step():
+        st, _, timing = ctx.compare(a, b, capi.OP_INTRSEC, out={capi.OP_INTRSEC: out})
+        return st[capi.OP_INTRSEC], timing
+
+    def fence():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    kernel_ms, device_ms = [], []
+    stat = None
+    for _ in range(args.steps):
+        stat, timing = step()
+        kernel_ms.append(timing["merge_kernel_ms"])
+        device_ms.append(timing["device_ms"])
+    fence()
+    elapsed = time.perf_counter() - t0
+    totals = [stat[0], stat[1]]
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        # the only exchange the sharded intersection needs: per-shard header totals
+        g = [torch.zeros(2, dtype=torch.int64, device="cuda") for _ in range(world)]
+        dist.all_gather(g, torch.tensor(totals, dtype=torch.int64, device="cuda"))
+        totals = [int(sum(x[0].item() for x in g)), int(sum(x[1].item() for x in g))]
+
+    if rank == 0:
+        n_out = stat[0]
+        k_ms = statistics.mean(kernel_ms)
+        alg_bytes = 12 * (n_a + n_b) + 12 * n_out
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("n_per_list") == n:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                pass
+        res = {
+            "metric": "k-mers merged/sec, 2-list k=%d intersection (glistcompare -i), lists resident in HBM" % args.k,
+            "value": world * (n_a + n_b) * args.steps / elapsed,
+            "unit": "k-mers/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u64 keys + u32 counts",
+            "data": "synthetic",
+            "config": {
+                "workload": "single-GPU intersection, two %d-entry k=%d lists (%.1f GB each) per GPU, |A n B| = n/2, bit-exact vs CPU"
+                            % (n, args.k, 12 * n / 1e9),
+                "entries_per_list_per_gpu": n,
+                "word_length": args.k,
+                "output_records": totals[0],
+                "output_total_count": totals[1],
+                "sharding": "one key-range shard per GPU, no data-path collective" if world > 1 else "none",
+                "path": "two_pass" if args.two_pass else "single_pass_lookback",
+                "device": ctx.device_info(),
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_pair_merge",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "read_only_frac": 12 * (n_a + n_b) / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "kernel_ms_avg": k_ms,
+                "device_ms_avg": statistics.mean(device_ms),
+                "traffic": traffic,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                res["cpu_baseline"] = cpu_baseline(ctx, a, b, args.k, args.cpu_sample)
+            except Exception as e:  # the GPU number stands on its own; say why the CPU leg is missing
+                res["cpu_baseline"] = {"value": None, "unit": "k-mers/s", "cores": 0, "kind": "reference", "sample": "failed: %s" % e}
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

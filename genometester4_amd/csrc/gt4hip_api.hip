@@ -1,0 +1,752 @@
+/*
+ * gt4hip_api.hip -- implementation of the C ABI declared in include/gt4hip.h.
+ *
+ * Host-side orchestration only: contexts, HBM-resident lists, workspace, kernel sequencing and
+ * timing.  All per-record work happens in gt4hip_kernels.hip.  Nothing here falls back to the CPU.
+ */
+#include "../../include/gt4hip.h"
+#include "gt4hip_internal.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+using namespace gt4;
+
+struct gt4hip_context {
+  int device;
+  hipStream_t stream;
+  hipEvent_t ev[4];
+  int n_cus;
+  int two_pass;
+  int64_t grid_override;
+  /* workspace, grown on demand */
+  uint64_t *part;
+  size_t part_bytes;
+  unsigned long long *desc;
+  size_t desc_bytes;
+  unsigned long long *block_sums;
+  size_t block_sums_bytes;
+  PairControl *ctl;          /* device */
+  PairControl *ctl_host;     /* pinned */
+  unsigned long long *scratch;      /* device, 4 x u64 */
+  unsigned long long *scratch_host; /* pinned */
+  char err[512];
+  char info[256];
+};
+
+struct gt4hip_list {
+  gt4hip_context *ctx;
+  void *dev;
+  uint64_t n_words;
+  uint64_t capacity;
+  uint32_t word_length;
+  int owns;
+};
+
+static char g_create_err[512] = "";
+
+static int fail (gt4hip_context *ctx, int code, const char *fmt, ...)
+{
+  va_list ap;
+  va_start (ap, fmt);
+  vsnprintf (ctx ? ctx->err : g_create_err, 512, fmt, ap);
+  va_end (ap);
+  return code;
+}
+
+#define HIPCHK(ctx, call)                                                                               \
+  do {                                                                                                  \
+    hipError_t e_ = (call);                                                                             \
+    if (e_ != hipSuccess) return fail ((ctx), e_ == hipErrorOutOfMemory ? GT4HIP_ENOMEM : GT4HIP_EHIP, \
+                                       "%s failed: %s", #call, hipGetErrorString (e_));                 \
+  } while (0)
+
+extern "C" const char *gt4hip_strerror (int code)
+{
+  switch (code) {
+    case GT4HIP_OK: return "ok";
+    case GT4HIP_EINVAL: return "invalid argument";
+    case GT4HIP_ENODEVICE: return "no usable HIP device";
+    case GT4HIP_ENOMEM: return "out of memory";
+    case GT4HIP_ERULE: return "rule not allowed for this operation";
+    case GT4HIP_EHIP: return "HIP runtime error";
+    case GT4HIP_EWORDLEN: return "lists have different word lengths";
+    case GT4HIP_EINTERNAL: return "internal consistency check failed";
+    case GT4HIP_ECALLBACK: return "stopped by callback";
+    default: return "unknown error";
+  }
+}
+
+extern "C" const char *gt4hip_last_error (const gt4hip_context *ctx)
+{
+  return ctx ? ctx->err : g_create_err;
+}
+
+extern "C" int gt4hip_device_count (void)
+{
+  int n = 0;
+  if (hipGetDeviceCount (&n) != hipSuccess) return 0;
+  return n;
+}
+
+extern "C" int gt4hip_create (int device, gt4hip_context **out)
+{
+  if (!out || device < 0) return fail (NULL, GT4HIP_EINVAL, "gt4hip_create: bad arguments");
+  *out = NULL;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount (&n);
+  if (e != hipSuccess || n <= 0)
+    return fail (NULL, GT4HIP_ENODEVICE, "gt4hip_create: no HIP device (%s)", e != hipSuccess ? hipGetErrorString (e) : "count 0");
+  if (device >= n) return fail (NULL, GT4HIP_ENODEVICE, "gt4hip_create: device %d not present (%d visible)", device, n);
+  if ((e = hipSetDevice (device)) != hipSuccess)
+    return fail (NULL, GT4HIP_ENODEVICE, "gt4hip_create: hipSetDevice(%d): %s", device, hipGetErrorString (e));
+  gt4hip_context *ctx = new (std::nothrow) gt4hip_context ();
+  if (!ctx) return fail (NULL, GT4HIP_ENOMEM, "gt4hip_create: host allocation failed");
+  memset (ctx, 0, sizeof *ctx);
+  ctx->device = device;
+  hipDeviceProp_t prop;
+  if ((e = hipGetDeviceProperties (&prop, device)) != hipSuccess) {
+    delete ctx;
+    return fail (NULL, GT4HIP_ENODEVICE, "gt4hip_create: hipGetDeviceProperties: %s", hipGetErrorString (e));
+  }
+  ctx->n_cus = prop.multiProcessorCount;
+  snprintf (ctx->info, sizeof ctx->info, "%s|%s|%d|%zu", prop.name, prop.gcnArchName, prop.multiProcessorCount, prop.totalGlobalMem);
+  if ((e = hipStreamCreateWithFlags (&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
+    delete ctx;
+    return fail (NULL, GT4HIP_ENODEVICE, "gt4hip_create: hipStreamCreate: %s", hipGetErrorString (e));
+  }
+  for (int i = 0; i < 4; i++) hipEventCreate (&ctx->ev[i]);
+  if (hipMalloc ((void **) &ctx->ctl, sizeof (PairControl)) != hipSuccess ||
+      hipHostMalloc ((void **) &ctx->ctl_host, sizeof (PairControl), hipHostMallocDefault) != hipSuccess ||
+      hipMalloc ((void **) &ctx->scratch, 64) != hipSuccess ||
+      hipHostMalloc ((void **) &ctx->scratch_host, 64, hipHostMallocDefault) != hipSuccess) {
+    gt4hip_destroy (ctx);
+    return fail (NULL, GT4HIP_ENOMEM, "gt4hip_create: control block allocation failed");
+  }
+  *out = ctx;
+  return GT4HIP_OK;
+}
+
+extern "C" void gt4hip_destroy (gt4hip_context *ctx)
+{
+  if (!ctx) return;
+  hipSetDevice (ctx->device);
+  if (ctx->stream) hipStreamSynchronize (ctx->stream);
+  if (ctx->part) hipFree (ctx->part);
+  if (ctx->desc) hipFree (ctx->desc);
+  if (ctx->block_sums) hipFree (ctx->block_sums);
+  if (ctx->ctl) hipFree (ctx->ctl);
+  if (ctx->ctl_host) hipHostFree (ctx->ctl_host);
+  if (ctx->scratch) hipFree (ctx->scratch);
+  if (ctx->scratch_host) hipHostFree (ctx->scratch_host);
+  for (int i = 0; i < 4; i++) if (ctx->ev[i]) hipEventDestroy (ctx->ev[i]);
+  if (ctx->stream) hipStreamDestroy (ctx->stream);
+  delete ctx;
+}
+
+extern "C" const char *gt4hip_device_info (const gt4hip_context *ctx)
+{
+  return ctx ? ctx->info : "";
+}
+
+extern "C" int gt4hip_set_option (gt4hip_context *ctx, const char *name, int64_t value)
+{
+  if (!ctx || !name) return GT4HIP_EINVAL;
+  if (!strcmp (name, "two_pass")) ctx->two_pass = value != 0;
+  else if (!strcmp (name, "grid")) ctx->grid_override = value;
+  else return fail (ctx, GT4HIP_EINVAL, "unknown option %s", name);
+  return GT4HIP_OK;
+}
+
+extern "C" int gt4hip_synchronize (gt4hip_context *ctx)
+{
+  if (!ctx) return GT4HIP_EINVAL;
+  HIPCHK (ctx, hipStreamSynchronize (ctx->stream));
+  return GT4HIP_OK;
+}
+
+/* ------------------------------------------------------------------ lists */
+
+static int list_new (gt4hip_context *ctx, uint64_t capacity, uint32_t word_length, gt4hip_list **out)
+{
+  gt4hip_list *l = new (std::nothrow) gt4hip_list ();
+  if (!l) return fail (ctx, GT4HIP_ENOMEM, "host allocation failed");
+  l->ctx = ctx;
+  l->dev = NULL;
+  l->n_words = capacity;
+  l->capacity = capacity;
+  l->word_length = word_length;
+  l->owns = 1;
+  /* 16 bytes of slack so that 16-byte vector loads that straddle the end stay inside the allocation */
+  size_t bytes = (size_t) capacity * GT4HIP_RECORD_BYTES + 16;
+  hipError_t e = hipMalloc (&l->dev, bytes);
+  if (e != hipSuccess) {
+    delete l;
+    return fail (ctx, GT4HIP_ENOMEM, "hipMalloc of %zu bytes failed: %s", bytes, hipGetErrorString (e));
+  }
+  *out = l;
+  return GT4HIP_OK;
+}
+
+extern "C" int gt4hip_list_alloc (gt4hip_context *ctx, uint64_t capacity, uint32_t word_length, gt4hip_list **out)
+{
+  if (!ctx || !out) return GT4HIP_EINVAL;
+  HIPCHK (ctx, hipSetDevice (ctx->device));
+  return list_new (ctx, capacity, word_length, out);
+}
+
+extern "C" int gt4hip_list_upload (gt4hip_context *ctx, const void *host_records, uint64_t n_words, uint32_t word_length,
+                                    gt4hip_list **out)
+{
+  if (!ctx || !out || (n_words && !host_records)) return GT4HIP_EINVAL;
+  HIPCHK (ctx, hipSetDevice (ctx->device));
+  gt4hip_list *l = NULL;
+  int rc = list_new (ctx, n_words, word_length, &l);
+  if (rc) return rc;
+  if (n_words) {
+    hipError_t e = hipMemcpyAsync (l->dev, host_records, (size_t) n_words * GT4HIP_RECORD_BYTES, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize (ctx->stream);
+    if (e != hipSuccess) {
+      gt4hip_list_free (l);
+      return fail (ctx, GT4HIP_EHIP, "upload failed: %s", hipGetErrorString (e));
+    }
+  }
+  *out = l;
+  return GT4HIP_OK;
+}
+
+extern "C" int gt4hip_list_wrap (gt4hip_context *ctx, void *device_records, uint64_t n_words, uint32_t word_length, gt4hip_list **out)
+{
+  if (!ctx || !out || (n_words && !device_records)) return GT4HIP_EINVAL;
+  if (((uintptr_t) device_records) & 3) return fail (ctx, GT4HIP_EINVAL, "device records must be 4-byte aligned");
+  gt4hip_list *l = new (std::nothrow) gt4hip_list ();
+  if (!l) return fail (ctx, GT4HIP_ENOMEM, "host allocation failed");
+  l->ctx = ctx;
+  l->dev = device_records;
+  l->n_words = n_words;
+  l->capacity = n_words;
+  l->word_length = word_length;
+  l->owns = 0;
+  *out = l;
+  return GT4HIP_OK;
+}
+
+extern "C" int gt4hip_list_slice (gt4hip_context *ctx, const gt4hip_list *list, uint64_t first, uint64_t count, gt4hip_list **out)
+{
+  if (!ctx || !list || !out || first > list->n_words || count > list->n_words - first) return GT4HIP_EINVAL;
+  return gt4hip_list_wrap (ctx, (char *) list->dev + first * GT4HIP_RECORD_BYTES, count, list->word_length, out);
+}
+
+extern "C" int gt4hip_list_download_range (gt4hip_context *ctx, const gt4hip_list *list, uint64_t first, uint64_t count, void *host)
+{
+  if (!ctx || !list || first > list->n_words || count > list->n_words - first || (count && !host)) return GT4HIP_EINVAL;
+  if (!count) return GT4HIP_OK;
+  HIPCHK (ctx, hipSetDevice (ctx->device));
+  HIPCHK (ctx, hipMemcpyAsync (host, (const char *) list->dev + first * GT4HIP_RECORD_BYTES, (size_t) count * GT4HIP_RECORD_BYTES,
+                               hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK (ctx, hipStreamSynchronize (ctx->stream));
+  return GT4HIP_OK;
+}
+
+extern "C" int gt4hip_list_download (gt4hip_context *ctx, const gt4hip_list *list, void *host)
+{
+  if (!list) return GT4HIP_EINVAL;
+  return gt4hip_list_download_range (ctx, list, 0, list->n_words, host);
+}
+
+extern "C" void gt4hip_list_free (gt4hip_list *l)
+{
+  if (!l) return;
+  if (l->owns && l->dev) {
+    hipSetDevice (l->ctx->device);
+    hipFree (l->dev);
+  }
+  delete l;
+}
+
+extern "C" uint64_t gt4hip_list_n_words (const gt4hip_list *l) { return l ? l->n_words : 0; }
+extern "C" uint32_t gt4hip_list_word_length (const gt4hip_list *l) { return l ? l->word_length : 0; }
+extern "C" void *gt4hip_list_device_ptr (const gt4hip_list *l) { return l ? l->dev : NULL; }
+
+extern "C" int gt4hip_list_set_n_words (gt4hip_list *l, uint64_t n)
+{
+  if (!l || n > l->capacity) return GT4HIP_EINVAL;
+  l->n_words = n;
+  return GT4HIP_OK;
+}
+
+static int read_scratch (gt4hip_context *ctx, unsigned n)
+{
+  HIPCHK (ctx, hipMemcpyAsync (ctx->scratch_host, ctx->scratch, n * sizeof (unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK (ctx, hipStreamSynchronize (ctx->stream));
+  return GT4HIP_OK;
+}
+
+extern "C" int gt4hip_list_sum_counts (gt4hip_context *ctx, const gt4hip_list *l, uint64_t *sum)
+{
+  if (!ctx || !l || !sum) return GT4HIP_EINVAL;
+  HIPCHK (ctx, hipSetDevice (ctx->device));
+  HIPCHK (ctx, hipMemsetAsync (ctx->scratch, 0, 64, ctx->stream));
+  if (l->n_words) HIPCHK (ctx, launch_sum_counts (ctx->stream, (const uint32_t *) l->dev, l->n_words, ctx->scratch));
+  int rc = read_scratch (ctx, 1);
+  if (rc) return rc;
+  *sum = ctx->scratch_host[0];
+  return GT4HIP_OK;
+}
+
+extern "C" int gt4hip_list_is_sorted (gt4hip_context *ctx, const gt4hip_list *l, int *sorted)
+{
+  if (!ctx || !l || !sorted) return GT4HIP_EINVAL;
+  HIPCHK (ctx, hipSetDevice (ctx->device));
+  HIPCHK (ctx, hipMemsetAsync (ctx->scratch, 0, 64, ctx->stream));
+  if (l->n_words > 1) HIPCHK (ctx, launch_check_sorted (ctx->stream, (const uint32_t *) l->dev, l->n_words, (unsigned int *) ctx->scratch));
+  int rc = read_scratch (ctx, 1);
+  if (rc) return rc;
+  *sorted = (ctx->scratch_host[0] & 0xffffffffu) == 0;
+  return GT4HIP_OK;
+}
+
+extern "C" int gt4hip_list_lower_bound (gt4hip_context *ctx, const gt4hip_list *l, uint64_t key, uint64_t *index)
+{
+  if (!ctx || !l || !index) return GT4HIP_EINVAL;
+  HIPCHK (ctx, hipSetDevice (ctx->device));
+  if (!l->n_words) {
+    *index = 0;
+    return GT4HIP_OK;
+  }
+  HIPCHK (ctx, launch_lower_bound (ctx->stream, (const uint32_t *) l->dev, l->n_words, key, ctx->scratch));
+  int rc = read_scratch (ctx, 1);
+  if (rc) return rc;
+  *index = ctx->scratch_host[0];
+  return GT4HIP_OK;
+}
+
+extern "C" int gt4hip_list_get_word (gt4hip_context *ctx, const gt4hip_list *l, uint64_t idx, uint64_t *word, uint32_t *count)
+{
+  if (!ctx || !l || idx >= l->n_words) return GT4HIP_EINVAL;
+  unsigned char rec[12];
+  int rc = gt4hip_list_download_range (ctx, l, idx, 1, rec);
+  if (rc) return rc;
+  if (word) memcpy (word, rec, 8);
+  if (count) memcpy (count, rec + 8, 4);
+  return GT4HIP_OK;
+}
+
+extern "C" int gt4hip_generate_ex (gt4hip_context *ctx, gt4hip_list *l, uint64_t n, uint64_t key_seed, uint64_t count_seed,
+                                   uint32_t max_count, uint64_t mult, uint64_t add)
+{
+  if (!ctx || !l || n > l->capacity || !max_count || !l->word_length || l->word_length > 32 || !mult || add >= mult) return GT4HIP_EINVAL;
+  HIPCHK (ctx, hipSetDevice (ctx->device));
+  l->n_words = n;
+  if (!n) return GT4HIP_OK;
+  /* keyspace 4^k (2^64 for k = 32), thinned by `mult`; stride = floor(keyspace / mult / n) */
+  unsigned __int128 space = l->word_length == 32 ? ((unsigned __int128) 1 << 64) : ((unsigned __int128) 1 << (2 * l->word_length));
+  space /= mult;
+  unsigned __int128 st = space / n;
+  if (st > 0xffffffffffffffffull) st = 0xffffffffffffffffull;
+  const uint64_t stride = (uint64_t) st;
+  if (!stride) return fail (ctx, GT4HIP_EINVAL, "gt4hip_generate: %llu keys do not fit k=%u", (unsigned long long) n, l->word_length);
+  HIPCHK (ctx, launch_generate (ctx->stream, (uint32_t *) l->dev, n, stride, key_seed, count_seed, max_count, mult, add));
+  HIPCHK (ctx, hipStreamSynchronize (ctx->stream));
+  return GT4HIP_OK;
+}
+
+extern "C" int gt4hip_generate (gt4hip_context *ctx, gt4hip_list *l, uint64_t n, uint64_t seed, uint32_t max_count)
+{
+  return gt4hip_generate_ex (ctx, l, n, seed, seed + 1, max_count, 1, 0);
+}
+
+/* ------------------------------------------------------------------ workspace */
+
+static int grow (gt4hip_context *ctx, void **p, size_t *have, size_t need)
+{
+  if (*have >= need) return GT4HIP_OK;
+  if (*p) {
+    HIPCHK (ctx, hipStreamSynchronize (ctx->stream));
+    HIPCHK (ctx, hipFree (*p));
+    *p = NULL;
+    *have = 0;
+  }
+  need += need / 8; /* slack so that slightly larger follow-up calls do not reallocate */
+  hipError_t e = hipMalloc (p, need);
+  if (e != hipSuccess) return fail (ctx, GT4HIP_ENOMEM, "workspace hipMalloc of %zu bytes failed: %s", need, hipGetErrorString (e));
+  *have = need;
+  return GT4HIP_OK;
+}
+
+/* ------------------------------------------------------------------ pair operation core */
+
+struct PairRun {
+  uint64_t n_words[4];
+  uint64_t total_count[4];
+  double merge_ms, device_ms;
+  uint64_t tiles;
+};
+
+/* Runs the merge of (a, b) with fully resolved kernel parameters.  dst[s] (device record buffers)
+ * must be non-null for every requested stream unless count_only. */
+static int run_pair (gt4hip_context *ctx, const uint32_t *A, uint64_t nA, const uint32_t *B, uint64_t nB,
+                     const PairParams &p, bool count_only, uint32_t *const dst[4], PairRun *run)
+{
+  memset (run, 0, sizeof *run);
+  const uint64_t total = nA + nB;
+  if (!total || !p.ops) return GT4HIP_OK;
+  const uint64_t tiles = (total + MERGE_TILE - 1) / MERGE_TILE;
+  run->tiles = tiles;
+  int rc;
+  if ((rc = grow (ctx, (void **) &ctx->part, &ctx->part_bytes, (size_t) (tiles + 1) * 16))) return rc;
+  const bool two_pass = ctx->two_pass && !count_only;
+  const bool need_desc = !count_only;
+  if (need_desc && (rc = grow (ctx, (void **) &ctx->desc, &ctx->desc_bytes, (size_t) tiles * 32))) return rc;
+  if (two_pass) {
+    const size_t nb = (size_t) ((tiles + 2047) / 2048) * 32;
+    if ((rc = grow (ctx, (void **) &ctx->block_sums, &ctx->block_sums_bytes, nb))) return rc;
+  }
+  int grid = ctx->n_cus * merge_blocks_per_cu ();
+  if (ctx->grid_override > 0) grid = (int) ctx->grid_override;
+  if ((uint64_t) grid > tiles) grid = (int) tiles;
+
+  PairOutputs outs;
+  for (int s = 0; s < 4; s++) outs.rec[s] = (count_only || !dst) ? NULL : dst[s];
+
+  hipStream_t st = ctx->stream;
+  HIPCHK (ctx, hipEventRecord (ctx->ev[0], st));
+  HIPCHK (ctx, hipMemsetAsync (ctx->ctl, 0, sizeof (PairControl), st));
+  if (need_desc && !two_pass) HIPCHK (ctx, hipMemsetAsync (ctx->desc, 0, (size_t) tiles * 32, st));
+  HIPCHK (ctx, launch_partition (st, A, nA, B, nB, tiles, ctx->part));
+  HIPCHK (ctx, hipEventRecord (ctx->ev[1], st));
+  if (count_only) {
+    HIPCHK (ctx, launch_pair_merge (st, MODE_COUNT, grid, A, nA, B, nB, ctx->part, tiles, p, outs, NULL, ctx->ctl));
+  } else if (two_pass) {
+    HIPCHK (ctx, launch_pair_merge (st, MODE_COUNT, grid, A, nA, B, nB, ctx->part, tiles, p, outs, ctx->desc, ctx->ctl));
+    HIPCHK (ctx, launch_scan_tiles (st, ctx->desc, tiles, ctx->block_sums));
+    HIPCHK (ctx, hipMemsetAsync (ctx->ctl, 0, sizeof (PairControl), st));
+    HIPCHK (ctx, launch_pair_merge (st, MODE_OFFSETS, grid, A, nA, B, nB, ctx->part, tiles, p, outs, ctx->desc, ctx->ctl));
+  } else {
+    HIPCHK (ctx, launch_pair_merge (st, MODE_LOOKBACK, grid, A, nA, B, nB, ctx->part, tiles, p, outs, ctx->desc, ctx->ctl));
+  }
+  HIPCHK (ctx, hipEventRecord (ctx->ev[2], st));
+  HIPCHK (ctx, hipMemcpyAsync (ctx->ctl_host, ctx->ctl, sizeof (PairControl), hipMemcpyDeviceToHost, st));
+  HIPCHK (ctx, hipEventRecord (ctx->ev[3], st));
+  HIPCHK (ctx, hipStreamSynchronize (st));
+  float ms = 0;
+  if (hipEventElapsedTime (&ms, ctx->ev[1], ctx->ev[2]) == hipSuccess) run->merge_ms = ms;
+  if (hipEventElapsedTime (&ms, ctx->ev[0], ctx->ev[3]) == hipSuccess) run->device_ms = ms;
+  if (ctx->ctl_host->error) return fail (ctx, GT4HIP_EINTERNAL, "merge kernel reported error flags 0x%x", ctx->ctl_host->error);
+  for (int s = 0; s < 4; s++) {
+    run->n_words[s] = ctx->ctl_host->n_words[s];
+    run->total_count[s] = ctx->ctl_host->total_count[s];
+  }
+  return GT4HIP_OK;
+}
+
+static uint64_t worst_case (int s, uint64_t nA, uint64_t nB)
+{
+  switch (s) {
+    case 0: return nA + nB;
+    case 1: return nA < nB ? nA : nB;
+    case 2: return nA;
+    default: return nB;
+  }
+}
+
+/* Allocates missing outputs, runs, trims.  `given[s]` optional caller lists. */
+static int pair_with_outputs (gt4hip_context *ctx, const gt4hip_list *a, const gt4hip_list *b, const PairParams &p,
+                              bool count_only, gt4hip_list *out[4], PairRun *run)
+{
+  gt4hip_list *made[4] = { NULL, NULL, NULL, NULL };
+  uint32_t *dst[4] = { NULL, NULL, NULL, NULL };
+  int rc = GT4HIP_OK;
+  if (!count_only) {
+    for (int s = 0; s < 4 && !rc; s++) {
+      if (!((p.ops >> s) & 1u)) continue;
+      const uint64_t need = worst_case (s, a->n_words, b->n_words);
+      if (out[s]) {
+        if (out[s]->capacity < need) rc = fail (ctx, GT4HIP_EINVAL, "output %d: capacity %llu < worst case %llu", s,
+                                                 (unsigned long long) out[s]->capacity, (unsigned long long) need);
+      } else {
+        rc = list_new (ctx, need, a->word_length, &made[s]);
+        if (!rc) out[s] = made[s];
+      }
+      if (!rc) dst[s] = (uint32_t *) out[s]->dev;
+    }
+  }
+  if (!rc) rc = run_pair (ctx, (const uint32_t *) a->dev, a->n_words, (const uint32_t *) b->dev, b->n_words, p, count_only, dst, run);
+  if (rc) {
+    for (int s = 0; s < 4; s++)
+      if (made[s]) {
+        gt4hip_list_free (made[s]);
+        out[s] = NULL;
+      }
+    return rc;
+  }
+  if (!count_only)
+    for (int s = 0; s < 4; s++)
+      if ((p.ops >> s) & 1u) {
+        out[s]->n_words = run->n_words[s];
+        out[s]->word_length = a->word_length;
+      }
+  return GT4HIP_OK;
+}
+
+extern "C" int gt4hip_compare (gt4hip_context *ctx, const gt4hip_list *a, const gt4hip_list *b,
+                                const gt4hip_compare_params *prm, gt4hip_compare_result *res)
+{
+  if (!ctx || !a || !b || !prm || !res) return GT4HIP_EINVAL;
+  if (prm->ops & ~15u) return fail (ctx, GT4HIP_EINVAL, "gt4hip_compare: unknown op bits 0x%x", prm->ops);
+  if (prm->rule < 0 || prm->rule > 7) return fail (ctx, GT4HIP_EINVAL, "gt4hip_compare: unknown rule %d", prm->rule);
+  if (a->word_length != b->word_length) return fail (ctx, GT4HIP_EWORDLEN, "word lengths differ (%u != %u)", b->word_length, a->word_length);
+  HIPCHK (ctx, hipSetDevice (ctx->device));
+  PairParams p;
+  memset (&p, 0, sizeof p);
+  p.ops = prm->ops;
+  /* DEFAULT resolves per output: ADD for union (:463), MIN for intersection (:472), SUBTRACT for
+   * both complements (:486) */
+  const uint32_t r = (uint32_t) prm->rule;
+  p.rule[0] = r ? r : GT4HIP_RULE_ADD;
+  p.rule[1] = r ? r : GT4HIP_RULE_MIN;
+  p.rule[2] = r ? r : GT4HIP_RULE_SUBTRACT;
+  p.rule[3] = r ? r : GT4HIP_RULE_SUBTRACT;
+  p.cutoff = prm->cutoff;
+  p.subtract = prm->subtract ? 1u : 0u;
+  p.count_override = prm->count_override;
+  p.filter = FILTER_REFERENCE;
+  PairRun run;
+  gt4hip_list *out[4];
+  for (int s = 0; s < 4; s++) out[s] = ((prm->ops >> s) & 1u) && !prm->count_only ? res->out[s] : NULL;
+  int rc = pair_with_outputs (ctx, a, b, p, prm->count_only != 0, out, &run);
+  if (rc) return rc;
+  for (int s = 0; s < 4; s++) {
+    res->n_words[s] = run.n_words[s];
+    res->total_count[s] = run.total_count[s];
+    res->out[s] = out[s];
+  }
+  res->merge_kernel_ms = run.merge_ms;
+  res->device_ms = run.device_ms;
+  res->merge_tiles = run.tiles;
+  return GT4HIP_OK;
+}
+
+/* ------------------------------------------------------------------ N-way operations */
+
+static PairParams nway_params (uint32_t op_bit, uint32_t rule, uint32_t cutoff, uint32_t ovr, uint32_t filter)
+{
+  PairParams p;
+  memset (&p, 0, sizeof p);
+  p.ops = op_bit;
+  for (int s = 0; s < 4; s++) p.rule[s] = rule;
+  p.cutoff = cutoff;
+  p.count_override = ovr;
+  p.filter = filter;
+  return p;
+}
+
+/* Final step shared by both N-way ops: merge (a, b) into the caller-visible result. */
+static int nway_final (gt4hip_context *ctx, const gt4hip_list *a, const gt4hip_list *b, const PairParams &p, int stream_idx,
+                       bool count_only, gt4hip_multi_result *res)
+{
+  gt4hip_list *out[4] = { NULL, NULL, NULL, NULL };
+  out[stream_idx] = count_only ? NULL : res->out;
+  PairRun run;
+  int rc = pair_with_outputs (ctx, a, b, p, count_only, out, &run);
+  if (rc) return rc;
+  res->n_words = run.n_words[stream_idx];
+  res->total_count = run.total_count[stream_idx];
+  res->out = count_only ? NULL : out[stream_idx];
+  res->device_ms += run.device_ms;
+  return GT4HIP_OK;
+}
+
+static int empty_result (gt4hip_context *ctx, uint32_t word_length, bool count_only, gt4hip_multi_result *res)
+{
+  res->n_words = 0;
+  res->total_count = 0;
+  if (count_only) {
+    res->out = NULL;
+    return GT4HIP_OK;
+  }
+  if (res->out) {
+    res->out->n_words = 0;
+    return GT4HIP_OK;
+  }
+  return list_new (ctx, 0, word_length, &res->out);
+}
+
+extern "C" int gt4hip_union_multi (gt4hip_context *ctx, const gt4hip_list *const lists[], uint32_t n_lists, uint32_t cutoff,
+                                    int32_t rule, uint32_t ovr, int32_t count_only, gt4hip_multi_result *res)
+{
+  if (!ctx || !lists || !n_lists || !res) return GT4HIP_EINVAL;
+  /* src/glistcompare.c:518-523 */
+  if (rule == GT4HIP_RULE_DEFAULT) rule = GT4HIP_RULE_ADD;
+  else if (rule != GT4HIP_RULE_ADD && rule != GT4HIP_RULE_MAX && rule != GT4HIP_RULE_NUMBER)
+    return fail (ctx, GT4HIP_ERULE, "union_multi: Invalid rule %u (only ADD, MAX and NUMBER allowed)", (unsigned) rule);
+  for (uint32_t j = 0; j < n_lists; j++) {
+    if (!lists[j]) return GT4HIP_EINVAL;
+    if (lists[j]->word_length != lists[0]->word_length) return fail (ctx, GT4HIP_EWORDLEN, "word lengths differ");
+  }
+  HIPCHK (ctx, hipSetDevice (ctx->device));
+  res->device_ms = 0;
+  std::vector<const gt4hip_list *> work;
+  std::vector<gt4hip_list *> owned; /* intermediate levels, freed as soon as consumed */
+  for (uint32_t j = 0; j < n_lists; j++)
+    if (lists[j]->n_words) work.push_back (lists[j]); /* :525-532 empty lists are dropped */
+  const uint32_t wl = lists[0]->word_length;
+  if (work.empty ()) return empty_result (ctx, wl, count_only != 0, res);
+  gt4hip_list empty_b;
+  memset (&empty_b, 0, sizeof empty_b);
+  empty_b.ctx = ctx;
+  empty_b.word_length = wl;
+  int rc = GT4HIP_OK;
+  /* pairwise tree in HBM: intermediate levels keep every key (count rules ADD/MAX are associative
+   * and commutative), the cutoff is applied once, on the final count (:574) */
+  const PairParams raw = nway_params (GT4HIP_OP_UNION, (uint32_t) rule, cutoff, ovr, FILTER_RAW);
+  while (work.size () > 2 && !rc) {
+    std::vector<const gt4hip_list *> next;
+    std::vector<gt4hip_list *> next_owned;
+    for (size_t i = 0; i + 1 < work.size () && !rc; i += 2) {
+      gt4hip_list *out[4] = { NULL, NULL, NULL, NULL };
+      PairRun run;
+      rc = pair_with_outputs (ctx, work[i], work[i + 1], raw, false, out, &run);
+      if (!rc) {
+        res->device_ms += run.device_ms;
+        next.push_back (out[0]);
+        next_owned.push_back (out[0]);
+      }
+    }
+    if (work.size () & 1) next.push_back (work.back ());
+    /* the previous level's temporaries are consumed, except an odd one carried over */
+    for (gt4hip_list *l : owned) {
+      bool carried = false;
+      for (const gt4hip_list *n : next) carried |= (n == l);
+      if (carried) next_owned.push_back (l);
+      else gt4hip_list_free (l);
+    }
+    owned.swap (next_owned);
+    work.swap (next);
+  }
+  if (!rc) {
+    const PairParams fin = nway_params (GT4HIP_OP_UNION, (uint32_t) rule, cutoff, ovr, FILTER_RESULT);
+    rc = nway_final (ctx, work[0], work.size () > 1 ? work[1] : &empty_b, fin, 0, count_only != 0, res);
+  }
+  for (gt4hip_list *l : owned) gt4hip_list_free (l);
+  return rc;
+}
+
+extern "C" int gt4hip_intersect_multi (gt4hip_context *ctx, const gt4hip_list *const lists[], uint32_t n_lists, uint32_t cutoff,
+                                        int32_t rule, uint32_t ovr, int32_t count_only, gt4hip_multi_result *res)
+{
+  if (!ctx || !lists || !n_lists || !res) return GT4HIP_EINVAL;
+  /* src/glistcompare.c:622-627 */
+  if (rule == GT4HIP_RULE_DEFAULT) rule = GT4HIP_RULE_MIN;
+  else if (rule != GT4HIP_RULE_ADD && rule != GT4HIP_RULE_MIN && rule != GT4HIP_RULE_MAX && rule != GT4HIP_RULE_NUMBER)
+    return fail (ctx, GT4HIP_ERULE, "intersect_multi: Invalid rule %u (only ADD, MIN, MAX and NUMBER allowed)", (unsigned) rule);
+  bool any_empty = false;
+  for (uint32_t j = 0; j < n_lists; j++) {
+    if (!lists[j]) return GT4HIP_EINVAL;
+    if (lists[j]->word_length != lists[0]->word_length) return fail (ctx, GT4HIP_EWORDLEN, "word lengths differ");
+    any_empty |= lists[j]->n_words == 0;
+  }
+  HIPCHK (ctx, hipSetDevice (ctx->device));
+  res->device_ms = 0;
+  const uint32_t wl = lists[0]->word_length;
+  if (any_empty) return empty_result (ctx, wl, count_only != 0, res); /* :633-636 */
+  /* Left-to-right chain R_k = R_{k-1} n L_k, exactly the reference's fold order over the lists
+   * (:655-678): the running MIN restarts at 0 (RULE_MINZ), which is not associative, so no tree. */
+  const uint32_t krule = rule == GT4HIP_RULE_MIN ? RULE_MINZ : (uint32_t) rule;
+  if (n_lists == 1) {
+    gt4hip_list empty_b;
+    memset (&empty_b, 0, sizeof empty_b);
+    empty_b.ctx = ctx;
+    empty_b.word_length = wl;
+    /* fold(0, c) of one list: c for MIN/MAX/ADD, the override for NUMBER */
+    const PairParams fin = nway_params (GT4HIP_OP_UNION, rule == GT4HIP_RULE_NUMBER ? GT4HIP_RULE_NUMBER : GT4HIP_RULE_FIRST, cutoff, ovr, FILTER_RESULT);
+    return nway_final (ctx, lists[0], &empty_b, fin, 0, count_only != 0, res);
+  }
+  const gt4hip_list *acc = lists[0];
+  gt4hip_list *acc_owned = NULL;
+  int rc = GT4HIP_OK;
+  for (uint32_t k = 1; k + 1 < n_lists && !rc; k++) {
+    gt4hip_list *out[4] = { NULL, NULL, NULL, NULL };
+    PairRun run;
+    rc = pair_with_outputs (ctx, acc, lists[k], nway_params (GT4HIP_OP_INTRSEC, krule, cutoff, ovr, FILTER_RAW), false, out, &run);
+    if (acc_owned) gt4hip_list_free (acc_owned);
+    acc_owned = NULL;
+    if (!rc) {
+      res->device_ms += run.device_ms;
+      acc = acc_owned = out[1];
+    }
+  }
+  if (!rc) rc = nway_final (ctx, acc, lists[n_lists - 1], nway_params (GT4HIP_OP_INTRSEC, krule, cutoff, ovr, FILTER_RESULT), 1, count_only != 0, res);
+  if (acc_owned) gt4hip_list_free (acc_owned);
+  return rc;
+}
+
+/* ------------------------------------------------------------------ per-key count table (gt4_union) */
+
+extern "C" int gt4hip_union_table (gt4hip_context *ctx, const gt4hip_list *const lists[], uint32_t n_lists, gt4hip_count_table *table)
+{
+  if (!ctx || !lists || !n_lists || !table) return GT4HIP_EINVAL;
+  memset (table, 0, sizeof *table);
+  table->n_lists = n_lists;
+  /* all distinct keys ascending = N-way union with nothing filtered out */
+  gt4hip_multi_result u;
+  memset (&u, 0, sizeof u);
+  int rc;
+  {
+    /* FILTER_RESULT with cutoff 0 keeps every key (count >= 0) */
+    rc = gt4hip_union_multi (ctx, lists, n_lists, 0, GT4HIP_RULE_MAX, 0, 0, &u);
+  }
+  if (rc) return rc;
+  const uint64_t n = u.n_words;
+  table->n_keys = n;
+  if (!n) {
+    gt4hip_list_free (u.out);
+    return GT4HIP_OK;
+  }
+  hipError_t e = hipMalloc (&table->device_keys, (size_t) n * 8);
+  if (e == hipSuccess) e = hipMalloc (&table->device_counts, (size_t) n * n_lists * 4);
+  if (e != hipSuccess) {
+    gt4hip_list_free (u.out);
+    gt4hip_table_free (table);
+    return fail (ctx, GT4HIP_ENOMEM, "count table allocation failed: %s", hipGetErrorString (e));
+  }
+  e = launch_extract_keys (ctx->stream, (const uint32_t *) u.out->dev, n, (unsigned long long *) table->device_keys);
+  for (uint32_t j = 0; j < n_lists && e == hipSuccess; j++)
+    e = launch_counts_table (ctx->stream, (const uint32_t *) u.out->dev, n, (const uint32_t *) lists[j]->dev, lists[j]->n_words,
+                             (uint32_t *) table->device_counts, n_lists, j);
+  if (e == hipSuccess) e = hipStreamSynchronize (ctx->stream);
+  gt4hip_list_free (u.out);
+  if (e != hipSuccess) {
+    gt4hip_table_free (table);
+    return fail (ctx, GT4HIP_EHIP, "count table kernels failed: %s", hipGetErrorString (e));
+  }
+  return GT4HIP_OK;
+}
+
+extern "C" int gt4hip_table_download (gt4hip_context *ctx, const gt4hip_count_table *t, uint64_t first, uint64_t count,
+                                       uint64_t *host_keys, uint32_t *host_counts)
+{
+  if (!ctx || !t || first > t->n_keys || count > t->n_keys - first) return GT4HIP_EINVAL;
+  if (!count) return GT4HIP_OK;
+  HIPCHK (ctx, hipSetDevice (ctx->device));
+  if (host_keys) HIPCHK (ctx, hipMemcpyAsync (host_keys, (const char *) t->device_keys + first * 8, (size_t) count * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (host_counts)
+    HIPCHK (ctx, hipMemcpyAsync (host_counts, (const char *) t->device_counts + first * t->n_lists * 4, (size_t) count * t->n_lists * 4,
+                                 hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK (ctx, hipStreamSynchronize (ctx->stream));
+  return GT4HIP_OK;
+}
+
+extern "C" void gt4hip_table_free (gt4hip_count_table *t)
+{
+  if (!t) return;
+  if (t->device_keys) hipFree (t->device_keys);
+  if (t->device_counts) hipFree (t->device_counts);
+  t->device_keys = t->device_counts = NULL;
+  t->n_keys = 0;
+}

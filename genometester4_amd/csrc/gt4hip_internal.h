@@ -1,0 +1,79 @@
+/* gt4hip_internal.h -- shared between the kernel file and the C-ABI implementation. */
+#ifndef GT4HIP_INTERNAL_H
+#define GT4HIP_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gt4 {
+
+/* Internal rule code on top of the reference's enum Rules (src/glistcompare.c:45-54):
+ * the running minimum of intersect_multi, which restarts whenever it is 0
+ * (`if (!freq || c < freq) freq = c`, src/glistcompare.c:669). */
+constexpr uint32_t RULE_MINZ = 8;
+
+/* How an output stream decides to keep a key once its count is computed. */
+enum Filter : uint32_t {
+  FILTER_REFERENCE = 0, /* include_in_{union,intersection,complement}, src/glistcompare.c:459-489   */
+  FILTER_RAW = 1,       /* keep every key of the stream's domain (intermediate N-way levels)        */
+  FILTER_RESULT = 2     /* keep iff count >= cutoff (union_multi/intersect_multi, :574, :682)       */
+};
+
+struct PairParams {
+  uint32_t ops;            /* bit s: stream s is produced (0 union, 1 intrsec, 2 diff1, 3 diff2) */
+  uint32_t rule[4];        /* resolved rule per stream (never DEFAULT)                           */
+  uint32_t cutoff;
+  uint32_t subtract;       /* diff1 only                                                         */
+  uint32_t count_override;
+  uint32_t filter;
+};
+
+struct PairOutputs {
+  uint32_t *rec[4];        /* packed 12-byte records as dwords; may be null in count mode */
+};
+
+/* Control block in device memory, zeroed before every launch. */
+struct PairControl {
+  unsigned long long n_words[4];
+  unsigned long long total_count[4];
+  unsigned int ticket;     /* dynamic tile counter */
+  unsigned int error;      /* non-zero: a bounded spin gave up / consistency check tripped */
+  unsigned int pad[2];
+};
+
+enum MergeMode : int {
+  MODE_COUNT = 0,     /* totals only (--count_only), also pass 1 of the two-pass path: writes tile counts */
+  MODE_LOOKBACK = 1,  /* single pass: decoupled look-back gives each tile its output offsets            */
+  MODE_OFFSETS = 2    /* pass 2 of the two-pass path: tile offsets already scanned                       */
+};
+
+/* Geometry of the merge kernel. */
+constexpr int MERGE_NT = 256;               /* threads per workgroup (4 wavefronts)      */
+constexpr int MERGE_VT = 7;                 /* merged items per thread; odd => LDS-conflict-free strides */
+constexpr int MERGE_CAP = MERGE_NT * MERGE_VT; /* LDS capacity in records                 */
+constexpr int MERGE_TILE = MERGE_CAP - 1;   /* nominal tile; pair fix-up makes it +-1    */
+constexpr int MERGE_WAVES_PER_SIMD = 3;     /* LDS admits 3 workgroups (12 waves) per CU; cap VGPRs to match */
+
+hipError_t launch_partition (hipStream_t s, const uint32_t *A, uint64_t nA, const uint32_t *B, uint64_t nB,
+                             uint64_t num_tiles, uint64_t *part);
+hipError_t launch_pair_merge (hipStream_t s, int mode, int grid, const uint32_t *A, uint64_t nA,
+                              const uint32_t *B, uint64_t nB, const uint64_t *part, uint64_t num_tiles,
+                              const PairParams &p, const PairOutputs &o, unsigned long long *desc,
+                              PairControl *ctl);
+hipError_t launch_scan_tiles (hipStream_t s, unsigned long long *desc, uint64_t num_tiles,
+                              unsigned long long *block_sums);
+hipError_t launch_generate (hipStream_t s, uint32_t *rec, uint64_t n, uint64_t stride, uint64_t seed,
+                            uint64_t count_seed, uint32_t max_count, uint64_t mult, uint64_t add);
+hipError_t launch_sum_counts (hipStream_t s, const uint32_t *rec, uint64_t n, unsigned long long *sum);
+hipError_t launch_check_sorted (hipStream_t s, const uint32_t *rec, uint64_t n, unsigned int *bad);
+hipError_t launch_lower_bound (hipStream_t s, const uint32_t *rec, uint64_t n, uint64_t key,
+                               unsigned long long *idx);
+hipError_t launch_counts_table (hipStream_t s, const uint32_t *keys_rec, uint64_t n_keys, const uint32_t *list,
+                                uint64_t n_list, uint32_t *counts, uint32_t n_lists, uint32_t column);
+hipError_t launch_extract_keys (hipStream_t s, const uint32_t *rec, uint64_t n, unsigned long long *keys);
+
+int merge_blocks_per_cu ();
+
+}  // namespace gt4
+
+#endif

@@ -1,0 +1,210 @@
+/*
+ * gt4hip.h -- C ABI of the MI355X (gfx950) sorted k-mer list set-operation engine.
+ *
+ * This is the drop-in boundary between a C host -- the glistcompare CLI in
+ * genometester4_amd/csrc/glistcompare.c, or GenomeTester4's own glistcompare.c / glistmaker.c /
+ * glistquery.c with the binding shown in INTEGRATION.md -- and the hand-written HIP kernels.
+ * Plain C types only; nothing here throws, exits or prints.  Every function returns
+ * GT4HIP_OK (0) or a GT4HIP_E* code; gt4hip_last_error() gives the message.
+ *
+ * A "list" is an array of packed 12-byte records (u64 key LE + u32 count LE), strictly ascending
+ * by key, resident in HBM -- the record layout of a GenomeTester4 .list file body
+ * (reference src/word-map.h:89-99, src/word-list.h:61-72).
+ *
+ * Threading: one host thread per context.  The context owns its HIP stream and workspace;
+ * callers never manage streams.  Inputs are borrowed for the duration of a call (the reference
+ * maps them PROT_READ, src/utils.c:54); outputs belong to the caller and are released with
+ * gt4hip_list_free().
+ *
+ * There is NO CPU fallback behind this interface: without a usable gfx950 device every entry
+ * point fails with GT4HIP_ENODEVICE.
+ */
+#ifndef GT4HIP_H
+#define GT4HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GT4HIP_RECORD_BYTES 12u
+
+enum {
+  GT4HIP_OK = 0,
+  GT4HIP_EINVAL = 1,      /* bad argument                                   */
+  GT4HIP_ENODEVICE = 2,   /* no usable GPU / HIP runtime failure at init     */
+  GT4HIP_ENOMEM = 3,      /* device or host allocation failed                */
+  GT4HIP_ERULE = 4,       /* rule not allowed for this operation (the reference returns 1:
+                             src/glistcompare.c:518-523, :622-627)           */
+  GT4HIP_EHIP = 5,        /* a HIP call or kernel failed                     */
+  GT4HIP_EWORDLEN = 6,    /* lists of different word length                  */
+  GT4HIP_EINTERNAL = 7,   /* in-kernel consistency check tripped             */
+  GT4HIP_ECALLBACK = 8    /* (internal) walk stopped by the caller's callback */
+};
+
+/* enum Rules of the reference, src/glistcompare.c:45-54 (same numeric values) */
+enum {
+  GT4HIP_RULE_DEFAULT = 0,
+  GT4HIP_RULE_ADD = 1,
+  GT4HIP_RULE_SUBTRACT = 2,
+  GT4HIP_RULE_MIN = 3,
+  GT4HIP_RULE_MAX = 4,
+  GT4HIP_RULE_FIRST = 5,
+  GT4HIP_RULE_SECOND = 6,
+  GT4HIP_RULE_NUMBER = 7
+};
+
+/* the four outputs of compare_wordmaps, src/glistcompare.c:814-834; also the index order */
+enum {
+  GT4HIP_OP_UNION = 1,   /* index 0: <out>_<k>_union.list   */
+  GT4HIP_OP_INTRSEC = 2, /* index 1: <out>_<k>_intrsec.list */
+  GT4HIP_OP_DIFF1 = 4,   /* index 2: <out>_<k>_0_diff1.list */
+  GT4HIP_OP_DIFF2 = 8    /* index 3: <out>_<k>_0_diff2.list */
+};
+
+typedef struct gt4hip_context gt4hip_context;
+typedef struct gt4hip_list gt4hip_list;
+
+/* ---------------------------------------------------------------- (i) init / teardown */
+
+/* Binds a context to HIP device `device` (>= 0), creating its stream and workspace. */
+int gt4hip_create (int device, gt4hip_context **ctx);
+void gt4hip_destroy (gt4hip_context *ctx);
+/* Message of the last failure on this context (or of the last failed gt4hip_create when ctx is
+ * NULL).  Valid until the next call on the same context. */
+const char *gt4hip_last_error (const gt4hip_context *ctx);
+const char *gt4hip_strerror (int code);
+/* Number of HIP devices visible; 0 when there is none or the runtime is unusable. */
+int gt4hip_device_count (void);
+/* "name|gcnArch|CUs|HBM bytes" of the context's device, for logs. */
+const char *gt4hip_device_info (const gt4hip_context *ctx);
+
+/* ---------------------------------------------------------------- lists in HBM */
+
+/* Copies n_words packed records from host memory (pageable or pinned) into a new HBM list.
+ * Replaces gt4_word_map_new's mmap (src/word-map.c:165-241) as the way a list becomes readable. */
+int gt4hip_list_upload (gt4hip_context *ctx, const void *host_records, uint64_t n_words,
+                        uint32_t word_length, gt4hip_list **out);
+/* Wraps records already in device memory (16-byte aligned); not freed by gt4hip_list_free. */
+int gt4hip_list_wrap (gt4hip_context *ctx, void *device_records, uint64_t n_words,
+                      uint32_t word_length, gt4hip_list **out);
+/* Uninitialised list with room for `capacity` records (n_words = capacity until set). */
+int gt4hip_list_alloc (gt4hip_context *ctx, uint64_t capacity, uint32_t word_length, gt4hip_list **out);
+/* A view of records [first, first+count) of `list` (shares storage; used for key-range shards). */
+int gt4hip_list_slice (gt4hip_context *ctx, const gt4hip_list *list, uint64_t first, uint64_t count,
+                       gt4hip_list **out);
+/* Copies the records back to host memory (n_words * 12 bytes). */
+int gt4hip_list_download (gt4hip_context *ctx, const gt4hip_list *list, void *host_records);
+/* Copies records [first, first+count) back to host memory. */
+int gt4hip_list_download_range (gt4hip_context *ctx, const gt4hip_list *list, uint64_t first,
+                                uint64_t count, void *host_records);
+void gt4hip_list_free (gt4hip_list *list);
+
+uint64_t gt4hip_list_n_words (const gt4hip_list *list);      /* GT4WordSListInstance.num_words   */
+uint32_t gt4hip_list_word_length (const gt4hip_list *list);  /* GT4WordSListInstance.word_length */
+void *gt4hip_list_device_ptr (const gt4hip_list *list);
+int gt4hip_list_set_n_words (gt4hip_list *list, uint64_t n_words);
+/* Sum of counts (GT4WordSListInstance.sum_counts), computed on the device. */
+int gt4hip_list_sum_counts (gt4hip_context *ctx, const gt4hip_list *list, uint64_t *sum);
+/* 1 if keys are strictly ascending (the precondition of every merge below), else 0. */
+int gt4hip_list_is_sorted (gt4hip_context *ctx, const gt4hip_list *list, int *sorted);
+/* Index of the first record with key >= `key` (binary search on the device; shard splitters). */
+int gt4hip_list_lower_bound (gt4hip_context *ctx, const gt4hip_list *list, uint64_t key, uint64_t *index);
+/* GT4WordSArray get_word(idx), src/word-array-sorted.h:41-49 */
+int gt4hip_list_get_word (gt4hip_context *ctx, const gt4hip_list *list, uint64_t idx, uint64_t *word,
+                          uint32_t *count);
+
+/* ---------------------------------------------------------------- (ii) pair operation */
+
+/* Arguments of compare_wordmaps (src/glistcompare.c:789-790), minus the file naming. */
+typedef struct {
+  uint32_t ops;            /* mask of GT4HIP_OP_*: which of the four outputs to produce      */
+  int32_t rule;            /* GT4HIP_RULE_*; DEFAULT resolves per output as the reference does */
+  uint32_t cutoff;         /* -c / --cutoff (default 1)                                       */
+  int32_t subtract;        /* -du: diff1 keeps keys with equal counts (src/glistcompare.c:480) */
+  uint32_t count_override; /* the integer given to -r (RULE_NUMBER)                           */
+  int32_t count_only;      /* --count_only: totals only, no records materialised              */
+} gt4hip_compare_params;
+
+typedef struct {
+  uint64_t n_words[4];     /* records per output (header n_words), 0 for outputs not requested */
+  uint64_t total_count[4]; /* sum of counts per output (header total_count)                    */
+  /* In: NULL, or a caller-provided list (gt4hip_list_alloc) with enough capacity to receive the
+   * output.  Out: the output records (a new list when NULL was passed; NULL for count_only and
+   * for outputs not requested).  Worst-case capacities: union na+nb, intrsec min(na,nb),
+   * diff1 na, diff2 nb. */
+  gt4hip_list *out[4];
+  double merge_kernel_ms;  /* device time of the merge kernel alone (HIP events on the stream)  */
+  double device_ms;        /* device time of everything the call enqueued                        */
+  uint64_t merge_tiles;    /* tiles the merge kernel processed                                   */
+} gt4hip_compare_result;
+
+/* One pass over the merged key sequence of a and b producing up to four outputs
+ * (compare_wordmaps hot loop, src/glistcompare.c:843-905). */
+int gt4hip_compare (gt4hip_context *ctx, const gt4hip_list *a, const gt4hip_list *b,
+                    const gt4hip_compare_params *params, gt4hip_compare_result *result);
+
+/* ---------------------------------------------------------------- (iii) N-way operations */
+
+typedef struct {
+  uint64_t n_words;
+  uint64_t total_count;
+  gt4hip_list *out;        /* as gt4hip_compare_result.out: optional in, result out */
+  double device_ms;
+} gt4hip_multi_result;
+
+/* union_multi, src/glistcompare.c:500-603: rule in {DEFAULT(=ADD), ADD, MAX, NUMBER}, cutoff
+ * applied to the RESULTING count.  Empty lists are skipped. */
+int gt4hip_union_multi (gt4hip_context *ctx, const gt4hip_list *const lists[], uint32_t n_lists,
+                        uint32_t cutoff, int32_t rule, uint32_t count_override, int32_t count_only,
+                        gt4hip_multi_result *result);
+/* intersect_multi, src/glistcompare.c:605-717: rule in {DEFAULT(=MIN), MIN, MAX, ADD, NUMBER}. */
+int gt4hip_intersect_multi (gt4hip_context *ctx, const gt4hip_list *const lists[], uint32_t n_lists,
+                            uint32_t cutoff, int32_t rule, uint32_t count_override, int32_t count_only,
+                            gt4hip_multi_result *result);
+
+/* Per-key count table of an N-way union: for every distinct key ascending, counts[j] = count in
+ * list j or 0 (what gt4_union hands to its callback, src/set-operations.c:161-179).
+ * keys_out: n_keys u64; counts_out: n_keys * n_lists u32, row-major.  Both are device buffers
+ * owned by the result; release with gt4hip_table_free. */
+typedef struct {
+  uint64_t n_keys;
+  uint32_t n_lists;
+  void *device_keys;
+  void *device_counts;
+} gt4hip_count_table;
+int gt4hip_union_table (gt4hip_context *ctx, const gt4hip_list *const lists[], uint32_t n_lists,
+                        gt4hip_count_table *table);
+/* Copies rows [first, first+count) of the table to host memory. */
+int gt4hip_table_download (gt4hip_context *ctx, const gt4hip_count_table *table, uint64_t first,
+                           uint64_t count, uint64_t *host_keys, uint32_t *host_counts);
+void gt4hip_table_free (gt4hip_count_table *table);
+
+/* ---------------------------------------------------------------- synthetic lists (bench) */
+
+/* Fills `list` (capacity >= n) with n strictly ascending keys < 4^word_length and counts in
+ * [1, max_count]: record i gets key i*stride + (hash(seed,i) mod stride) with
+ * stride = floor(keyspace / n); counts from hash(seed+1,i).  Same (seed, n, word_length) =>
+ * same list on every device (tests regenerate it on the CPU). */
+int gt4hip_generate (gt4hip_context *ctx, gt4hip_list *list, uint64_t n, uint64_t seed, uint32_t max_count);
+/* General form: key_i = (i*stride + hash(key_seed,i) mod stride) * mult + add with
+ * stride = floor(keyspace / mult / n) and add < mult, counts from hash(count_seed,i).  Lists made
+ * with different `add` under one `mult` are disjoint; lists sharing key_seed share keys.  The
+ * bench builds A = S u PA, B = S' u PB from three disjoint residue classes this way, which fixes
+ * |A n B| = |S| exactly.  gt4hip_generate is (seed, seed+1, mult 1, add 0). */
+int gt4hip_generate_ex (gt4hip_context *ctx, gt4hip_list *list, uint64_t n, uint64_t key_seed, uint64_t count_seed,
+                        uint32_t max_count, uint64_t mult, uint64_t add);
+
+/* Blocks until everything enqueued on the context's stream has finished. */
+int gt4hip_synchronize (gt4hip_context *ctx);
+
+/* Tuning / debugging knobs (not part of the reference surface):
+ *   "two_pass" = 1  count + scan + write instead of the single-pass look-back kernel. */
+int gt4hip_set_option (gt4hip_context *ctx, const char *name, int64_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,70 @@
+"""Helpers shared by the GPU parity tests."""
+from __future__ import annotations
+
+import numpy as np
+
+from genometester4_amd.listio import make_records
+
+MERGE_TILE = None  # filled lazily from the header the kernels were built with
+
+
+def merge_tile():
+    """Nominal merge tile size (MERGE_NT * MERGE_VT - 1) parsed from the kernel header."""
+    global MERGE_TILE
+    if MERGE_TILE is None:
+        import os
+        import re
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        txt = open(os.path.join(root, "genometester4_amd", "csrc", "gt4hip_internal.h")).read()
+        nt = int(re.search(r"MERGE_NT\s*=\s*(\d+)", txt).group(1))
+        vt = int(re.search(r"MERGE_VT\s*=\s*(\d+)", txt).group(1))
+        MERGE_TILE = nt * vt - 1
+    return MERGE_TILE
+
+
+def random_pair(seed, n_universe, p_a, p_b, k=16, max_count=8, special=True):
+    """Shared-universe pair: controlled overlap, strictly ascending unique keys."""
+    rng = np.random.default_rng(seed)
+    limit = (1 << (2 * k)) if k < 32 else (1 << 64)
+    if limit <= (1 << 63):
+        keys = np.unique(rng.integers(0, limit, size=n_universe, dtype=np.uint64))
+    else:
+        keys = np.unique(rng.integers(0, 1 << 63, size=n_universe, dtype=np.uint64) * np.uint64(2) +
+                         rng.integers(0, 2, size=n_universe, dtype=np.uint64))
+    in_a = rng.random(len(keys)) < p_a
+    in_b = rng.random(len(keys)) < p_b
+    ka, kb = keys[in_a], keys[in_b]
+    ca = rng.integers(1, max_count + 1, size=len(ka), dtype=np.uint32)
+    cb = rng.integers(1, max_count + 1, size=len(kb), dtype=np.uint32)
+    if special and len(ca) > 8 and len(cb) > 8:
+        # a few wrap-around and zero counts so that "count != 0" / u32 wrap paths are exercised
+        ca[rng.integers(0, len(ca), 4)] = 0xFFFFFFFF
+        cb[rng.integers(0, len(cb), 4)] = 0xFFFFFFFF
+        ca[rng.integers(0, len(ca), 2)] = 0
+        cb[rng.integers(0, len(cb), 2)] = 0
+    return make_records(ka, ca), make_records(kb, cb)
+
+
+_M1 = np.uint64(0x9E3779B97F4A7C15)
+_M2 = np.uint64(0xBF58476D1CE4E5B9)
+_M3 = np.uint64(0x94D049BB133111EB)
+
+
+def _mix64(x):
+    x = x + _M1
+    x = (x ^ (x >> np.uint64(30))) * _M2
+    x = (x ^ (x >> np.uint64(27))) * _M3
+    return x ^ (x >> np.uint64(31))
+
+
+def generate_cpu(n, seed, word_length, max_count=8, count_seed=None, mult=1, add=0):
+    """numpy restatement of k_generate (gt4hip_generate[_ex]): same parameters => same list."""
+    if count_seed is None:
+        count_seed = seed + 1
+    with np.errstate(over="ignore"):
+        i = np.arange(n, dtype=np.uint64)
+        space = (1 << 64) if word_length == 32 else (1 << (2 * word_length))
+        stride = np.uint64(min(space // mult // n, 0xFFFFFFFFFFFFFFFF))
+        key = (i * stride + _mix64(np.uint64(seed) ^ (i * np.uint64(0x2545F4914F6CDD1D))) % stride) * np.uint64(mult) + np.uint64(add)
+        cnt = np.uint64(1) + _mix64(np.uint64(count_seed) ^ (i * _M1)) % np.uint64(max_count)
+    return make_records(key, cnt.astype(np.uint32))

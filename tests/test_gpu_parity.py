@@ -1,0 +1,234 @@
+"""GPU parity: the HIP path (through the C ABI, libgt4hip.so) against the reference's golden
+outputs and against the CPU oracle on seeded inputs.  Bit-exact: integer/byte work only."""
+import numpy as np
+import pytest
+
+import golden_util as G
+import gpu_util as U
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+CASES, INPUTS, OUTPUTS = G.load()
+FILE_CASES = [c for c in CASES if c["tool"] == "glistcompare" and c["exit"] == 0 and c["files"]]
+COUNT_CASES = [c for c in CASES if c["tool"] == "glistcompare" and c["exit"] == 0 and "--count_only" in c["argv"]]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from genometester4_amd import capi
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def _gpu_case(ctx, case, count_only=False):
+    """Runs what the CLI would run for this argv; returns ({file: bytes}, [(n, total)...])."""
+    p = G.parse_argv(case["argv"])
+    lists = [G.input_records(INPUTS, f) for f in p["files"]]
+    k = lists[0][1]
+    dev = [ctx.upload(r, k) for r, _ in lists]
+    files, stats = {}, []
+    if len(dev) == 2:
+        st, out, _ = ctx.compare(dev[0], dev[1], p["ops"], p["rule"], p["cutoff"], p["subtract"], p["count_override"], count_only)
+        for bit in sorted(st):
+            n, total = st[bit]
+            stats.append((n, total))
+            if not count_only:
+                recs = out[bit].download()
+                assert len(recs) == n
+                files["%s_%d_%s.list" % (p["out"], k, G.OP_FILES[bit])] = G.list_file_bytes(k, n, total, recs)
+    else:
+        for bit, fn, name in ((1, ctx.union_multi, "union"), (2, ctx.intersect_multi, "intrsec")):
+            if not p["ops"] & bit:
+                continue
+            rc, n, total, out = fn(dev, p["cutoff"], p["rule"], p["count_override"], count_only)
+            assert rc == 0
+            stats.append((n, total))
+            if not count_only:
+                files["%s_%d_%s.list" % (p["out"], k, name)] = G.list_file_bytes(k, n, total, out.download())
+    return files, stats
+
+
+@pytest.mark.parametrize("case", FILE_CASES, ids=[c["id"] for c in FILE_CASES])
+def test_gpu_reproduces_reference_files(ctx, case):
+    files, _ = _gpu_case(ctx, case)
+    assert sorted(files) == sorted(case["files"])
+    for name, data in files.items():
+        assert data == bytes(OUTPUTS["%s/%s" % (case["id"], name)]), name
+
+
+@pytest.mark.parametrize("case", COUNT_CASES, ids=[c["id"] for c in COUNT_CASES])
+def test_gpu_count_only_matches_reference_stdout(ctx, case):
+    _, stats = _gpu_case(ctx, case, count_only=True)
+    assert "".join("NUnique\t%d\nNTotal\t%d\n" % s for s in stats) == case["stdout"]
+
+
+def test_gpu_multi_rule_rejection(ctx):
+    from genometester4_amd import capi
+    recs = [ctx.upload(INPUTS["M%d" % j][0], 8) for j in range(4)]
+    for c in CASES:
+        if c["id"].startswith("multi_r") and c["exit"] == 1 and "Invalid rule" in c["stderr"]:
+            p = G.parse_argv(c["argv"])
+            fn = ctx.union_multi if p["ops"] & 1 else ctx.intersect_multi
+            assert fn(recs, p["cutoff"], p["rule"], p["count_override"])[0] == capi.ERULE
+
+
+def _check_pair(ctx, a, b, ops, rule=0, cutoff=1, subtract=0, ovr=1, k=16):
+    da, db = ctx.upload(a, k), ctx.upload(b, k)
+    exp = O.compare(a, b, ops, rule, cutoff, subtract, ovr)
+    st, out, _ = ctx.compare(da, db, ops, rule, cutoff, subtract, ovr)
+    for bit, (n, total, recs) in exp.items():
+        assert st[bit] == (n, total), "op %d stats" % bit
+        got = out[bit].download()
+        assert got.tobytes() == recs.tobytes(), "op %d records" % bit
+    st2, _, _ = ctx.compare(da, db, ops, rule, cutoff, subtract, ovr, count_only=True)
+    assert st2 == st
+
+
+@pytest.mark.parametrize("rule", range(8))
+@pytest.mark.parametrize("cutoff", [0, 1, 3])
+def test_random_pairs_all_rules(ctx, rule, cutoff):
+    a, b = U.random_pair(100 + rule * 7 + cutoff, 60000, 0.6, 0.5)
+    for sub in (0, 1):
+        _check_pair(ctx, a, b, 15, rule, cutoff, sub, ovr=5)
+
+
+@pytest.mark.parametrize("ops", [1, 2, 4, 8, 3, 5, 12, 10])
+def test_op_subsets(ctx, ops):
+    a, b = U.random_pair(7, 40000, 0.5, 0.7)
+    _check_pair(ctx, a, b, ops, cutoff=2)
+
+
+def test_tile_boundary_sizes(ctx):
+    """Sizes straddling the merge tile; identical lists put a matched pair on every boundary."""
+    T = U.merge_tile()
+    rng = np.random.default_rng(5)
+    for n in (1, 2, T // 2 - 1, T // 2, T // 2 + 1, T - 1, T, T + 1, 2 * T, 3 * T + 1, 10 * T - 1):
+        keys = np.unique(rng.integers(0, 1 << 40, size=n, dtype=np.uint64))
+        a = U.make_records(keys, rng.integers(1, 9, size=len(keys), dtype=np.uint32))
+        b = U.make_records(keys, rng.integers(1, 9, size=len(keys), dtype=np.uint32))
+        _check_pair(ctx, a, b, 15, k=20)          # identical key sets
+        _check_pair(ctx, a, b[::2], 15, k=20)     # every other key shared
+        _check_pair(ctx, a[: n // 3], b, 15, k=20)
+
+
+def test_empty_and_ragged(ctx):
+    a, b = U.random_pair(11, 50000, 0.9, 0.02)
+    empty = a[:0]
+    _check_pair(ctx, empty, empty, 15)
+    _check_pair(ctx, a, empty, 15)
+    _check_pair(ctx, empty, b, 15)
+    _check_pair(ctx, a, b, 15)
+    _check_pair(ctx, b, a, 15)
+    # disjoint ranges: all of A below all of B, and interleaved-by-parity
+    lo = U.make_records(np.arange(1000, dtype=np.uint64), np.ones(1000, np.uint32))
+    hi = U.make_records(np.arange(5000, 9000, dtype=np.uint64), np.full(4000, 2, np.uint32))
+    _check_pair(ctx, lo, hi, 15)
+    _check_pair(ctx, hi, lo, 15)
+    ev = U.make_records(np.arange(0, 20000, 2, dtype=np.uint64), np.ones(10000, np.uint32))
+    od = U.make_records(np.arange(1, 20000, 2, dtype=np.uint64), np.ones(10000, np.uint32))
+    _check_pair(ctx, ev, od, 15)
+
+
+def test_k32_full_range_keys(ctx):
+    a, b = U.random_pair(3, 30000, 0.6, 0.6, k=32)
+    top = U.make_records([0xFFFFFFFFFFFFFFFE, 0xFFFFFFFFFFFFFFFF], [3, 4])
+    a = np.concatenate([a[a["key"] < 0xFFFFFFFFFFFFFFFE], top])
+    b = np.concatenate([b[b["key"] < 0xFFFFFFFFFFFFFFFE], top[1:]])
+    _check_pair(ctx, a, b, 15, k=32)
+    _check_pair(ctx, a, b, 15, rule=1, cutoff=0, k=32)
+
+
+def test_two_pass_path_equals_lookback(ctx):
+    a, b = U.random_pair(21, 80000, 0.6, 0.6)
+    ctx.set_option("two_pass", 1)
+    try:
+        _check_pair(ctx, a, b, 15, cutoff=2)
+    finally:
+        ctx.set_option("two_pass", 0)
+
+
+@pytest.mark.parametrize("rule", [0, 1, 3, 4, 7])
+@pytest.mark.parametrize("cutoff", [0, 1, 4])
+def test_multi_random(ctx, rule, cutoff):
+    rng = np.random.default_rng(rule * 10 + cutoff)
+    keys = np.unique(rng.integers(0, 1 << 30, size=50000, dtype=np.uint64))
+    lists = []
+    for j in range(5):
+        m = rng.random(len(keys)) < (0.2 + 0.15 * j)
+        c = rng.integers(0, 6, size=int(m.sum()), dtype=np.uint32)   # zero counts included (MINZ fold)
+        lists.append(U.make_records(keys[m], c))
+    lists.insert(2, lists[0][:0])  # an empty member
+    dev = [ctx.upload(x, 16) for x in lists]
+    for fn_g, fn_o, ls_g, ls_o in ((ctx.union_multi, O.union_multi, dev, lists),
+                                   (ctx.intersect_multi, O.intersect_multi, dev, lists),
+                                   (ctx.intersect_multi, O.intersect_multi, dev[:2] + dev[3:], lists[:2] + lists[3:])):
+        rc_o, n_o, t_o, r_o = fn_o(ls_o, cutoff, rule, 9)
+        rc_g, n_g, t_g, out = fn_g(ls_g, cutoff, rule, 9)
+        assert (rc_g != 0) == (rc_o != 0)
+        if rc_o:
+            continue
+        assert (n_g, t_g) == (n_o, t_o)
+        assert out.download().tobytes() == r_o.tobytes()
+        rc_c, n_c, t_c, _ = fn_g(ls_g, cutoff, rule, 9, True)
+        assert (n_c, t_c) == (n_o, t_o)
+
+
+def test_union_table_matches_oracle_walk(ctx):
+    lists = [INPUTS["M%d" % j][0] for j in range(4)]
+    keys, counts = ctx.union_table([ctx.upload(x, 8) for x in lists])
+    _, rows = O.union_walk(lists)
+    rows = [r for r in rows if any(r[1:])]  # the reference's duplicate all-zero visits are a host-walk quirk
+    assert [int(k) for k in keys] == [r[0] for r in rows]
+    assert counts.tolist() == [list(r[1:]) for r in rows]
+
+
+def test_list_utilities(ctx):
+    a, _ = U.random_pair(2, 20000, 0.7, 0.1, special=False)
+    d = ctx.upload(a, 16)
+    assert d.n_words == len(a) and d.word_length == 16
+    assert d.sum_counts() == int(a["count"].astype(np.uint64).sum())
+    assert d.is_sorted()
+    bad = a.copy()
+    bad[100], bad[101] = a[101], a[100]
+    assert not ctx.upload(bad, 16).is_sorted()
+    for key in (0, int(a["key"][17]), int(a["key"][17]) + 1, 1 << 40):
+        assert d.lower_bound(key) == int(np.searchsorted(a["key"], np.uint64(key), "left"))
+    assert d.get_word(123) == (int(a["key"][123]), int(a["count"][123]))
+    assert d.slice(10, 50).download().tobytes() == a[10:60].tobytes()
+
+
+def test_generator_matches_cpu_restatement(ctx):
+    for k, n, seed in ((25, 100003, 1), (32, 50000, 9), (16, 1 << 16, 3)):
+        d = ctx.alloc(n, k)
+        ctx.generate(d, n, seed, 8)
+        assert d.download().tobytes() == U.generate_cpu(n, seed, k).tobytes()
+        assert d.is_sorted()
+    d = ctx.alloc(70000, 25)
+    ctx.generate_ex(d, 70000, 5, 77, 8, 3, 2)
+    assert d.download().tobytes() == U.generate_cpu(70000, 5, 25, 8, 77, 3, 2).tobytes()
+
+
+def test_medium_generated_pair_properties(ctx):
+    """2 x 2e7 records generated in HBM: oracle parity + size-independent identities."""
+    n = 20_000_000
+    a, b = ctx.alloc(n, 25), ctx.alloc(n, 25)
+    ctx.generate(a, n, 1, 8)
+    ctx.generate(b, n, 1, 8)          # same keys ...
+    st, out, _ = ctx.compare(a, b, 3)
+    assert st[1][0] == n and st[2][0] == n          # A == B: union = intersection = A
+    sa = a.sum_counts()
+    assert st[1][1] == 2 * sa and st[2][1] == sa    # ADD doubles, MIN keeps
+    assert out[2].download_range(0, 1000).tobytes() == a.download_range(0, 1000).tobytes()
+    del out
+    ctx.generate(b, n, 2, 8)          # ... then an independent list
+    st, out, _ = ctx.compare(a, b, 15, cutoff=1)
+    nu, ni, nd1, nd2 = (st[x][0] for x in (1, 2, 4, 8))
+    assert nu == 2 * n - ni and nd1 == n - ni and nd2 == n - ni
+    assert all(out[x].is_sorted() for x in (1, 2, 4, 8))
+    ha, hb = a.download(), b.download()
+    exp = O.compare(ha, hb, 15)
+    for bit in (1, 2, 4, 8):
+        assert st[bit] == exp[bit][:2]
+        assert out[bit].download().tobytes() == exp[bit][2].tobytes()
