@@ -402,14 +402,14 @@ static int run_pair (gt4hip_context *ctx, const uint32_t *A, uint64_t nA, const 
   if ((rc = grow (ctx, (void **) &ctx->part, &ctx->part_bytes, (size_t) (tiles + 1) * 16))) return rc;
   const bool two_pass = ctx->two_pass && !count_only;
   const bool need_desc = !count_only;
-  if (need_desc && (rc = grow (ctx, (void **) &ctx->desc, &ctx->desc_bytes, (size_t) tiles * 32))) return rc;
+  if (need_desc && (rc = grow (ctx, (void **) &ctx->desc, &ctx->desc_bytes, (size_t) tiles * 48))) return rc; /* agg u32[4][T] + excl u64[4][T] */
   if (two_pass) {
     const size_t nb = (size_t) ((tiles + 2047) / 2048) * 32;
     if ((rc = grow (ctx, (void **) &ctx->block_sums, &ctx->block_sums_bytes, nb))) return rc;
   }
   int grid = ctx->n_cus * merge_blocks_per_cu ();
   if (ctx->grid_override > 0) grid = (int) ctx->grid_override;
-  if ((uint64_t) grid > tiles) grid = (int) tiles;
+  if ((uint64_t) grid > tiles + 1) grid = (int) tiles + 1; /* + the scanner workgroup */
 
   PairOutputs outs;
   for (int s = 0; s < 4; s++) outs.rec[s] = (count_only || !dst) ? NULL : dst[s];
@@ -417,7 +417,7 @@ static int run_pair (gt4hip_context *ctx, const uint32_t *A, uint64_t nA, const 
   hipStream_t st = ctx->stream;
   HIPCHK (ctx, hipEventRecord (ctx->ev[0], st));
   HIPCHK (ctx, hipMemsetAsync (ctx->ctl, 0, sizeof (PairControl), st));
-  if (need_desc && !two_pass) HIPCHK (ctx, hipMemsetAsync (ctx->desc, 0, (size_t) tiles * 32, st));
+  if (need_desc && !two_pass) HIPCHK (ctx, hipMemsetAsync (ctx->desc, 0, (size_t) tiles * 48, st));
   HIPCHK (ctx, launch_partition (st, A, nA, B, nB, tiles, ctx->part));
   HIPCHK (ctx, hipEventRecord (ctx->ev[1], st));
   if (count_only) {

@@ -38,21 +38,23 @@ struct PairControl {
   unsigned long long total_count[4];
   unsigned int ticket;     /* dynamic tile counter */
   unsigned int error;      /* non-zero: a bounded spin gave up / consistency check tripped */
-  unsigned int pad[2];
+  unsigned int role;       /* first workgroup to arrive becomes the scanner */
+  unsigned int pad;
 };
 
 enum MergeMode : int {
   MODE_COUNT = 0,     /* totals only (--count_only), also pass 1 of the two-pass path: writes tile counts */
-  MODE_LOOKBACK = 1,  /* single pass: decoupled look-back gives each tile its output offsets            */
+  MODE_LOOKBACK = 1,  /* single pass: a scanner wavefront chains tile totals into output offsets          */
   MODE_OFFSETS = 2    /* pass 2 of the two-pass path: tile offsets already scanned                       */
 };
 
 /* Geometry of the merge kernel. */
-constexpr int MERGE_NT = 256;               /* threads per workgroup (4 wavefronts)      */
-constexpr int MERGE_VT = 7;                 /* merged items per thread; odd => LDS-conflict-free strides */
+constexpr int MERGE_NT = 512;               /* threads per workgroup (8 wavefronts)      */
+constexpr int MERGE_VT = 4;                 /* records per thread (one per lane per pass)  */
 constexpr int MERGE_CAP = MERGE_NT * MERGE_VT; /* LDS capacity in records                 */
 constexpr int MERGE_TILE = MERGE_CAP - 1;   /* nominal tile; pair fix-up makes it +-1    */
-constexpr int MERGE_WAVES_PER_SIMD = 3;     /* LDS admits 3 workgroups (12 waves) per CU; cap VGPRs to match */
+constexpr int MERGE_WAVES_PER_SIMD = 6;     /* single-output kernels: <= 80 VGPRs, 3 workgroups (24 waves) per CU */
+constexpr int MERGE_WAVES_PER_SIMD_GENERIC = 4; /* any-combination kernel: <= 128 VGPRs                     */
 
 hipError_t launch_partition (hipStream_t s, const uint32_t *A, uint64_t nA, const uint32_t *B, uint64_t nB,
                              uint64_t num_tiles, uint64_t *part);

@@ -8,11 +8,11 @@
  *   K1 k_partition    merge-path co-ranking: tile t starts at (a_t, b_t) with a_t + b_t = t*TILE,
  *                     "A first on ties"; a matching A/B pair is never split between tiles.
  *   K2 k_pair_merge   persistent workgroups pull tiles by ticket; per tile: coalesced loads of the
- *                     two record ranges -> LDS (SoA: 8-byte-aligned keys + counts), per-thread
- *                     merge-path search + serial merge of VT items in LDS, classification
- *                     {A only, B only, both}, up to four output predicates, packed block scan,
- *                     decoupled look-back for the tile's global output offsets, LDS-staged
- *                     compaction and coalesced record stores.
+ *                     two record ranges -> LDS (SoA: 8-byte-aligned keys + counts), one record per
+ *                     lane: rank in the other list by LDS binary search, classification
+ *                     {A only, B only, both}, up to four output predicates, wavefront ballots +
+ *                     popcount prefix for output slots; a scanner wavefront chains the tile totals
+ *                     into global output offsets; LDS-staged compaction, coalesced record stores.
  *   K3 k_scan_*       tile-count scan for the two-pass fallback.
  *   K0 k_generate     synthetic ascending lists written straight into HBM (bench only).
  */
@@ -109,43 +109,6 @@ __device__ __forceinline__ bool eval_stream (u32 kind, u32 fa, u32 fb, const Str
   return keep;
 }
 
-/* per-thread pass over its VT merged items for one stream: which are kept, and their count sum */
-template <int S, int VT>
-__device__ __forceinline__ void count_stream (u32 kinds, const u32 (&fa)[VT], const u32 (&fb)[VT], const PairParams &p, u32 &mask, u64 &sum)
-{
-  /* an empty volatile asm pins this body behind its wave-uniform branch: without it the compiler
-   * speculates all four streams' bodies into one straight-line block (3x the registers) */
-  asm volatile ("" ::: "memory");
-  const StreamCoef c = make_coef<S> (p);
-#pragma unroll
-  for (int i = 0; i < VT; i++) {
-    u32 f;
-    const bool keep = eval_stream<S> ((kinds >> (2 * i)) & 3u, fa[i], fb[i], c, f);
-    mask |= keep ? (1u << i) : 0u;
-    sum += keep ? f : 0u;
-  }
-}
-
-/* writes this thread's kept records of one stream into the LDS output view at slots pos, pos+1, ... */
-template <int S, int VT>
-__device__ __forceinline__ void scatter_stream (u32 kinds, u32 mask, u32 pos, const u64 (&key)[VT], const u32 (&fa)[VT],
-                                                const u32 (&fb)[VT], const PairParams &p, u32 *lds32)
-{
-  asm volatile ("" ::: "memory");
-  const StreamCoef c = make_coef<S> (p);
-#pragma unroll
-  for (int i = 0; i < VT; i++) {
-    u32 f;
-    eval_stream<S> ((kinds >> (2 * i)) & 3u, fa[i], fb[i], c, f);
-    if ((mask >> i) & 1u) {
-      lds32[3 * pos] = (u32) key[i];
-      lds32[3 * pos + 1] = (u32) (key[i] >> 32);
-      lds32[3 * pos + 2] = f;
-      pos++;
-    }
-  }
-}
-
 /* ------------------------------------------------------------------ K1: partition */
 
 /* Number of A records among the first `diag` records of merge(A, B) with A first on ties. */
@@ -208,276 +171,479 @@ __device__ __forceinline__ u64 wave_sum (u64 v)
   return v;
 }
 
-/* ------------------------------------------------------------------ look-back descriptors */
+/* ------------------------------------------------------------------ tile descriptors (chained scan) */
 
-/* One 64-bit word per (tile, stream): status in bits 63:62, value in bits 61:0.  Written and read
- * as single relaxed agent-scope 8-byte accesses: the value IS the flag, so no fence is needed
- * (cdna_hip_programming.md Guideline 16, form R2). */
-constexpr u64 DESC_AGG = 1ull << 62;    /* tile's own count is known          */
-constexpr u64 DESC_PREFIX = 2ull << 62; /* inclusive prefix over tiles 0..t   */
-constexpr u64 DESC_VALUE = (1ull << 62) - 1;
+/* Per output stream s and tile t, two words in device memory, zeroed before every launch:
+ *   agg[s][t]   u32: bit 31 = published, low bits = records the tile keeps in stream s
+ *   excl[s][t]  u64: bit 63 = published, low bits = records kept by tiles 0..t-1 (global offset)
+ * Workers publish agg; ONE scanner wavefront per stream walks agg in tile order and publishes
+ * excl.  Every word is written once by a single relaxed agent-scope store and read by relaxed
+ * agent-scope loads: value and flag travel in the same naturally aligned word, so no fence is
+ * needed (cdna_hip_programming.md Guideline 16, form R2). */
+constexpr u32 AGG_READY = 1u << 31;
+constexpr u64 EXCL_READY = 1ull << 63;
 
-__device__ __forceinline__ void desc_store (u64 *p, u64 v)
-{
-  __hip_atomic_store (p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-__device__ __forceinline__ u64 desc_load (u64 *p)
-{
-  return __hip_atomic_load (p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
+__device__ __forceinline__ void publish_u32 (u32 *p, u32 v) { __hip_atomic_store (p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void publish_u64 (u64 *p, u64 v) { __hip_atomic_store (p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ u32 peek_u32 (u32 *p) { return __hip_atomic_load (p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ u64 peek_u64 (u64 *p) { return __hip_atomic_load (p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 constexpr u32 SPIN_LIMIT = 1u << 22; /* bounded: ~seconds; sets ctl->error instead of hanging */
+constexpr int SCAN_ROWS = 16;        /* rows of 64 tiles a scanner wavefront keeps in flight */
 
-/* ------------------------------------------------------------------ K2: tile merge */
+/* The scanner: one wavefront per stream.  Loads SCAN_ROWS x 64 tile counts at once (so that its
+ * rate is set by L2 bandwidth, not by one round trip per 64 tiles), waits for stragglers, scans,
+ * publishes the exclusive offsets. */
+__device__ void scanner_wave (u32 *agg, u64 *excl, u64 num_tiles, PairControl *ctl, int lane)
+{
+  u64 carry = 0;
+  const u64 rows = (num_tiles + WAVE - 1) / WAVE;
+  for (u64 r0 = 0; r0 < rows; r0 += SCAN_ROWS) {
+    u32 v[SCAN_ROWS];
+#pragma unroll
+    for (int j = 0; j < SCAN_ROWS; j++) {
+      const u64 idx = (r0 + j) * WAVE + lane;
+      v[j] = idx < num_tiles ? peek_u32 (&agg[idx]) : AGG_READY;
+    }
+#pragma unroll
+    for (int j = 0; j < SCAN_ROWS; j++) {
+      if (r0 + j >= rows) break;
+      const u64 idx = (r0 + j) * WAVE + lane;
+      /* Publish every tile as soon as all tiles before it have reported -- never wait for the
+       * whole row: a worker may be blocked on tile t's offset while it still holds the ticket of
+       * tile t+1 (same row). */
+      u32 published = 0, spins = 0, incl = 0;
+      for (;;) {
+        const u64 ready = __ballot ((v[j] & AGG_READY) != 0);
+        const u32 f = ~ready ? (u32) __ffsll ((long long) ~ready) - 1u : (u32) WAVE; /* length of the ready prefix */
+        if (f > published) {
+          const u32 val = (u32) lane < f ? (v[j] & ~AGG_READY) : 0u;
+          incl = val;
+#pragma unroll
+          for (int d = 1; d < WAVE; d <<= 1) {
+            const u32 o = __shfl_up (incl, d, WAVE);
+            if (lane >= d) incl += o;
+          }
+          if ((u32) lane >= published && (u32) lane < f && idx < num_tiles) publish_u64 (&excl[idx], EXCL_READY | (carry + incl - val));
+          published = f;
+        }
+        if (f == (u32) WAVE) break;
+        if (++spins > SPIN_LIMIT) {
+          if (lane == 0) atomicOr (&ctl->error, 4u);
+          return;
+        }
+        if (spins > 2) __builtin_amdgcn_s_sleep (2);
+        if (!(v[j] & AGG_READY)) v[j] = peek_u32 (&agg[idx]);
+      }
+      carry += __shfl (incl, WAVE - 1, WAVE);
+    }
+  }
+}
 
-template <int NT, int VT>
-struct MergeShared {
-  static constexpr int CAP = NT * VT;
-  /* input view: keys[CAP] (u64, 8-byte aligned) followed by counts[CAP] (u32);
-   * output view (after the merge, same bytes): 3*CAP dwords of packed records */
-  u64 keys[CAP];
+/* ------------------------------------------------------------------ K2: tile merge by rank search */
+
+/*
+ * Persistent workgroups; each processes one merge-path tile (<= CAP records of A and B together)
+ * at a time, tiles handed out in index order by an atomic ticket:
+ *
+ *  phase 0  the tile's two packed record ranges, fetched one tile AHEAD into registers with
+ *           coalesced dword loads, go to LDS as SoA (keys[] 8-byte aligned, counts[]); A records
+ *           first, then B records.  The next tile's loads are issued right away and stay in
+ *           flight during phases 1-3.
+ *  phase 1  one record per lane (striped: consecutive lanes hold consecutive sorted keys, so the
+ *           64 binary searches of a wavefront walk nearly the same LDS addresses -> broadcasts, few
+ *           bank conflicts): rank r = number of records of the OTHER list with a smaller key,
+ *           match test at r, classification {A only, B only, both}, per-stream keep predicate;
+ *           the keep flags of each 64-record chunk go to LDS as one wavefront ballot.
+ *  phase 2  one wavefront per stream: popcount-scan of the chunk ballots, tile total published
+ *           for the scanner wavefront (chained scan, above).
+ *  phase 3  output slot of a kept record = (kept records before it in its own list)
+ *           + (kept records of the other list before its rank) -- two ballot/prefix lookups, no
+ *           sort; records are scattered into an LDS staging area in output order and leave with
+ *           coalesced dword stores at the tile's global offset.
+ *
+ * Single-output kernels (OPS = union or intersection) DEFER the write-out of tile i until tile
+ * i+1 has been ranked: by then the scanner has long published tile i's offset, so no wavefront
+ * ever waits on the chain.  The any-combination kernel (OPS = 0) writes out in place (staging
+ * aliases the dead input view) and waits for its offset right after publishing its totals.
+ *
+ * Keys are unique inside a list (reference precondition), so "both" pairs are found by the match
+ * test alone; the B record of a pair keeps nothing (its A partner carries both counts).
+ */
+template <int NT, int IPT, int OPS>
+struct RankShared {
+  static constexpr int CAP = NT * IPT;
+  static constexpr int NCH = CAP / WAVE;
+  /* deferred staging: an intersection keeps at most one record per pair, a union at most CAP */
+  static constexpr int STAGE_DW = OPS == 2 ? 3 * (CAP / 2 + 1) : (OPS == 1 ? 3 * CAP : 4);
+  u64 keys[CAP];          /* input view; OPS == 0: the output view (3 * CAP dwords) starts here too */
   u32 cnts[CAP];
-  u64 wave_tot[NT / WAVE];
-  u64 tile_excl[4];   /* global exclusive offset of this tile per stream */
-  u32 tile;           /* ticket */
+  u32 stage[STAGE_DW];
+  u64 kmask[4][NCH + 1];  /* keep-flag ballot per 64-record chunk, per stream (+1: empty sentinel chunk) */
+  u32 cpre[4][NCH + 1];   /* exclusive prefix of popcount(kmask) over chunks, per stream               */
+  u64 excl[4];            /* global exclusive output offset of the tile being written out              */
+  u32 tot[4];             /* records the current tile keeps, per stream                                */
+  u32 tick[2];            /* ticket ring: tile of the next iteration / the one after                   */
 };
 
-template <int NT, int VT, int MODE>
-__global__ __launch_bounds__ (NT, MERGE_WAVES_PER_SIMD) void k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 nB,
-                                                      const u64 *__restrict__ part, u64 num_tiles, PairParams p,
-                                                      PairOutputs outs, u64 *desc, PairControl *ctl)
+/* number of kept records among the concatenated tile positions [0, z) */
+__device__ __forceinline__ u32 kept_before (const u64 *km, const u32 *cp, u32 z)
 {
-  constexpr int CAP = NT * VT;
+  const u32 c = z >> 6;
+  return cp[c] + (u32) __popcll (km[c] & ((1ull << (z & 63u)) - 1ull));
+}
+
+template <int S, int NT, int IPT, int OPS>
+__device__ __forceinline__ void scatter_stream (RankShared<NT, IPT, OPS> &sh, u32 *dst32, const PairParams &p, u32 na, int lane, int wid,
+                                                const u64 (&key)[IPT], const u32 (&fa)[IPT], const u32 (&fb)[IPT], const u32 (&meta)[IPT])
+{
   constexpr int NW = NT / WAVE;
-  __shared__ MergeShared<NT, VT> sh;
+  const StreamCoef c = make_coef<S> (p);
+  const u32 pna = kept_before (sh.kmask[S], sh.cpre[S], na);
+#pragma unroll
+  for (int k = 0; k < IPT; k++) {
+    const u32 chunk = (u32) k * NW + (u32) wid;
+    const u64 m = sh.kmask[S][chunk];
+    if ((m >> lane) & 1ull) {
+      const u32 own = sh.cpre[S][chunk] + (u32) __popcll (m & ((1ull << lane) - 1ull));
+      const u32 r = meta[k] & 0xffffu;
+      const u32 z = ((meta[k] >> 18) & 1u) ? na + r : r;
+      const u32 slot = own + kept_before (sh.kmask[S], sh.cpre[S], z) - pna;
+      u32 f;
+      eval_stream<S> ((meta[k] >> 16) & 3u, fa[k], fb[k], c, f);
+      dst32[3 * slot] = (u32) key[k];
+      dst32[3 * slot + 1] = (u32) (key[k] >> 32);
+      dst32[3 * slot + 2] = f;
+    }
+  }
+}
+
+struct TileRange {
+  u64 a0, b0;
+  u32 na, nb;
+};
+
+__device__ __forceinline__ TileRange load_tile_range (const u64 *__restrict__ part, u64 tile)
+{
+  TileRange t;
+  t.a0 = part[2 * tile];
+  t.b0 = part[2 * tile + 1];
+  t.na = (u32) (part[2 * tile + 2] - t.a0);
+  t.nb = (u32) (part[2 * tile + 3] - t.b0);
+  return t;
+}
+
+/* OPS != 0 fixes the set of output streams at compile time (the common single-output calls get a
+ * kernel without the other streams' code and registers); OPS == 0 takes it from p.ops. */
+template <int NT, int IPT, int MODE, int OPS>
+__global__ __launch_bounds__ (NT, OPS ? MERGE_WAVES_PER_SIMD : MERGE_WAVES_PER_SIMD_GENERIC) void
+k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 nB, const u64 *__restrict__ part, u64 num_tiles,
+              PairParams p, PairOutputs outs, u64 *desc, PairControl *ctl)
+{
+  constexpr int CAP = NT * IPT;
+  constexpr int NW = NT / WAVE;
+  constexpr int NCH = CAP / WAVE;
+  constexpr int NLOAD = 3 * IPT;                 /* dwords each thread fetches per tile */
+  constexpr bool DEFER = (OPS == 1 || OPS == 2) && MODE != MODE_COUNT;
+  constexpr int S0 = OPS == 2 ? 1 : 0;           /* the stream of a single-output kernel */
+  static_assert (NW >= 4, "one wavefront per output stream in phase 2");
+  static_assert (NCH <= WAVE, "chunk scan is a single wavefront pass");
+  __shared__ RankShared<NT, IPT, OPS> sh;
   u32 *const lds32 = reinterpret_cast<u32 *> (&sh.keys[0]);
 
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
+  const u32 ops = OPS ? (u32) OPS : p.ops;
+  /* every "both" pair is evaluated at its A record, so A records always matter; B records only
+   * where a B-only key can be kept (union, diff2) */
+  const bool need_b = (ops & 9u) != 0;
 
-  u64 acc_sum0 = 0, acc_sum1 = 0, acc_sum2 = 0, acc_sum3 = 0; /* per-thread sums of emitted counts */
-  u64 blk_cnt[4] = { 0, 0, 0, 0 };                              /* thread 0: records emitted by this workgroup */
+  /* single pass: agg u32[4][T] then excl u64[4][T] inside desc (zeroed by the host) */
+  u32 *const agg = reinterpret_cast<u32 *> (desc);
+  u64 *const excl = desc + 2 * num_tiles; /* 4 * T u32 = 2 * T u64 */
 
-  for (;;) {
-    /* ---- ticket: tiles are claimed in index order, so every predecessor a look-back waits on
-     * belongs to a workgroup that is already running (no residency assumption). */
-    if (tid == 0) sh.tile = atomicAdd (&ctl->ticket, 1u);
+  if (MODE == MODE_LOOKBACK) {
+    /* role election: the first workgroup to arrive is running by definition, it becomes the scanner */
+    if (tid == 0) sh.tick[0] = atomicAdd (&ctl->role, 1u);
     __syncthreads ();
-    const u64 tile = sh.tile;
-    if (tile >= num_tiles) break;
+    const u32 role = sh.tick[0];
+    __syncthreads ();
+    if (role == 0) {
+      if (wid < 4 && ((ops >> wid) & 1u)) scanner_wave (agg + (u64) wid * num_tiles, excl + (u64) wid * num_tiles, num_tiles, ctl, lane);
+      return;
+    }
+  }
 
-    const u64 a0 = part[2 * tile], b0 = part[2 * tile + 1];
-    const u64 a1 = part[2 * tile + 2], b1 = part[2 * tile + 3];
-    const u32 na = (u32) (a1 - a0), nb = (u32) (b1 - b0), nt = na + nb;
+  u64 acc_sum0 = 0, acc_sum1 = 0, acc_sum2 = 0, acc_sum3 = 0; /* per-thread sums of kept counts */
+  u64 blk_cnt = 0;                                              /* lane 0 of wave s: records kept in stream s */
+
+  /* tickets: tiles are claimed in index order, so every tile the scanner waits on belongs to a
+   * workgroup that is already running (no residency assumption).  Two tickets are held: the tile
+   * being processed and the one whose records are being prefetched. */
+  if (tid == 0) {
+    sh.tick[0] = atomicAdd (&ctl->ticket, 1u);
+    sh.tick[1] = atomicAdd (&ctl->ticket, 1u);
+  }
+  __syncthreads ();
+  u64 cur = sh.tick[0];
+  TileRange tr = { 0, 0, 0, 0 };
+  u32 pre[NLOAD];
+
+  auto fetch = [&] (const TileRange &t) {
+    const u32 *__restrict__ srcA = A + 3 * t.a0;
+    const u32 *__restrict__ srcB = B + 3 * t.b0;
+    const u32 da = 3 * t.na, dt = 3 * (t.na + t.nb);
+#pragma unroll
+    for (int j = 0; j < NLOAD; j++) {
+      const u32 d = (u32) j * NT + (u32) tid;
+      u32 w = 0;
+      if (d < da) w = srcA[d];
+      else if (d < dt) w = srcB[d - da];
+      pre[j] = w;
+    }
+  };
+
+  if (cur < num_tiles) {
+    tr = load_tile_range (part, cur);
+    fetch (tr);
+  }
+  u64 prev_tile = 0;   /* DEFER: tile whose output is staged but not yet written */
+  u32 prev_tot = 0;
+  bool have_prev = false;
+  int it = 0;
+
+  while (cur < num_tiles) {
+    const u32 na = tr.na, nb = tr.nb, nt = na + nb;
     if (nt > (u32) CAP) {
       if (tid == 0) atomicOr (&ctl->error, 2u);
       break;
     }
-
-    /* ---- stage both record ranges into LDS, AoS dwords -> SoA (keys 8-byte aligned: an
-     * unaligned ds_read_b64 would replay at 64 cycles, Guideline 17) */
-    {
-      const u32 *__restrict__ srcA = A + 3 * a0;
-      for (u32 d = tid; d < 3 * na; d += NT) {
-        const u32 w = srcA[d];
+    /* ---- phase 0: registers -> LDS, AoS dwords -> SoA (an 8-byte key read at a 4-byte aligned
+     * LDS address would replay at 64 cycles, Guideline 17) */
+#pragma unroll
+    for (int j = 0; j < NLOAD; j++) {
+      const u32 d = (u32) j * NT + (u32) tid;
+      if (d < 3 * nt) {
         const u32 r = d / 3, f = d - 3 * r;
-        const u32 at = (f == 2) ? (2 * CAP + r) : (2 * r + f);
-        lds32[at] = w;
-      }
-      const u32 *__restrict__ srcB = B + 3 * b0;
-      for (u32 d = tid; d < 3 * nb; d += NT) {
-        const u32 w = srcB[d];
-        const u32 r = d / 3 + na, f = d % 3;
-        const u32 at = (f == 2) ? (2 * CAP + r) : (2 * r + f);
-        lds32[at] = w;
+        lds32[(f == 2) ? (2 * CAP + r) : (2 * r + f)] = pre[j];
       }
     }
-    __syncthreads ();
+    const u64 nxt = sh.tick[(it + 1) & 1];
+    __syncthreads (); /* B0 */
+    if (tid == 0) sh.tick[it & 1] = atomicAdd (&ctl->ticket, 1u);
+    TileRange tn = { 0, 0, 0, 0 };
+    if (nxt < num_tiles) {
+      tn = load_tile_range (part, nxt);
+      fetch (tn); /* in flight until the next iteration's phase 0 */
+    }
 
-    /* ---- per-thread merge path inside the tile */
-    const u64 *const keyA = sh.keys, *const keyB = sh.keys + na;
-    u32 diag = (u32) tid * VT;
-    if (diag > nt) diag = nt;
-    u32 ai, bi;
+    /* ---- phase 1: rank, classify, predicates */
+    u64 key[IPT];
+    u32 fa[IPT], fb[IPT], meta[IPT]; /* meta: rank | kind << 16 | is_a << 18 */
     {
-      u32 lo = diag > nb ? diag - nb : 0, hi = diag < na ? diag : na;
-      while (lo < hi) {
-        const u32 mid = (lo + hi) >> 1;
-        if (keyA[mid] <= keyB[diag - 1 - mid]) lo = mid + 1;
-        else hi = mid;
-      }
-      ai = lo;
-      bi = diag - lo;
-    }
-
-    /* ---- serial merge of VT items; classification per merged record.  Straight-line: every
-     * step does two count reads and one key read at selected (clamped) LDS indices. */
-    u64 item_key[VT];
-    u32 item_fa[VT], item_fb[VT];
-    u32 kinds = 0; /* 2 bits per item */
-    {
-      constexpr u32 LAST = (u32) CAP - 1;
-      bool have_prev = ai > 0;
-      u64 prev_a = sh.keys[have_prev ? ai - 1 : 0];
-      u64 ka = sh.keys[ai < LAST ? ai : LAST], kb = sh.keys[na + bi < LAST ? na + bi : LAST];
+      const StreamCoef c0 = make_coef<0> (p), c1 = make_coef<1> (p), c2 = make_coef<2> (p), c3 = make_coef<3> (p);
 #pragma unroll
-      for (int s = 0; s < VT; s++) {
-        const bool valid = diag + s < nt;
-        const bool a_ok = ai < na, b_ok = bi < nb;
-        const bool take_a = a_ok && (!b_ok || ka <= kb);
-        const bool both = take_a && b_ok && ka == kb;
-        const u32 b_at = na + bi;
-        const u32 own_at = take_a ? ai : b_at;
-        const u32 c_own = sh.cnts[own_at < LAST ? own_at : LAST];
-        const u32 c_b = sh.cnts[b_at < LAST ? b_at : LAST];
-        /* a B record whose key equals the A record consumed just before it is that record's
-         * partner: the pair was already classified BOTH at the A record */
-        const bool partner = have_prev && prev_a == kb;
-        u32 kind = take_a ? (both ? KIND_BOTH : KIND_A) : (partner ? KIND_SKIP : KIND_B);
-        kind = valid ? kind : KIND_SKIP;
-        item_key[s] = take_a ? ka : kb;
-        item_fa[s] = take_a ? c_own : 0u;
-        item_fb[s] = take_a ? (both ? c_b : 0u) : c_own;
-        kinds |= kind << (2 * s);
-        prev_a = take_a ? ka : prev_a;
-        have_prev = have_prev || take_a;
-        ai += take_a ? 1u : 0u;
-        bi += take_a ? 0u : 1u;
-        const u32 nxt = take_a ? ai : na + bi;
-        const u64 nk = sh.keys[nxt < LAST ? nxt : LAST];
-        ka = take_a ? nk : ka;
-        kb = take_a ? kb : nk;
-      }
-    }
-
-    /* ---- predicates: per-thread emit masks (4 x 16 bit), counts (4 x 16 bit) and count sums.
-     * One pass per requested stream behind a wave-uniform branch keeps register pressure flat. */
-    u64 emit_packed = 0, packed = 0;
-#pragma unroll 1
-    for (int s = 0; s < 4; s++) {
-      if (!((p.ops >> s) & 1u)) continue;
-      u32 m = 0;
-      u64 sum = 0;
-      switch (s) {
-        case 0: count_stream<0, VT> (kinds, item_fa, item_fb, p, m, sum); break;
-        case 1: count_stream<1, VT> (kinds, item_fa, item_fb, p, m, sum); break;
-        case 2: count_stream<2, VT> (kinds, item_fa, item_fb, p, m, sum); break;
-        default: count_stream<3, VT> (kinds, item_fa, item_fb, p, m, sum); break;
-      }
-      emit_packed |= (u64) m << (16 * s);
-      packed |= (u64) __popc (m) << (16 * s);
-      if (s == 0) acc_sum0 += sum;
-      else if (s == 1) acc_sum1 += sum;
-      else if (s == 2) acc_sum2 += sum;
-      else acc_sum3 += sum;
-    }
-
-    /* ---- block exclusive scan of the packed counts (all four streams at once; totals <= CAP < 2^16) */
-    const u64 incl = wave_inclusive_scan (packed, lane);
-    if (lane == WAVE - 1) sh.wave_tot[wid] = incl;
-    __syncthreads (); /* also: every thread is done reading the input view of LDS */
-    u64 wave_off = 0, tile_tot = 0;
-#pragma unroll
-    for (int w = 0; w < NW; w++) {
-      const u64 t = sh.wave_tot[w];
-      if (w < wid) wave_off += t;
-      tile_tot += t;
-    }
-    const u64 excl = wave_off + incl - packed; /* this thread's first slot per stream, packed */
-
-    if (tid == 0) {
-#pragma unroll
-      for (int s = 0; s < 4; s++) blk_cnt[s] += (tile_tot >> (16 * s)) & 0xffffu;
-    }
-
-    if (MODE == MODE_COUNT) {
-      /* pass 1 of the two-pass path (and --count_only): leave the tile's counts for the scan */
-      if (desc && tid < 4) desc[4 * tile + tid] = (tile_tot >> (16 * tid)) & 0xffffu;
-      __syncthreads ();
-      continue;
-    }
-
-    /* ---- global offsets of this tile */
-    if (MODE == MODE_LOOKBACK) {
-      if (wid == 0) {
-        /* lanes 0..3 own one stream each for publishing; the look-back itself runs per stream
-         * with all 64 lanes inspecting 64 predecessors at a time */
-        const u64 my_agg = (lane < 4) ? ((tile_tot >> (16 * lane)) & 0xffffu) : 0;
-        if (tile == 0) {
-          if (lane < 4) {
-            desc_store (&desc[lane], DESC_PREFIX | my_agg);
-            sh.tile_excl[lane] = 0;
-          }
-        } else {
-          if (lane < 4) desc_store (&desc[4 * tile + lane], DESC_AGG | my_agg);
-          u64 excl_s[4] = { 0, 0, 0, 0 };
-          bool failed = false;
-#pragma unroll
-          for (int s = 0; s < 4; s++) {
-            if (!((p.ops >> s) & 1u)) continue;
-            u64 running = 0;
-            long long base = (long long) tile - 1; /* nearest predecessor examined by lane 0 */
-            for (;;) {
-              const long long idx = base - lane;
-              u64 d = DESC_PREFIX; /* before tile 0: prefix 0 */
-              u32 spins = 0;
-              if (idx >= 0) {
-                d = desc_load (&desc[4 * (u64) idx + s]);
-                while ((d >> 62) == 0) {
-                  if (++spins > SPIN_LIMIT) { failed = true; break; }
-                  __builtin_amdgcn_s_sleep (1);
-                  d = desc_load (&desc[4 * (u64) idx + s]);
-                }
-              }
-              if (__any (failed)) { failed = true; break; }
-              const u64 has_prefix = __ballot ((d >> 62) == 2);
-              if (has_prefix) {
-                const int first = __ffsll ((long long) has_prefix) - 1; /* nearest tile with a full prefix */
-                running += wave_sum (lane <= first ? (d & DESC_VALUE) : 0);
-                break;
-              }
-              running += wave_sum (d & DESC_VALUE);
-              base -= WAVE;
+      for (int k = 0; k < IPT; k++) {
+        const u32 e = (u32) k * NT + (u32) tid;
+        const u32 chunk = (u32) k * NW + (u32) wid; /* wave-uniform */
+        const u32 cbeg = chunk * WAVE;
+        const bool chunk_live = cbeg < nt && (need_b || cbeg < na);
+        u64 ky = 0;
+        u32 xa = 0, xb = 0, kind = KIND_SKIP, r = 0, is_a = 0;
+        if (chunk_live) {
+          const bool valid = e < nt;
+          const u32 ec = valid ? e : 0u;
+          is_a = ec < na ? 1u : 0u;
+          ky = sh.keys[ec];
+          const u32 own = sh.cnts[ec];
+          const u32 obase = is_a ? na : 0u, on = is_a ? nb : na;
+          /* lower bound of ky in the other list */
+          u32 lo = 0, len = valid ? on : 0u;
+          while (len > 0) {
+            const u32 half = len >> 1;
+            if (sh.keys[obase + lo + half] < ky) {
+              lo += half + 1;
+              len -= half + 1;
+            } else {
+              len = half;
             }
-            if (failed) break;
-            excl_s[s] = running;
           }
-          if (failed) {
-            if (lane == 0) atomicOr (&ctl->error, 1u);
+          r = lo;
+          const bool in = r < on;
+          const u32 oat = obase + (in ? r : 0u);
+          const bool matched = in && sh.keys[oat] == ky;
+          const u32 ocnt = sh.cnts[oat];
+          if (is_a) {
+            kind = matched ? KIND_BOTH : KIND_A;
+            xa = own;
+            xb = matched ? ocnt : 0u;
+          } else {
+            kind = matched ? KIND_SKIP : KIND_B;
+            xb = own;
           }
-          if (lane < 4) {
-            u64 mine = 0;
-#pragma unroll
-            for (int s = 0; s < 4; s++) if (lane == s) mine = excl_s[s];
-            desc_store (&desc[4 * tile + lane], DESC_PREFIX | ((mine + my_agg) & DESC_VALUE));
-            sh.tile_excl[lane] = mine;
-          }
+          if (!valid) kind = KIND_SKIP;
+        }
+        key[k] = ky;
+        fa[k] = xa;
+        fb[k] = xb;
+        meta[k] = r | (kind << 16) | (is_a << 18);
+        u32 f;
+        if (ops & 1u) {
+          const bool keep = eval_stream<0> (kind, xa, xb, c0, f);
+          const u64 m = __ballot (keep);
+          if (lane == 0) sh.kmask[0][chunk] = m;
+          acc_sum0 += keep ? f : 0u;
+        }
+        if (ops & 2u) {
+          const bool keep = eval_stream<1> (kind, xa, xb, c1, f);
+          const u64 m = __ballot (keep);
+          if (lane == 0) sh.kmask[1][chunk] = m;
+          acc_sum1 += keep ? f : 0u;
+        }
+        if (ops & 4u) {
+          const bool keep = eval_stream<2> (kind, xa, xb, c2, f);
+          const u64 m = __ballot (keep);
+          if (lane == 0) sh.kmask[2][chunk] = m;
+          acc_sum2 += keep ? f : 0u;
+        }
+        if (ops & 8u) {
+          const bool keep = eval_stream<3> (kind, xa, xb, c3, f);
+          const u64 m = __ballot (keep);
+          if (lane == 0) sh.kmask[3][chunk] = m;
+          acc_sum3 += keep ? f : 0u;
         }
       }
-    } else { /* MODE_OFFSETS: desc holds the scanned exclusive offsets */
-      if (tid < 4) sh.tile_excl[tid] = desc[4 * tile + tid];
+    }
+    /* cut the value-numbering link between phase 1 and phase 3: without it the compiler keeps every
+     * stream's count of every record alive across phase 2 instead of recomputing it (2x the VGPRs) */
+#pragma unroll
+    for (int k = 0; k < IPT; k++) asm volatile ("" : "+v"(fa[k]), "+v"(fb[k]), "+v"(meta[k]));
+    __syncthreads (); /* B1: all input reads done */
+
+    /* ---- phase 2: wavefront s owns stream s: chunk scan, tile total, publish for the scanner */
+    if (wid < 4 && ((ops >> wid) & 1u)) {
+      const int s = wid;
+      const u32 v = lane < NCH ? (u32) __popcll (sh.kmask[s][lane]) : 0u;
+      const u32 incl = (u32) wave_inclusive_scan (v, lane);
+      const u32 total = __shfl (incl, WAVE - 1, WAVE);
+      if (lane < NCH) sh.cpre[s][lane] = incl - v;
+      if (lane == 0) {
+        sh.cpre[s][NCH] = total;
+        sh.kmask[s][NCH] = 0;
+        sh.tot[s] = total;
+        blk_cnt += total;
+        if (MODE == MODE_COUNT) {
+          if (desc) desc[4 * cur + s] = total; /* pass 1 of the two-pass path: counts for the scan kernel */
+        } else if (MODE == MODE_LOOKBACK) {
+          publish_u32 (&agg[(u64) s * num_tiles + cur], AGG_READY | total);
+        }
+      }
+      if (MODE != MODE_COUNT && !DEFER) {
+        /* the tile's own offset: wait for the scanner (or read the pre-scanned offsets) */
+        if (lane == 0) {
+          u64 x;
+          if (MODE == MODE_LOOKBACK) {
+            u64 *const w = &excl[(u64) s * num_tiles + cur];
+            u32 spins = 0;
+            while (!((x = peek_u64 (w)) & EXCL_READY)) {
+              if (++spins > SPIN_LIMIT) {
+                atomicOr (&ctl->error, 1u);
+                break;
+              }
+              __builtin_amdgcn_s_sleep (2);
+            }
+            x &= ~EXCL_READY;
+          } else {
+            x = desc[4 * cur + s];
+          }
+          sh.excl[s] = x;
+        }
+      }
+    } else if (DEFER && have_prev && wid == 4) {
+      /* offset of the PREVIOUS tile, published long ago by the scanner */
+      if (lane == 0) {
+        u64 x;
+        if (MODE == MODE_LOOKBACK) {
+          u64 *const w = &excl[(u64) S0 * num_tiles + prev_tile];
+          u32 spins = 0;
+          while (!((x = peek_u64 (w)) & EXCL_READY)) {
+            if (++spins > SPIN_LIMIT) {
+              atomicOr (&ctl->error, 1u);
+              break;
+            }
+            __builtin_amdgcn_s_sleep (2);
+          }
+          x &= ~EXCL_READY;
+        } else {
+          x = desc[4 * prev_tile + S0];
+        }
+        sh.excl[S0] = x;
+      }
+    }
+
+    if (MODE != MODE_COUNT) {
+      __syncthreads (); /* B2 */
+      if (DEFER) {
+        /* write out the previous tile from the staging area, then stage this one */
+        if (have_prev) {
+          u32 *__restrict__ dst = outs.rec[S0] + 3 * sh.excl[S0];
+          const u32 nd = 3 * prev_tot;
+          for (u32 d = tid; d < nd; d += NT) dst[d] = sh.stage[d];
+        }
+        const u32 my_tot = sh.tot[S0];
+        __syncthreads (); /* B3: staging area free */
+        if (S0 == 0) scatter_stream<0, NT, IPT, OPS> (sh, sh.stage, p, na, lane, wid, key, fa, fb, meta);
+        else scatter_stream<1, NT, IPT, OPS> (sh, sh.stage, p, na, lane, wid, key, fa, fb, meta);
+        prev_tile = cur;
+        prev_tot = my_tot;
+        have_prev = true;
+      } else {
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+          if (!((ops >> s) & 1u)) continue;
+          switch (s) {
+            case 0: scatter_stream<0, NT, IPT, OPS> (sh, lds32, p, na, lane, wid, key, fa, fb, meta); break;
+            case 1: scatter_stream<1, NT, IPT, OPS> (sh, lds32, p, na, lane, wid, key, fa, fb, meta); break;
+            case 2: scatter_stream<2, NT, IPT, OPS> (sh, lds32, p, na, lane, wid, key, fa, fb, meta); break;
+            default: scatter_stream<3, NT, IPT, OPS> (sh, lds32, p, na, lane, wid, key, fa, fb, meta); break;
+          }
+          __syncthreads ();
+          u32 *__restrict__ dst = outs.rec[s] + 3 * sh.excl[s];
+          const u32 nd = 3 * sh.tot[s];
+          for (u32 d = tid; d < nd; d += NT) dst[d] = lds32[d];
+          __syncthreads ();
+        }
+      }
+    }
+    cur = nxt;
+    tr = tn;
+    it++;
+  }
+
+  if (DEFER && have_prev) {
+    /* drain: the last staged tile */
+    __syncthreads ();
+    if (tid == 0) {
+      u64 x;
+      if (MODE == MODE_LOOKBACK) {
+        u64 *const w = &excl[(u64) S0 * num_tiles + prev_tile];
+        u32 spins = 0;
+        while (!((x = peek_u64 (w)) & EXCL_READY)) {
+          if (++spins > SPIN_LIMIT) {
+            atomicOr (&ctl->error, 1u);
+            break;
+          }
+          __builtin_amdgcn_s_sleep (2);
+        }
+        x &= ~EXCL_READY;
+      } else {
+        x = desc[4 * prev_tile + S0];
+      }
+      sh.excl[S0] = x;
     }
     __syncthreads ();
-
-    /* ---- compaction: per stream, scatter kept records into LDS in output order, then store the
-     * tile's run with coalesced dword stores at its global offset */
-#pragma unroll 1
-    for (int s = 0; s < 4; s++) {
-      if (!((p.ops >> s) & 1u)) continue;
-      const u32 cnt_s = (u32) ((tile_tot >> (16 * s)) & 0xffffu);
-      const u32 pos = (u32) ((excl >> (16 * s)) & 0xffffu);
-      const u32 m = (u32) ((emit_packed >> (16 * s)) & 0xffffu);
-      switch (s) {
-        case 0: scatter_stream<0, VT> (kinds, m, pos, item_key, item_fa, item_fb, p, lds32); break;
-        case 1: scatter_stream<1, VT> (kinds, m, pos, item_key, item_fa, item_fb, p, lds32); break;
-        case 2: scatter_stream<2, VT> (kinds, m, pos, item_key, item_fa, item_fb, p, lds32); break;
-        default: scatter_stream<3, VT> (kinds, m, pos, item_key, item_fa, item_fb, p, lds32); break;
-      }
-      __syncthreads ();
-      u32 *__restrict__ dst = outs.rec[s] + 3 * sh.tile_excl[s];
-      for (u32 d = tid; d < 3 * cnt_s; d += NT) dst[d] = lds32[d];
-      __syncthreads ();
-    }
+    u32 *__restrict__ dst = outs.rec[S0] + 3 * sh.excl[S0];
+    const u32 nd = 3 * prev_tot;
+    for (u32 d = tid; d < nd; d += NT) dst[d] = sh.stage[d];
   }
 
   /* ---- kernel totals: header n_words / total_count (reference :801-802, :909-910) */
@@ -485,10 +651,10 @@ __global__ __launch_bounds__ (NT, MERGE_WAVES_PER_SIMD) void k_pair_merge (const
     const u64 sums[4] = { acc_sum0, acc_sum1, acc_sum2, acc_sum3 };
 #pragma unroll
     for (int s = 0; s < 4; s++) {
-      if (!((p.ops >> s) & 1u)) continue;
+      if (!((ops >> s) & 1u)) continue;
       const u64 v = wave_sum (sums[s]);
       if (lane == 0 && v) atomicAdd (&ctl->total_count[s], v);
-      if (tid == 0 && blk_cnt[s]) atomicAdd (&ctl->n_words[s], blk_cnt[s]);
+      if (lane == 0 && wid == s && blk_cnt) atomicAdd (&ctl->n_words[s], blk_cnt);
     }
   }
 }
@@ -645,12 +811,29 @@ hipError_t launch_partition (hipStream_t s, const uint32_t *A, uint64_t nA, cons
   return hipGetLastError ();
 }
 
+template <int OPS>
+static hipError_t launch_pair_merge_ops (hipStream_t s, int mode, int grid, const uint32_t *A, uint64_t nA, const uint32_t *B, uint64_t nB,
+                                         const uint64_t *part, uint64_t num_tiles, const PairParams &p, const PairOutputs &o,
+                                         unsigned long long *desc, PairControl *ctl)
+{
+  if (mode == MODE_COUNT)
+    hipLaunchKernelGGL ((k_pair_merge<MERGE_NT, MERGE_VT, MODE_COUNT, OPS>), dim3 (grid), dim3 (MERGE_NT), 0, s, A, nA, B, nB,
+                        (const u64 *) part, num_tiles, p, o, desc, ctl);
+  else if (mode == MODE_LOOKBACK)
+    hipLaunchKernelGGL ((k_pair_merge<MERGE_NT, MERGE_VT, MODE_LOOKBACK, OPS>), dim3 (grid), dim3 (MERGE_NT), 0, s, A, nA, B, nB,
+                        (const u64 *) part, num_tiles, p, o, desc, ctl);
+  else
+    hipLaunchKernelGGL ((k_pair_merge<MERGE_NT, MERGE_VT, MODE_OFFSETS, OPS>), dim3 (grid), dim3 (MERGE_NT), 0, s, A, nA, B, nB,
+                        (const u64 *) part, num_tiles, p, o, desc, ctl);
+  return hipGetLastError ();
+}
+
 int merge_blocks_per_cu ()
 {
   static int cached = 0;
   if (!cached) {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor (&n, k_pair_merge<MERGE_NT, MERGE_VT, MODE_LOOKBACK>, MERGE_NT, 0) != hipSuccess || n < 1) n = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor (&n, k_pair_merge<MERGE_NT, MERGE_VT, MODE_LOOKBACK, 0>, MERGE_NT, 0) != hipSuccess || n < 1) n = 1;
     cached = n;
   }
   return cached;
@@ -661,16 +844,10 @@ hipError_t launch_pair_merge (hipStream_t s, int mode, int grid, const uint32_t 
                               const PairParams &p, const PairOutputs &o, unsigned long long *desc,
                               PairControl *ctl)
 {
-  if (mode == MODE_COUNT)
-    hipLaunchKernelGGL ((k_pair_merge<MERGE_NT, MERGE_VT, MODE_COUNT>), dim3 (grid), dim3 (MERGE_NT), 0, s, A, nA, B, nB,
-                        (const u64 *) part, num_tiles, p, o, desc, ctl);
-  else if (mode == MODE_LOOKBACK)
-    hipLaunchKernelGGL ((k_pair_merge<MERGE_NT, MERGE_VT, MODE_LOOKBACK>), dim3 (grid), dim3 (MERGE_NT), 0, s, A, nA, B, nB,
-                        (const u64 *) part, num_tiles, p, o, desc, ctl);
-  else
-    hipLaunchKernelGGL ((k_pair_merge<MERGE_NT, MERGE_VT, MODE_OFFSETS>), dim3 (grid), dim3 (MERGE_NT), 0, s, A, nA, B, nB,
-                        (const u64 *) part, num_tiles, p, o, desc, ctl);
-  return hipGetLastError ();
+  /* single-output calls (glistcompare -u / -i, every N-way level) take a specialised kernel */
+  if (p.ops == 1u) return launch_pair_merge_ops<1> (s, mode, grid, A, nA, B, nB, part, num_tiles, p, o, desc, ctl);
+  if (p.ops == 2u) return launch_pair_merge_ops<2> (s, mode, grid, A, nA, B, nB, part, num_tiles, p, o, desc, ctl);
+  return launch_pair_merge_ops<0> (s, mode, grid, A, nA, B, nB, part, num_tiles, p, o, desc, ctl);
 }
 
 hipError_t launch_scan_tiles (hipStream_t s, unsigned long long *desc, uint64_t num_tiles, unsigned long long *block_sums)
