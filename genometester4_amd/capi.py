@@ -13,7 +13,7 @@ import numpy as np
 from .listio import RECORD_DTYPE
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, "libgt4hip.so")
+LIB_PATH = os.environ.get("GT4HIP_LIB") or os.path.join(PKG_DIR, "libgt4hip.so")  # GT4HIP_LIB: diagnostic builds
 
 OK = 0
 EINVAL, ENODEVICE, ENOMEM, ERULE, EHIP, EWORDLEN, EINTERNAL = 1, 2, 3, 4, 5, 6, 7

@@ -24,6 +24,7 @@ struct gt4hip_context {
   int n_cus;
   int two_pass;
   int64_t grid_override;
+  uint64_t single_pass_fallbacks; /* calls that had to be rerun on the two-pass path */
   /* workspace, grown on demand */
   uint64_t *part;
   size_t part_bytes;
@@ -381,6 +382,17 @@ static int grow (gt4hip_context *ctx, void **p, size_t *have, size_t need)
 
 /* ------------------------------------------------------------------ pair operation core */
 
+/* descriptor workspace: single pass agg u32[4][rows*64] + carry u64[4][rows+1]; the two-pass path
+ * keeps u64[4] per tile in the same buffer */
+static size_t desc_bytes_for (uint64_t tiles)
+{
+  const uint64_t rows = (tiles + 63) / 64;
+  const size_t single = (size_t) rows * 64 * 16 + (size_t) (rows + 1) * 32;
+  const size_t two = (size_t) tiles * 32;
+  return ((single > two ? single : two) + 255) & ~(size_t) 255;
+}
+
+
 struct PairRun {
   uint64_t n_words[4];
   uint64_t total_count[4];
@@ -391,7 +403,7 @@ struct PairRun {
 /* Runs the merge of (a, b) with fully resolved kernel parameters.  dst[s] (device record buffers)
  * must be non-null for every requested stream unless count_only. */
 static int run_pair (gt4hip_context *ctx, const uint32_t *A, uint64_t nA, const uint32_t *B, uint64_t nB,
-                     const PairParams &p, bool count_only, uint32_t *const dst[4], PairRun *run)
+                     const PairParams &p, bool count_only, uint32_t *const dst[4], PairRun *run, bool force_two_pass = false)
 {
   memset (run, 0, sizeof *run);
   const uint64_t total = nA + nB;
@@ -400,16 +412,19 @@ static int run_pair (gt4hip_context *ctx, const uint32_t *A, uint64_t nA, const 
   run->tiles = tiles;
   int rc;
   if ((rc = grow (ctx, (void **) &ctx->part, &ctx->part_bytes, (size_t) (tiles + 1) * 16))) return rc;
-  const bool two_pass = ctx->two_pass && !count_only;
+  const bool two_pass = (ctx->two_pass || force_two_pass) && !count_only;
   const bool need_desc = !count_only;
-  if (need_desc && (rc = grow (ctx, (void **) &ctx->desc, &ctx->desc_bytes, (size_t) tiles * 48))) return rc; /* agg u32[4][T] + excl u64[4][T] */
+  if (need_desc && (rc = grow (ctx, (void **) &ctx->desc, &ctx->desc_bytes, desc_bytes_for (tiles)))) return rc;
   if (two_pass) {
     const size_t nb = (size_t) ((tiles + 2047) / 2048) * 32;
     if ((rc = grow (ctx, (void **) &ctx->block_sums, &ctx->block_sums_bytes, nb))) return rc;
   }
-  int grid = ctx->n_cus * merge_blocks_per_cu ();
+  const int first_mode = count_only ? MODE_COUNT : (two_pass ? MODE_COUNT : MODE_LOOKBACK);
+  int grid = ctx->n_cus * merge_blocks_per_cu (first_mode, p.ops);
   if (ctx->grid_override > 0) grid = (int) ctx->grid_override;
-  if ((uint64_t) grid > tiles + 1) grid = (int) tiles + 1; /* + the scanner workgroup */
+  if ((uint64_t) grid > tiles + 1) grid = (int) tiles + 1; /* workers + the scanner workgroup */
+  int grid2 = ctx->n_cus * merge_blocks_per_cu (MODE_OFFSETS, p.ops);
+  if ((uint64_t) grid2 > tiles) grid2 = (int) tiles;
 
   PairOutputs outs;
   for (int s = 0; s < 4; s++) outs.rec[s] = (count_only || !dst) ? NULL : dst[s];
@@ -417,7 +432,7 @@ static int run_pair (gt4hip_context *ctx, const uint32_t *A, uint64_t nA, const 
   hipStream_t st = ctx->stream;
   HIPCHK (ctx, hipEventRecord (ctx->ev[0], st));
   HIPCHK (ctx, hipMemsetAsync (ctx->ctl, 0, sizeof (PairControl), st));
-  if (need_desc && !two_pass) HIPCHK (ctx, hipMemsetAsync (ctx->desc, 0, (size_t) tiles * 48, st));
+  if (need_desc && !two_pass) HIPCHK (ctx, hipMemsetAsync (ctx->desc, 0, desc_bytes_for (tiles), st));
   HIPCHK (ctx, launch_partition (st, A, nA, B, nB, tiles, ctx->part));
   HIPCHK (ctx, hipEventRecord (ctx->ev[1], st));
   if (count_only) {
@@ -426,7 +441,7 @@ static int run_pair (gt4hip_context *ctx, const uint32_t *A, uint64_t nA, const 
     HIPCHK (ctx, launch_pair_merge (st, MODE_COUNT, grid, A, nA, B, nB, ctx->part, tiles, p, outs, ctx->desc, ctx->ctl));
     HIPCHK (ctx, launch_scan_tiles (st, ctx->desc, tiles, ctx->block_sums));
     HIPCHK (ctx, hipMemsetAsync (ctx->ctl, 0, sizeof (PairControl), st));
-    HIPCHK (ctx, launch_pair_merge (st, MODE_OFFSETS, grid, A, nA, B, nB, ctx->part, tiles, p, outs, ctx->desc, ctx->ctl));
+    HIPCHK (ctx, launch_pair_merge (st, MODE_OFFSETS, grid2, A, nA, B, nB, ctx->part, tiles, p, outs, ctx->desc, ctx->ctl));
   } else {
     HIPCHK (ctx, launch_pair_merge (st, MODE_LOOKBACK, grid, A, nA, B, nB, ctx->part, tiles, p, outs, ctx->desc, ctx->ctl));
   }
@@ -437,7 +452,26 @@ static int run_pair (gt4hip_context *ctx, const uint32_t *A, uint64_t nA, const 
   float ms = 0;
   if (hipEventElapsedTime (&ms, ctx->ev[1], ctx->ev[2]) == hipSuccess) run->merge_ms = ms;
   if (hipEventElapsedTime (&ms, ctx->ev[0], ctx->ev[3]) == hipSuccess) run->device_ms = ms;
-  if (ctx->ctl_host->error) return fail (ctx, GT4HIP_EINTERNAL, "merge kernel reported error flags 0x%x", ctx->ctl_host->error);
+#ifdef GT4_PROFILE_PHASES
+  {
+    static const char *names[8] = { "p0 wait+lds", "B0", "ring+fetch issue", "p1 rank", "B1", "p2 scan/publish", "B2+out+B3+scatter", "housekeeping" };
+    unsigned long long tot = 0;
+    for (int i = 0; i < 8; i++) tot += ctx->ctl_host->phase_cycles[i];
+    fprintf (stderr, "[phases] tiles %llu merge %.3f ms:", (unsigned long long) tiles, run->merge_ms);
+    for (int i = 0; i < 8; i++) fprintf (stderr, " %s %.1f%%", names[i], tot ? 100.0 * ctx->ctl_host->phase_cycles[i] / tot : 0.0);
+    fprintf (stderr, " | avg cycles/tile %.0f\n", tiles ? (double) tot / tiles : 0.0);
+  }
+#endif
+  if (ctx->ctl_host->error) {
+    const unsigned flags = ctx->ctl_host->error;
+    if (!two_pass && !count_only && !(flags & 2u)) {
+      /* a bounded wait of the single-pass path gave up (a worker was not resident, or the device
+       * is shared): the count + scan + write path has no inter-workgroup dependency -- rerun there */
+      ctx->single_pass_fallbacks++;
+      return run_pair (ctx, A, nA, B, nB, p, count_only, dst, run, true);
+    }
+    return fail (ctx, GT4HIP_EINTERNAL, "merge kernel reported error flags 0x%x", flags);
+  }
   for (int s = 0; s < 4; s++) {
     run->n_words[s] = ctx->ctl_host->n_words[s];
     run->total_count[s] = ctx->ctl_host->total_count[s];

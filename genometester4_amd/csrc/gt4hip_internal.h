@@ -36,10 +36,11 @@ struct PairOutputs {
 struct PairControl {
   unsigned long long n_words[4];
   unsigned long long total_count[4];
-  unsigned int ticket;     /* dynamic tile counter */
+  unsigned int ticket;     /* (unused, kept for layout) */
   unsigned int error;      /* non-zero: a bounded spin gave up / consistency check tripped */
   unsigned int role;       /* first workgroup to arrive becomes the scanner */
   unsigned int pad;
+  unsigned long long phase_cycles[8]; /* diagnostic builds (-DGT4_PROFILE_PHASES): shader cycles per phase, summed over workgroups */
 };
 
 enum MergeMode : int {
@@ -52,8 +53,8 @@ enum MergeMode : int {
 constexpr int MERGE_NT = 512;               /* threads per workgroup (8 wavefronts)      */
 constexpr int MERGE_VT = 4;                 /* records per thread (one per lane per pass)  */
 constexpr int MERGE_CAP = MERGE_NT * MERGE_VT; /* LDS capacity in records                 */
-constexpr int MERGE_TILE = MERGE_CAP - 1;   /* nominal tile; pair fix-up makes it +-1    */
-constexpr int MERGE_WAVES_PER_SIMD = 6;     /* single-output kernels: <= 80 VGPRs, 3 workgroups (24 waves) per CU */
+constexpr int MERGE_TILE = MERGE_CAP - 3;   /* nominal tile; pair fix-up makes it +-1; both ranges in 16-byte chunks fit */
+constexpr int MERGE_WAVES_PER_SIMD = 4;     /* single-output kernels: <= 80 VGPRs, 3 workgroups (24 waves) per CU */
 constexpr int MERGE_WAVES_PER_SIMD_GENERIC = 4; /* any-combination kernel: <= 128 VGPRs                     */
 
 hipError_t launch_partition (hipStream_t s, const uint32_t *A, uint64_t nA, const uint32_t *B, uint64_t nB,
@@ -74,7 +75,7 @@ hipError_t launch_counts_table (hipStream_t s, const uint32_t *keys_rec, uint64_
                                 uint64_t n_list, uint32_t *counts, uint32_t n_lists, uint32_t column);
 hipError_t launch_extract_keys (hipStream_t s, const uint32_t *rec, uint64_t n, unsigned long long *keys);
 
-int merge_blocks_per_cu ();
+int merge_blocks_per_cu (int mode, uint32_t ops);
 
 }  // namespace gt4
 

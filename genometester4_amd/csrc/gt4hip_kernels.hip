@@ -26,6 +26,7 @@ constexpr int WAVE = 64;
 
 typedef unsigned long long u64;
 typedef unsigned int u32;
+typedef u32 u32x4 __attribute__ ((ext_vector_type (4)));
 
 /* ------------------------------------------------------------------ record access */
 
@@ -173,71 +174,109 @@ __device__ __forceinline__ u64 wave_sum (u64 v)
 
 /* ------------------------------------------------------------------ tile descriptors (chained scan) */
 
-/* Per output stream s and tile t, two words in device memory, zeroed before every launch:
- *   agg[s][t]   u32: bit 31 = published, low bits = records the tile keeps in stream s
- *   excl[s][t]  u64: bit 63 = published, low bits = records kept by tiles 0..t-1 (global offset)
- * Workers publish agg; ONE scanner wavefront per stream walks agg in tile order and publishes
- * excl.  Every word is written once by a single relaxed agent-scope store and read by relaxed
- * agent-scope loads: value and flag travel in the same naturally aligned word, so no fence is
- * needed (cdna_hip_programming.md Guideline 16, form R2). */
+/* Two-level chained scan of the tiles' output counts.  Per output stream s, zeroed before every
+ * launch:
+ *   agg[s][t]      u32, one per tile: bit 31 = published, low bits = records tile t keeps
+ *   carry[s][r]    u64, one per row of 64 tiles: bit 63 = published, low bits = records kept by
+ *                  all tiles of rows 0..r-1
+ * Workers publish agg.  ONE scanner wavefront per stream walks the rows in order, sums each
+ * complete row and publishes the running carry.  A tile's global output offset is carry[its row]
+ * plus the counts of the tiles before it in its own row -- one coalesced 64-word load, summed by
+ * the worker itself.  Every word is written once by a single relaxed agent-scope store and read
+ * by relaxed agent-scope loads: value and flag travel in the same naturally aligned word, so no
+ * fence is needed (cdna_hip_programming.md Guideline 16, form R2). */
 constexpr u32 AGG_READY = 1u << 31;
-constexpr u64 EXCL_READY = 1ull << 63;
+constexpr u64 CARRY_READY = 1ull << 63;
 
 __device__ __forceinline__ void publish_u32 (u32 *p, u32 v) { __hip_atomic_store (p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void publish_u64 (u64 *p, u64 v) { __hip_atomic_store (p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ u32 peek_u32 (u32 *p) { return __hip_atomic_load (p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ u64 peek_u64 (u64 *p) { return __hip_atomic_load (p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+#ifdef GT4_PROFILE_PHASES
+#ifndef GT4_STAMP_TID
+#define GT4_STAMP_TID 0
+#endif
+/* one asm statement with its own wait, fenced from the scheduler (cdna_hip_programming.md section 7, In-kernel stamps) */
+#define PHASE_STAMP(i) do { __builtin_amdgcn_sched_barrier (0); u64 t_; asm volatile ("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier (0); if (tid == GT4_STAMP_TID) { ph[i] += t_ - t_last; } t_last = t_; } while (0)
+#else
+#define PHASE_STAMP(i) do { } while (0)
+#endif
+
 constexpr u32 SPIN_LIMIT = 1u << 22; /* bounded: ~seconds; sets ctl->error instead of hanging */
 constexpr int SCAN_ROWS = 16;        /* rows of 64 tiles a scanner wavefront keeps in flight */
 
+__device__ __forceinline__ u32 wave_sum_u32 (u32 v)
+{
+#pragma unroll
+  for (int m = WAVE / 2; m > 0; m >>= 1) v += __shfl_xor (v, m, WAVE);
+  return v;
+}
+
 /* The scanner: one wavefront per stream.  Loads SCAN_ROWS x 64 tile counts at once (so that its
- * rate is set by L2 bandwidth, not by one round trip per 64 tiles), waits for stragglers, scans,
- * publishes the exclusive offsets. */
-__device__ void scanner_wave (u32 *agg, u64 *excl, u64 num_tiles, PairControl *ctl, int lane)
+ * rate is set by L2 bandwidth, not by one round trip per row), waits for each row to be complete,
+ * publishes the carry into the next row. */
+__device__ void scanner_wave (u32 *agg, u64 *carry_out, u64 num_tiles, PairControl *ctl, int lane)
 {
   u64 carry = 0;
   const u64 rows = (num_tiles + WAVE - 1) / WAVE;
+  if (lane == 0) publish_u64 (&carry_out[0], CARRY_READY);
   for (u64 r0 = 0; r0 < rows; r0 += SCAN_ROWS) {
+    const int n = rows - r0 < (u64) SCAN_ROWS ? (int) (rows - r0) : SCAN_ROWS;
     u32 v[SCAN_ROWS];
 #pragma unroll
     for (int j = 0; j < SCAN_ROWS; j++) {
       const u64 idx = (r0 + j) * WAVE + lane;
-      v[j] = idx < num_tiles ? peek_u32 (&agg[idx]) : AGG_READY;
+      v[j] = (j < n && idx < num_tiles) ? peek_u32 (&agg[idx]) : AGG_READY;
     }
+    int done = 0;
+    u32 spins = 0;
+    for (;;) {
+      /* retire, in order, every row that is complete */
 #pragma unroll
-    for (int j = 0; j < SCAN_ROWS; j++) {
-      if (r0 + j >= rows) break;
-      const u64 idx = (r0 + j) * WAVE + lane;
-      /* Publish every tile as soon as all tiles before it have reported -- never wait for the
-       * whole row: a worker may be blocked on tile t's offset while it still holds the ticket of
-       * tile t+1 (same row). */
-      u32 published = 0, spins = 0, incl = 0;
-      for (;;) {
-        const u64 ready = __ballot ((v[j] & AGG_READY) != 0);
-        const u32 f = ~ready ? (u32) __ffsll ((long long) ~ready) - 1u : (u32) WAVE; /* length of the ready prefix */
-        if (f > published) {
-          const u32 val = (u32) lane < f ? (v[j] & ~AGG_READY) : 0u;
-          incl = val;
-#pragma unroll
-          for (int d = 1; d < WAVE; d <<= 1) {
-            const u32 o = __shfl_up (incl, d, WAVE);
-            if (lane >= d) incl += o;
-          }
-          if ((u32) lane >= published && (u32) lane < f && idx < num_tiles) publish_u64 (&excl[idx], EXCL_READY | (carry + incl - val));
-          published = f;
+      for (int j = 0; j < SCAN_ROWS; j++) {
+        if (j == done && j < n && __all ((v[j] & AGG_READY) != 0)) {
+          carry += wave_sum_u32 (v[j] & ~AGG_READY);
+          if (lane == 0) publish_u64 (&carry_out[r0 + j + 1], CARRY_READY | carry);
+          done++;
         }
-        if (f == (u32) WAVE) break;
-        if (++spins > SPIN_LIMIT) {
-          if (lane == 0) atomicOr (&ctl->error, 4u);
-          return;
-        }
-        if (spins > 2) __builtin_amdgcn_s_sleep (2);
-        if (!(v[j] & AGG_READY)) v[j] = peek_u32 (&agg[idx]);
       }
-      carry += __shfl (incl, WAVE - 1, WAVE);
+      if (done >= n) break;
+      if (++spins > SPIN_LIMIT) {
+        if (lane == 0) atomicOr (&ctl->error, 4u);
+        return;
+      }
+      /* one round trip re-reads the missing words of ALL pending rows: at the frontier the
+       * scanner must advance several rows per round trip to keep up with the workers */
+#pragma unroll
+      for (int j = 0; j < SCAN_ROWS; j++) {
+        const u64 idx = (r0 + j) * WAVE + lane;
+        if (j >= done && j < n && !(v[j] & AGG_READY)) v[j] = peek_u32 (&agg[idx]);
+      }
     }
   }
+}
+
+/* A tile's global output offset: carry of its row + counts of the tiles before it in the row.
+ * `a` and `c` are the values of an earlier, speculative load of the same words (or 0). */
+__device__ __forceinline__ u64 resolve_offset (u32 *agg, u64 *carry, u64 tile, int lane, u32 a, u64 c, PairControl *ctl)
+{
+  const u64 row = tile / WAVE;
+  const u32 pos = (u32) (tile % WAVE);
+  u32 *const wa = &agg[row * WAVE + lane];
+  u64 *const wc = &carry[row];
+  const bool mine = (u32) lane < pos;
+  u32 spins = 0;
+  while (!__all (!mine || (a & AGG_READY) != 0) || !(c & CARRY_READY)) {
+    if (++spins > SPIN_LIMIT) {
+      if (lane == 0) atomicOr (&ctl->error, 1u);
+      break;
+    }
+    if (spins > 1) __builtin_amdgcn_s_sleep (1);
+    if (mine && !(a & AGG_READY)) a = peek_u32 (wa);
+    if (!(c & CARRY_READY)) c = peek_u64 (wc);
+  }
+  return (c & ~CARRY_READY) + wave_sum_u32 (mine ? (a & ~AGG_READY) : 0u);
 }
 
 /* ------------------------------------------------------------------ K2: tile merge by rank search */
@@ -276,14 +315,16 @@ struct RankShared {
   static constexpr int NCH = CAP / WAVE;
   /* deferred staging: an intersection keeps at most one record per pair, a union at most CAP */
   static constexpr int STAGE_DW = OPS == 2 ? 3 * (CAP / 2 + 1) : (OPS == 1 ? 3 * CAP : 4);
+  static constexpr int STAGE_SLOTS = 2; /* write-out lags two tiles behind ranking */
   u64 keys[CAP];          /* input view; OPS == 0: the output view (3 * CAP dwords) starts here too */
   u32 cnts[CAP];
-  u32 stage[STAGE_DW];
+  u32 stage[STAGE_SLOTS][STAGE_DW];
   u64 kmask[4][NCH + 1];  /* keep-flag ballot per 64-record chunk, per stream (+1: empty sentinel chunk) */
   u32 cpre[4][NCH + 1];   /* exclusive prefix of popcount(kmask) over chunks, per stream               */
   u64 excl[4];            /* global exclusive output offset of the tile being written out              */
   u32 tot[4];             /* records the current tile keeps, per stream                                */
-  u32 tick[2];            /* ticket ring: tile of the next iteration / the one after                   */
+  u32 tick[3];            /* ticket ring: the tile in flight, the next one, the one after               */
+  u64 rng[3][4];          /* their record ranges {a0, b0, a1, b1} (part[] entries), fetched ahead        */
 };
 
 /* number of kept records among the concatenated tile positions [0, z) */
@@ -323,6 +364,14 @@ struct TileRange {
   u32 na, nb;
 };
 
+/* values read back from LDS are the same in every lane; say so, so that addresses, descriptors and
+ * loop bounds derived from them live in SGPRs (no waterfall loops around the buffer loads) */
+__device__ __forceinline__ u32 uniform32 (u32 v) { return __builtin_amdgcn_readfirstlane (v); }
+__device__ __forceinline__ u64 uniform64 (u64 v)
+{
+  return (u64) __builtin_amdgcn_readfirstlane ((u32) v) | ((u64) __builtin_amdgcn_readfirstlane ((u32) (v >> 32)) << 32);
+}
+
 __device__ __forceinline__ TileRange load_tile_range (const u64 *__restrict__ part, u64 tile)
 {
   TileRange t;
@@ -337,13 +386,13 @@ __device__ __forceinline__ TileRange load_tile_range (const u64 *__restrict__ pa
  * kernel without the other streams' code and registers); OPS == 0 takes it from p.ops. */
 template <int NT, int IPT, int MODE, int OPS>
 __global__ __launch_bounds__ (NT, OPS ? MERGE_WAVES_PER_SIMD : MERGE_WAVES_PER_SIMD_GENERIC) void
-k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 nB, const u64 *__restrict__ part, u64 num_tiles,
+k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 nB, u64 *part, u64 num_tiles,
               PairParams p, PairOutputs outs, u64 *desc, PairControl *ctl)
 {
   constexpr int CAP = NT * IPT;
   constexpr int NW = NT / WAVE;
   constexpr int NCH = CAP / WAVE;
-  constexpr int NLOAD = 3 * IPT;                 /* dwords each thread fetches per tile */
+  constexpr int NLOAD4 = (3 * IPT + 3) / 4;      /* 16-byte chunks each thread fetches per tile */
   constexpr bool DEFER = (OPS == 1 || OPS == 2) && MODE != MODE_COUNT;
   constexpr int S0 = OPS == 2 ? 1 : 0;           /* the stream of a single-output kernel */
   static_assert (NW >= 4, "one wavefront per output stream in phase 2");
@@ -357,18 +406,20 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
    * where a B-only key can be kept (union, diff2) */
   const bool need_b = (ops & 9u) != 0;
 
-  /* single pass: agg u32[4][T] then excl u64[4][T] inside desc (zeroed by the host) */
+  /* single pass: agg u32[4][rows * 64] then carry u64[4][rows + 1] inside desc (zeroed by the host) */
+  const u64 n_rows = (num_tiles + WAVE - 1) / WAVE;
   u32 *const agg = reinterpret_cast<u32 *> (desc);
-  u64 *const excl = desc + 2 * num_tiles; /* 4 * T u32 = 2 * T u64 */
+  u64 *const carry = desc + 2 * n_rows * WAVE; /* 4 * rows * 64 u32 */
 
+  u32 role = 0;
   if (MODE == MODE_LOOKBACK) {
     /* role election: the first workgroup to arrive is running by definition, it becomes the scanner */
     if (tid == 0) sh.tick[0] = atomicAdd (&ctl->role, 1u);
     __syncthreads ();
-    const u32 role = sh.tick[0];
+    role = sh.tick[0];
     __syncthreads ();
     if (role == 0) {
-      if (wid < 4 && ((ops >> wid) & 1u)) scanner_wave (agg + (u64) wid * num_tiles, excl + (u64) wid * num_tiles, num_tiles, ctl, lane);
+      if (wid < 4 && ((ops >> wid) & 1u)) scanner_wave (agg + (u64) wid * n_rows * WAVE, carry + (u64) wid * (n_rows + 1), num_tiles, ctl, lane);
       return;
     }
   }
@@ -376,39 +427,83 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
   u64 acc_sum0 = 0, acc_sum1 = 0, acc_sum2 = 0, acc_sum3 = 0; /* per-thread sums of kept counts */
   u64 blk_cnt = 0;                                              /* lane 0 of wave s: records kept in stream s */
 
-  /* tickets: tiles are claimed in index order, so every tile the scanner waits on belongs to a
-   * workgroup that is already running (no residency assumption).  Two tickets are held: the tile
-   * being processed and the one whose records are being prefetched. */
+  /* Tiles are dealt round-robin: worker w processes tiles w, w + W, w + 2W, ...  (A shared ticket
+   * counter saturates near 88 returning atomics per microsecond -- MI355X_MICROARCH.md, row
+   * dequeue -- which capped the whole kernel; counters sharded by worker class drift apart and
+   * leave every worker waiting for the slowest class.)  With the scanner this needs every worker
+   * resident, which the host guarantees by sizing the grid from the kernel's occupancy; worker
+   * ids come from arrival order, and every spin is bounded, so a non-resident worker shows up as
+   * an error flag (the host then reruns the call on the two-pass path), never as a hang.
+   * A three-deep ring keeps every dependent global round trip off the critical path: while tile i
+   * is processed, the records of tile i+1 are in flight and the range of tile i+2 is being read. */
+  const u32 n_workers = MODE == MODE_LOOKBACK ? gridDim.x - 1 : gridDim.x;
+  const u32 wk = MODE == MODE_LOOKBACK ? role - 1 : blockIdx.x;
+  u32 n_claimed = 0; /* thread 0 */
+  auto claim = [&] () -> u32 {
+    const u64 t = (u64) wk + (u64) (n_claimed++) * n_workers;
+    return t < num_tiles ? (u32) t : 0xffffffffu;
+  };
   if (tid == 0) {
-    sh.tick[0] = atomicAdd (&ctl->ticket, 1u);
-    sh.tick[1] = atomicAdd (&ctl->ticket, 1u);
+    for (int q = 0; q < 3; q++) {
+      const u32 t = claim ();
+      sh.tick[q] = t;
+      if (q < 2 && t < num_tiles)
+        for (int i = 0; i < 4; i++) sh.rng[q][i] = part[2 * (u64) t + i];
+    }
   }
   __syncthreads ();
-  u64 cur = sh.tick[0];
+  u64 cur = uniform32 (sh.tick[0]);
   TileRange tr = { 0, 0, 0, 0 };
-  u32 pre[NLOAD];
+  if (cur < num_tiles) {
+    tr.a0 = uniform64 (sh.rng[0][0]);
+    tr.b0 = uniform64 (sh.rng[0][1]);
+    tr.na = uniform32 ((u32) (sh.rng[0][2] - sh.rng[0][0]));
+    tr.nb = uniform32 ((u32) (sh.rng[0][3] - sh.rng[0][1]));
+  }
+  u32x4 pre[NLOAD4];
+  u32x4 pre_x = { 0, 0, 0, 0 }; /* B half of the one wave-instruction per tile that straddles the two ranges */
 
+  /* 16-byte chunk q of the tile: chunks [0, cA) cover the A range (3*na dwords), the rest the B
+   * range.  The packed 12-byte records are only 4-byte aligned, which a buffer_load_dwordx4 takes
+   * as is; one range-checked descriptor per range makes every byte past the range read as 0
+   * without touching memory, so the last, partial chunk needs no special case.  A wavefront is
+   * all-A, all-B, or (once per tile) straddles the two ranges; the choice is wave-uniform. */
   auto fetch = [&] (const TileRange &t) {
-    const u32 *__restrict__ srcA = A + 3 * t.a0;
-    const u32 *__restrict__ srcB = B + 3 * t.b0;
-    const u32 da = 3 * t.na, dt = 3 * (t.na + t.nb);
+    const u32 da = 3 * t.na, db = 3 * t.nb, cA = (da + 3) >> 2;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc ((void *) (A + 3 * t.a0), 0, (int) (4 * da), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc ((void *) (B + 3 * t.b0), 0, (int) (4 * db), 0x00020000);
 #pragma unroll
-    for (int j = 0; j < NLOAD; j++) {
-      const u32 d = (u32) j * NT + (u32) tid;
-      u32 w = 0;
-      if (d < da) w = srcA[d];
-      else if (d < dt) w = srcB[d - da];
+    for (int j = 0; j < NLOAD4; j++) {
+      const u32 q0 = (u32) j * NT + (u32) wid * WAVE; /* first chunk of this wavefront */
+      const u32 q = q0 + (u32) lane;
+      u32x4 w;
+      if (q0 + WAVE <= cA) {
+        w = __builtin_amdgcn_raw_buffer_load_b128 (ra, 16 * q, 0, 0);
+      } else if (q0 >= cA) {
+        w = __builtin_amdgcn_raw_buffer_load_b128 (rb, 16 * (q - cA), 0, 0);
+      } else {
+        /* lanes below cA are out of range of rb (the offset wraps), the others out of range of ra:
+         * the two results are OR-ed when they are consumed (phase 0), not here -- combining them
+         * now would put a full memory round trip on this wavefront's critical path */
+        w = __builtin_amdgcn_raw_buffer_load_b128 (ra, 16 * q, 0, 0);
+        pre_x = __builtin_amdgcn_raw_buffer_load_b128 (rb, 16 * (q - cA), 0, 0);
+      }
       pre[j] = w;
     }
   };
 
-  if (cur < num_tiles) {
-    tr = load_tile_range (part, cur);
-    fetch (tr);
-  }
-  u64 prev_tile = 0;   /* DEFER: tile whose output is staged but not yet written */
-  u32 prev_tot = 0;
-  bool have_prev = false;
+  if (cur < num_tiles) fetch (tr);
+#ifdef GT4_PROFILE_PHASES
+  u64 ph[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+  u64 t_last;
+  asm volatile ("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_last) :: "memory");
+#endif
+  /* DEFER: the two tiles whose output is staged in LDS but not yet written (slot = iteration parity) */
+  u64 older_tile = 0, newer_tile = 0;
+  u32 older_tot = 0, newer_tot = 0;
+  bool have_older = false, have_newer = false;
+  u32 xagg = 0;   /* wave 4: speculative loads of the older tile's row counts and row carry */
+  u64 xcarry = 0;
   int it = 0;
 
   while (cur < num_tiles) {
@@ -418,98 +513,172 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
       break;
     }
     /* ---- phase 0: registers -> LDS, AoS dwords -> SoA (an 8-byte key read at a 4-byte aligned
-     * LDS address would replay at 64 cycles, Guideline 17) */
+     * LDS address would replay at 64 cycles, Guideline 17).  Dword d of a range belongs to record
+     * d / 3, field d % 3 (0, 1: key halves, 2: count). */
+    {
+      const u32 da = 3 * na, db = 3 * nb, cA = (da + 3) >> 2, cB = (db + 3) >> 2;
 #pragma unroll
-    for (int j = 0; j < NLOAD; j++) {
-      const u32 d = (u32) j * NT + (u32) tid;
-      if (d < 3 * nt) {
-        const u32 r = d / 3, f = d - 3 * r;
-        lds32[(f == 2) ? (2 * CAP + r) : (2 * r + f)] = pre[j];
+      for (int j = 0; j < NLOAD4; j++) {
+        const u32 q = (u32) j * NT + (u32) tid;
+        if (q < cA + cB) {
+          const bool in_a = q < cA;
+          const u32 d0 = 4 * (in_a ? q : q - cA), lim = in_a ? da : db, rbase = in_a ? 0u : na;
+          const u32 r0 = d0 / 3, f0 = d0 - 3 * r0;
+          const u32 q0 = (u32) j * NT + (u32) wid * WAVE;
+          const bool straddle = q0 < cA && q0 + WAVE > cA; /* wave-uniform */
+          const u32x4 pj = straddle ? (pre[j] | pre_x) : pre[j];
+          const u32 w[4] = { pj.x, pj.y, pj.z, pj.w };
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const u32 fi = f0 + (u32) i;                       /* 0 .. 5 */
+            const u32 r = rbase + r0 + (fi >= 3 ? 1u : 0u);    /* f0 + i < 6: at most one wrap */
+            const u32 f = fi >= 3 ? fi - 3 : fi;
+            if (d0 + (u32) i < lim) lds32[(f == 2) ? (2 * CAP + r) : (2 * r + f)] = w[i];
+          }
+        }
       }
     }
-    const u64 nxt = sh.tick[(it + 1) & 1];
+    if (DEFER && have_older && wid == 4) {
+      /* global offset of the tile ranked two iterations ago: its words were requested at the end
+       * of the previous iteration and are normally complete by now */
+      u64 x;
+      if (MODE == MODE_LOOKBACK) x = resolve_offset (agg + (u64) S0 * n_rows * WAVE, carry + (u64) S0 * (n_rows + 1), older_tile, lane, xagg, xcarry, ctl);
+      else x = desc[4 * older_tile + S0];
+      if (lane == 0) sh.excl[S0] = x;
+    }
+    PHASE_STAMP (0); /* phase 0: wait for the prefetched records, LDS writes */
     __syncthreads (); /* B0 */
-    if (tid == 0) sh.tick[it & 1] = atomicAdd (&ctl->ticket, 1u);
+    PHASE_STAMP (1); /* barrier B0 */
+    const int s_nxt = (it + 1) % 3, s_nn = (it + 2) % 3, s_cur = it % 3;
+    const u64 nxt = uniform32 (sh.tick[s_nxt]);
     TileRange tn = { 0, 0, 0, 0 };
     if (nxt < num_tiles) {
-      tn = load_tile_range (part, nxt);
-      fetch (tn); /* in flight until the next iteration's phase 0 */
+      tn.a0 = uniform64 (sh.rng[s_nxt][0]);
+      tn.b0 = uniform64 (sh.rng[s_nxt][1]);
+      tn.na = uniform32 ((u32) (sh.rng[s_nxt][2] - sh.rng[s_nxt][0]));
+      tn.nb = uniform32 ((u32) (sh.rng[s_nxt][3] - sh.rng[s_nxt][1]));
     }
+    /* housekeeping by thread 0, results consumed at the end of this iteration */
+    u32 hk_ticket = 0;
+    u64 hk_rng[4] = { 0, 0, 0, 0 };
+    bool hk_have_rng = false;
+    if (tid == 0) {
+      hk_ticket = claim ();
+      const u64 tnn = sh.tick[s_nn];
+      if (tnn < num_tiles) {
+        hk_have_rng = true;
+#pragma unroll
+        /* relaxed atomic loads: plain vector loads the wave does not wait for here (a scalar load
+         * of this uniform address would be waited for on the spot) */
+        for (int i = 0; i < 4; i++) hk_rng[i] = __hip_atomic_load (&part[2 * tnn + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    /* DEFER: write out the tile staged two iterations ago BEFORE the next fetch is issued: the
+     * memory counter retires in order, so the wait for the fetched records at the next phase 0
+     * then only ever waits on stores that are a whole iteration old */
+    if (DEFER && have_older) {
+      const u32 *const slot = sh.stage[it & 1];
+      u32 *__restrict__ dst = outs.rec[S0] + 3 * sh.excl[S0];
+      const u32 nd = 3 * older_tot;
+      for (u32 d = tid; d < nd; d += NT) dst[d] = slot[d];
+    }
+    if (nxt < num_tiles) fetch (tn); /* in flight until the next iteration's phase 0 */
 
-    /* ---- phase 1: rank, classify, predicates */
+    PHASE_STAMP (2); /* ring read, housekeeping issue, fetch issue */
+    /* ---- phase 1: rank, classify, predicates.  Chunks are handled two at a time so that every
+     * step of the search has two independent LDS reads in flight per lane. */
     u64 key[IPT];
     u32 fa[IPT], fb[IPT], meta[IPT]; /* meta: rank | kind << 16 | is_a << 18 */
     {
       const StreamCoef c0 = make_coef<0> (p), c1 = make_coef<1> (p), c2 = make_coef<2> (p), c3 = make_coef<3> (p);
+      static_assert (IPT % 2 == 0, "chunks are searched in pairs");
 #pragma unroll
-      for (int k = 0; k < IPT; k++) {
-        const u32 e = (u32) k * NT + (u32) tid;
-        const u32 chunk = (u32) k * NW + (u32) wid; /* wave-uniform */
-        const u32 cbeg = chunk * WAVE;
-        const bool chunk_live = cbeg < nt && (need_b || cbeg < na);
-        u64 ky = 0;
-        u32 xa = 0, xb = 0, kind = KIND_SKIP, r = 0, is_a = 0;
-        if (chunk_live) {
-          const bool valid = e < nt;
-          const u32 ec = valid ? e : 0u;
-          is_a = ec < na ? 1u : 0u;
-          ky = sh.keys[ec];
-          const u32 own = sh.cnts[ec];
-          const u32 obase = is_a ? na : 0u, on = is_a ? nb : na;
-          /* lower bound of ky in the other list */
-          u32 lo = 0, len = valid ? on : 0u;
-          while (len > 0) {
-            const u32 half = len >> 1;
-            if (sh.keys[obase + lo + half] < ky) {
-              lo += half + 1;
-              len -= half + 1;
-            } else {
-              len = half;
+      for (int kk = 0; kk < IPT; kk += 2) {
+        bool live[2], valid[2];
+        u32 is_a[2], own[2], obase[2], on[2], lim_n[2], lo[2];
+        u64 ky[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+          const u32 e = (u32) (kk + u) * NT + (u32) tid;
+          const u32 cbeg = ((u32) (kk + u) * NW + (u32) wid) * WAVE; /* wave-uniform */
+          live[u] = cbeg < nt && (need_b || cbeg < na);
+          valid[u] = live[u] && e < nt;
+          const u32 ec = valid[u] ? e : 0u;
+          is_a[u] = ec < na ? 1u : 0u;
+          ky[u] = sh.keys[ec];
+          own[u] = sh.cnts[ec];
+          obase[u] = is_a[u] ? na : 0u;
+          on[u] = is_a[u] ? nb : na;
+          lim_n[u] = valid[u] ? on[u] : 0u;
+          lo[u] = 0;
+        }
+        if (live[0] || live[1]) {
+          /* lower bound of ky in the other list: greedy bit-by-bit search with a fixed step
+           * sequence -- wave-uniform control, no per-step branching, LDS offsets folded into the
+           * instruction.  A probe beyond the list reads in-bounds garbage of this workgroup's LDS
+           * and is masked out. */
+#pragma unroll
+          for (u32 step = CAP / 2; step >= 1; step >>= 1) {
+            u64 pv[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) pv[u] = sh.keys[obase[u] + lo[u] + step - 1];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+              const bool lt = (lo[u] + step - 1 < lim_n[u]) & (pv[u] < ky[u]);
+              lo[u] += lt ? step : 0u;
             }
           }
-          r = lo;
-          const bool in = r < on;
-          const u32 oat = obase + (in ? r : 0u);
-          const bool matched = in && sh.keys[oat] == ky;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+          const int k = kk + u;
+          const u32 chunk = (u32) k * NW + (u32) wid;
+          const u32 r = lo[u];
+          const bool in = r < lim_n[u];
+          const u32 oat = obase[u] + (in ? r : 0u);
+          const u64 okey = sh.keys[oat];
           const u32 ocnt = sh.cnts[oat];
-          if (is_a) {
+          const bool matched = in & (okey == ky[u]);
+          u32 kind, xa, xb;
+          if (is_a[u]) {
             kind = matched ? KIND_BOTH : KIND_A;
-            xa = own;
+            xa = own[u];
             xb = matched ? ocnt : 0u;
           } else {
             kind = matched ? KIND_SKIP : KIND_B;
-            xb = own;
+            xa = 0;
+            xb = own[u];
           }
-          if (!valid) kind = KIND_SKIP;
-        }
-        key[k] = ky;
-        fa[k] = xa;
-        fb[k] = xb;
-        meta[k] = r | (kind << 16) | (is_a << 18);
-        u32 f;
-        if (ops & 1u) {
-          const bool keep = eval_stream<0> (kind, xa, xb, c0, f);
-          const u64 m = __ballot (keep);
-          if (lane == 0) sh.kmask[0][chunk] = m;
-          acc_sum0 += keep ? f : 0u;
-        }
-        if (ops & 2u) {
-          const bool keep = eval_stream<1> (kind, xa, xb, c1, f);
-          const u64 m = __ballot (keep);
-          if (lane == 0) sh.kmask[1][chunk] = m;
-          acc_sum1 += keep ? f : 0u;
-        }
-        if (ops & 4u) {
-          const bool keep = eval_stream<2> (kind, xa, xb, c2, f);
-          const u64 m = __ballot (keep);
-          if (lane == 0) sh.kmask[2][chunk] = m;
-          acc_sum2 += keep ? f : 0u;
-        }
-        if (ops & 8u) {
-          const bool keep = eval_stream<3> (kind, xa, xb, c3, f);
-          const u64 m = __ballot (keep);
-          if (lane == 0) sh.kmask[3][chunk] = m;
-          acc_sum3 += keep ? f : 0u;
+          if (!valid[u]) kind = KIND_SKIP;
+          key[k] = ky[u];
+          fa[k] = xa;
+          fb[k] = xb;
+          meta[k] = r | (kind << 16) | (is_a[u] << 18);
+          u32 f;
+          if (ops & 1u) {
+            const bool keep = eval_stream<0> (kind, xa, xb, c0, f);
+            const u64 m = __ballot (keep);
+            if (lane == 0) sh.kmask[0][chunk] = m;
+            acc_sum0 += keep ? f : 0u;
+          }
+          if (ops & 2u) {
+            const bool keep = eval_stream<1> (kind, xa, xb, c1, f);
+            const u64 m = __ballot (keep);
+            if (lane == 0) sh.kmask[1][chunk] = m;
+            acc_sum1 += keep ? f : 0u;
+          }
+          if (ops & 4u) {
+            const bool keep = eval_stream<2> (kind, xa, xb, c2, f);
+            const u64 m = __ballot (keep);
+            if (lane == 0) sh.kmask[2][chunk] = m;
+            acc_sum2 += keep ? f : 0u;
+          }
+          if (ops & 8u) {
+            const bool keep = eval_stream<3> (kind, xa, xb, c3, f);
+            const u64 m = __ballot (keep);
+            if (lane == 0) sh.kmask[3][chunk] = m;
+            acc_sum3 += keep ? f : 0u;
+          }
         }
       }
     }
@@ -517,7 +686,9 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
      * stream's count of every record alive across phase 2 instead of recomputing it (2x the VGPRs) */
 #pragma unroll
     for (int k = 0; k < IPT; k++) asm volatile ("" : "+v"(fa[k]), "+v"(fb[k]), "+v"(meta[k]));
+    PHASE_STAMP (3); /* phase 1 */
     __syncthreads (); /* B1: all input reads done */
+    PHASE_STAMP (4); /* barrier B1 */
 
     /* ---- phase 2: wavefront s owns stream s: chunk scan, tile total, publish for the scanner */
     if (wid < 4 && ((ops >> wid) & 1u)) {
@@ -534,68 +705,41 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
         if (MODE == MODE_COUNT) {
           if (desc) desc[4 * cur + s] = total; /* pass 1 of the two-pass path: counts for the scan kernel */
         } else if (MODE == MODE_LOOKBACK) {
-          publish_u32 (&agg[(u64) s * num_tiles + cur], AGG_READY | total);
+          publish_u32 (&agg[(u64) s * n_rows * WAVE + cur], AGG_READY | total);
         }
       }
       if (MODE != MODE_COUNT && !DEFER) {
-        /* the tile's own offset: wait for the scanner (or read the pre-scanned offsets) */
-        if (lane == 0) {
-          u64 x;
-          if (MODE == MODE_LOOKBACK) {
-            u64 *const w = &excl[(u64) s * num_tiles + cur];
-            u32 spins = 0;
-            while (!((x = peek_u64 (w)) & EXCL_READY)) {
-              if (++spins > SPIN_LIMIT) {
-                atomicOr (&ctl->error, 1u);
-                break;
-              }
-              __builtin_amdgcn_s_sleep (2);
-            }
-            x &= ~EXCL_READY;
-          } else {
-            x = desc[4 * cur + s];
-          }
-          sh.excl[s] = x;
-        }
-      }
-    } else if (DEFER && have_prev && wid == 4) {
-      /* offset of the PREVIOUS tile, published long ago by the scanner */
-      if (lane == 0) {
+        /* the tile's own offset: rows before it from the scanner, its own row summed here
+         * (or the pre-scanned offsets of the two-pass path) */
         u64 x;
-        if (MODE == MODE_LOOKBACK) {
-          u64 *const w = &excl[(u64) S0 * num_tiles + prev_tile];
-          u32 spins = 0;
-          while (!((x = peek_u64 (w)) & EXCL_READY)) {
-            if (++spins > SPIN_LIMIT) {
-              atomicOr (&ctl->error, 1u);
-              break;
-            }
-            __builtin_amdgcn_s_sleep (2);
-          }
-          x &= ~EXCL_READY;
-        } else {
-          x = desc[4 * prev_tile + S0];
-        }
-        sh.excl[S0] = x;
+        if (MODE == MODE_LOOKBACK) x = resolve_offset (agg + (u64) s * n_rows * WAVE, carry + (u64) s * (n_rows + 1), cur, lane, 0, 0, ctl);
+        else x = desc[4 * cur + s];
+        if (lane == 0) sh.excl[s] = x;
       }
     }
 
+    PHASE_STAMP (5); /* phase 2 */
     if (MODE != MODE_COUNT) {
       __syncthreads (); /* B2 */
       if (DEFER) {
-        /* write out the previous tile from the staging area, then stage this one */
-        if (have_prev) {
-          u32 *__restrict__ dst = outs.rec[S0] + 3 * sh.excl[S0];
-          const u32 nd = 3 * prev_tot;
-          for (u32 d = tid; d < nd; d += NT) dst[d] = sh.stage[d];
-        }
+        /* stage this tile in the slot the write-out at the top of this iteration freed */
+        u32 *const slot = sh.stage[it & 1];
         const u32 my_tot = sh.tot[S0];
-        __syncthreads (); /* B3: staging area free */
-        if (S0 == 0) scatter_stream<0, NT, IPT, OPS> (sh, sh.stage, p, na, lane, wid, key, fa, fb, meta);
-        else scatter_stream<1, NT, IPT, OPS> (sh, sh.stage, p, na, lane, wid, key, fa, fb, meta);
-        prev_tile = cur;
-        prev_tot = my_tot;
-        have_prev = true;
+        if (S0 == 0) scatter_stream<0, NT, IPT, OPS> (sh, slot, p, na, lane, wid, key, fa, fb, meta);
+        else scatter_stream<1, NT, IPT, OPS> (sh, slot, p, na, lane, wid, key, fa, fb, meta);
+        older_tile = newer_tile;
+        older_tot = newer_tot;
+        have_older = have_newer;
+        newer_tile = cur;
+        newer_tot = my_tot;
+        have_newer = true;
+        /* ask now for the words the next iteration's write-out needs: row counts and row carry
+         * of the tile staged one iteration ago (published a whole iteration ago) */
+        if (MODE == MODE_LOOKBACK && have_older && wid == 4) {
+          const u64 prow = older_tile / WAVE;
+          xagg = (u32) lane < (u32) (older_tile % WAVE) ? peek_u32 (&agg[(u64) S0 * n_rows * WAVE + prow * WAVE + lane]) : 0u;
+          xcarry = peek_u64 (&carry[(u64) S0 * (n_rows + 1) + prow]);
+        }
       } else {
 #pragma unroll
         for (int s = 0; s < 4; s++) {
@@ -614,36 +758,45 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
         }
       }
     }
+    PHASE_STAMP (6); /* B2, write-out, B3, scatter */
+    if (tid == 0) {
+      sh.tick[s_cur] = hk_ticket; /* becomes the "after next" ticket of the next iteration */
+      if (hk_have_rng) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) sh.rng[s_nn][i] = hk_rng[i];
+      }
+    }
+    PHASE_STAMP (7); /* housekeeping results */
     cur = nxt;
     tr = tn;
     it++;
   }
+#ifdef GT4_PROFILE_PHASES
+  if (tid == GT4_STAMP_TID)
+    for (int i = 0; i < 8; i++) atomicAdd (&ctl->phase_cycles[i], ph[i]);
+#endif
 
-  if (DEFER && have_prev) {
-    /* drain: the last staged tile */
-    __syncthreads ();
-    if (tid == 0) {
-      u64 x;
-      if (MODE == MODE_LOOKBACK) {
-        u64 *const w = &excl[(u64) S0 * num_tiles + prev_tile];
-        u32 spins = 0;
-        while (!((x = peek_u64 (w)) & EXCL_READY)) {
-          if (++spins > SPIN_LIMIT) {
-            atomicOr (&ctl->error, 1u);
-            break;
-          }
-          __builtin_amdgcn_s_sleep (2);
-        }
-        x &= ~EXCL_READY;
-      } else {
-        x = desc[4 * prev_tile + S0];
+  if (DEFER) {
+    /* drain: the (up to two) tiles still staged, oldest first */
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const bool have = q == 0 ? have_older : have_newer;
+      const u64 tile = q == 0 ? older_tile : newer_tile;
+      const u32 tot = q == 0 ? older_tot : newer_tot;
+      if (!have) continue;
+      __syncthreads ();
+      if (wid == 0) {
+        u64 x;
+        if (MODE == MODE_LOOKBACK) x = resolve_offset (agg + (u64) S0 * n_rows * WAVE, carry + (u64) S0 * (n_rows + 1), tile, lane, 0, 0, ctl);
+        else x = desc[4 * tile + S0];
+        if (lane == 0) sh.excl[S0] = x;
       }
-      sh.excl[S0] = x;
+      __syncthreads ();
+      const u32 *const slot = sh.stage[(it + q) & 1];
+      u32 *__restrict__ dst = outs.rec[S0] + 3 * sh.excl[S0];
+      const u32 nd = 3 * tot;
+      for (u32 d = tid; d < nd; d += NT) dst[d] = slot[d];
     }
-    __syncthreads ();
-    u32 *__restrict__ dst = outs.rec[S0] + 3 * sh.excl[S0];
-    const u32 nd = 3 * prev_tot;
-    for (u32 d = tid; d < nd; d += NT) dst[d] = sh.stage[d];
   }
 
   /* ---- kernel totals: header n_words / total_count (reference :801-802, :909-910) */
@@ -818,25 +971,39 @@ static hipError_t launch_pair_merge_ops (hipStream_t s, int mode, int grid, cons
 {
   if (mode == MODE_COUNT)
     hipLaunchKernelGGL ((k_pair_merge<MERGE_NT, MERGE_VT, MODE_COUNT, OPS>), dim3 (grid), dim3 (MERGE_NT), 0, s, A, nA, B, nB,
-                        (const u64 *) part, num_tiles, p, o, desc, ctl);
+                        (u64 *) part, num_tiles, p, o, desc, ctl);
   else if (mode == MODE_LOOKBACK)
     hipLaunchKernelGGL ((k_pair_merge<MERGE_NT, MERGE_VT, MODE_LOOKBACK, OPS>), dim3 (grid), dim3 (MERGE_NT), 0, s, A, nA, B, nB,
-                        (const u64 *) part, num_tiles, p, o, desc, ctl);
+                        (u64 *) part, num_tiles, p, o, desc, ctl);
   else
     hipLaunchKernelGGL ((k_pair_merge<MERGE_NT, MERGE_VT, MODE_OFFSETS, OPS>), dim3 (grid), dim3 (MERGE_NT), 0, s, A, nA, B, nB,
-                        (const u64 *) part, num_tiles, p, o, desc, ctl);
+                        (u64 *) part, num_tiles, p, o, desc, ctl);
   return hipGetLastError ();
 }
 
-int merge_blocks_per_cu ()
+template <int OPS>
+static int blocks_per_cu_ops (int mode)
 {
-  static int cached = 0;
-  if (!cached) {
-    int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor (&n, k_pair_merge<MERGE_NT, MERGE_VT, MODE_LOOKBACK, 0>, MERGE_NT, 0) != hipSuccess || n < 1) n = 1;
-    cached = n;
-  }
-  return cached;
+  int n = 0;
+  hipError_t e;
+  if (mode == MODE_COUNT) e = hipOccupancyMaxActiveBlocksPerMultiprocessor (&n, k_pair_merge<MERGE_NT, MERGE_VT, MODE_COUNT, OPS>, MERGE_NT, 0);
+  else if (mode == MODE_LOOKBACK) e = hipOccupancyMaxActiveBlocksPerMultiprocessor (&n, k_pair_merge<MERGE_NT, MERGE_VT, MODE_LOOKBACK, OPS>, MERGE_NT, 0);
+  else e = hipOccupancyMaxActiveBlocksPerMultiprocessor (&n, k_pair_merge<MERGE_NT, MERGE_VT, MODE_OFFSETS, OPS>, MERGE_NT, 0);
+  if (e != hipSuccess || n < 1) n = 1;
+  /* never more than the register file admits for the declared launch bounds */
+  const int by_regs = (OPS ? MERGE_WAVES_PER_SIMD : MERGE_WAVES_PER_SIMD_GENERIC) * 4 / (MERGE_NT / 64);
+  if (by_regs >= 1 && n > by_regs) n = by_regs;
+  return n;
+}
+
+/* workgroups of the merge kernel that are resident per CU (the single-pass path needs every
+ * worker resident: see k_pair_merge) */
+int merge_blocks_per_cu (int mode, uint32_t ops)
+{
+  static int cache[3][3];
+  const int oi = ops == 1u ? 1 : (ops == 2u ? 2 : 0);
+  if (!cache[mode][oi]) cache[mode][oi] = oi == 1 ? blocks_per_cu_ops<1> (mode) : (oi == 2 ? blocks_per_cu_ops<2> (mode) : blocks_per_cu_ops<0> (mode));
+  return cache[mode][oi];
 }
 
 hipError_t launch_pair_merge (hipStream_t s, int mode, int grid, const uint32_t *A, uint64_t nA,
