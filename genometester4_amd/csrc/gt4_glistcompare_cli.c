@@ -1,0 +1,447 @@
+/*
+ * gt4_glistcompare_cli.c -- `glistcompare`, the drop-in command line of the GPU set-operation
+ * path.  Host C; every merge runs in the HIP kernels behind include/gt4hip.h.
+ *
+ * Same argv grammar, defaults, validation order, messages, output names (`<out>_<k>_union.list`
+ * ...), tmp + rename discipline, stdout of --count_only / --print_operation / -v and exit codes
+ * as the reference's main() (reference src/glistcompare.c:84-429, naming :814-834, :907-953).
+ * Deliberate differences, all loud:
+ *   - a file that cannot be opened is an error message + exit 1 (the reference dereferences NULL);
+ *   - GT4I index inputs, -mm and --subset are outside the GPU path: error + exit 1;
+ *   - --stream and --disable_scouts are accepted and ignored (the whole list is uploaded to HBM;
+ *     results are identical for well-formed files);
+ *   - without a usable GPU the program fails: there is no CPU fallback.
+ */
+#define _GNU_SOURCE
+#include <errno.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/stat.h>
+#include <sys/time.h>
+#include <unistd.h>
+
+#include "gt4_listfile.h"
+#include "gt4hip.h"
+
+#define MAX_FILES 1024
+
+enum { OPT_PLAIN, OPT_VERSION, OPT_HELP, OPT_OUT, OPT_CUTOFF, OPT_MM, OPT_UNION, OPT_INTRSEC, OPT_DIFF, OPT_DDIFF, OPT_DU,
+       OPT_COUNT_ONLY, OPT_RULE, OPT_SUBSET, OPT_SEED, OPT_PRINT_OP, OPT_NOSCOUTS, OPT_STREAM, OPT_DEBUG };
+
+static const struct {
+  const char *name;
+  int opt;
+} OPTIONS[] = {
+  { "-v", OPT_VERSION }, { "--version", OPT_VERSION }, { "-h", OPT_HELP }, { "--help", OPT_HELP }, { "-?", OPT_HELP },
+  { "-o", OPT_OUT }, { "--outputname", OPT_OUT }, { "-c", OPT_CUTOFF }, { "--cutoff", OPT_CUTOFF },
+  { "--count_cutoff", OPT_CUTOFF }, /* alias used by the benchmark description; not in the reference */
+  { "-mm", OPT_MM }, { "--mismatch", OPT_MM }, { "-u", OPT_UNION }, { "--union", OPT_UNION },
+  { "-i", OPT_INTRSEC }, { "--intersection", OPT_INTRSEC }, { "-d", OPT_DIFF }, { "--difference", OPT_DIFF },
+  { "-dd", OPT_DDIFF }, { "--double_difference", OPT_DDIFF }, { "-du", OPT_DU }, { "--diff_union", OPT_DU },
+  { "--count_only", OPT_COUNT_ONLY }, { "-r", OPT_RULE }, { "--rule", OPT_RULE }, { "-ss", OPT_SUBSET }, { "--subset", OPT_SUBSET },
+  { "--seed", OPT_SEED }, { "--print_operation", OPT_PRINT_OP }, { "--disable_scouts", OPT_NOSCOUTS }, { "--stream", OPT_STREAM },
+  { "-D", OPT_DEBUG },
+};
+
+static const char *const HELP_LINES[] = {
+  "Usage: glistcompare INPUTLIST1 [INPUTLIST2...] METHOD [OPTIONS]",
+  "Options:",
+  "    -v, --version            - print version information and exit",
+  "    -h, --help               - print this usage screen and exit",
+  "    -u, --union              - union of input lists",
+  "    -i, --intersection       - intersection of input lists",
+  "    -d, --difference         - difference of input lists",
+  "    -dd, --double_difference - double difference of input lists",
+  "    -du, --diff_union        - subtract first list from the second and finds difference",
+  "    -mm, --mismatch   NUMBER - specify number of mismatches (default 0, can be used with -diff and -ddiff)",
+  "    -c, --cutoff NUMBER      - specify frequency cut-off (default 1)",
+  "    -o, --outputname STRING  - specify output name (default \"out\")",
+  "    -r, --rule STRING        - specify rule how final frequencies are calculated (default, add, subtract, min, max, first, second, 1, 2)",
+  "                               NOTE: rules min, subtract, first and second can only be used with finding the intersection.",
+  "    -ss, --subset METHOD SIZE - make subset with given method (rand, rand_unique, rand_weighted_unique)",
+  "    --seed INTEGER           - Set seed of random number generator (default uses start time)",
+  "    --count_only             - output count of k-mers instead of k-mers themself",
+  "    --disable_scouts         - disable list read-ahead in background thread",
+  "    --stream                 - read input as stream (do not memory map files)",
+  "    -D                       - increase debug level",
+};
+
+static void print_version (void)
+{
+  fprintf (stdout, "glistcompare version %u.%u.%u (%s)\n", GT4_VERSION_MAJOR, GT4_VERSION_MINOR, GT4_VERSION_MICRO, GT4_VERSION_QUALIFIER);
+}
+
+static void print_help (int exit_value)
+{
+  print_version ();
+  for (size_t i = 0; i < sizeof HELP_LINES / sizeof HELP_LINES[0]; i++) fprintf (stdout, "%s\n", HELP_LINES[i]);
+  exit (exit_value);
+}
+
+static int lookup_option (const char *arg)
+{
+  for (size_t i = 0; i < sizeof OPTIONS / sizeof OPTIONS[0]; i++)
+    if (!strcmp (arg, OPTIONS[i].name)) return OPTIONS[i].opt;
+  return -1;
+}
+
+static double now_seconds (void)
+{
+  struct timeval tv;
+  gettimeofday (&tv, NULL);
+  return tv.tv_sec + tv.tv_usec * 1e-6;
+}
+
+#define DOWNLOAD_CHUNK (4u << 20) /* records per device -> host -> file step (48 MiB) */
+
+/* device list -> "<final>.tmp" -> rename, header back-patched with the kernel's totals */
+static int write_list_file (gt4hip_context *ctx, const gt4hip_list *list, unsigned int word_length, uint64_t n_words, uint64_t total_count,
+                            const char *final_name, unsigned int mode)
+{
+  char tmp_name[2048];
+  snprintf (tmp_name, sizeof tmp_name, "%s.tmp", final_name);
+  GT4ListWriter w;
+  if (gt4_listwriter_begin (&w, tmp_name, word_length, mode)) {
+    fprintf (stderr, "Error: Cannot create output file %s\n", tmp_name);
+    return 1;
+  }
+  int bad = 0;
+  void *buf = n_words ? malloc ((size_t) (n_words < DOWNLOAD_CHUNK ? n_words : DOWNLOAD_CHUNK) * 12u) : NULL;
+  if (n_words && !buf) bad = 1;
+  for (uint64_t first = 0; first < n_words && !bad; first += DOWNLOAD_CHUNK) {
+    const uint64_t cnt = n_words - first < DOWNLOAD_CHUNK ? n_words - first : DOWNLOAD_CHUNK;
+    if (gt4hip_list_download_range (ctx, list, first, cnt, buf)) {
+      fprintf (stderr, "Error: reading results back from the GPU failed: %s\n", gt4hip_last_error (ctx));
+      bad = 1;
+    } else if (gt4_listwriter_append (&w, buf, cnt)) {
+      fprintf (stderr, "Error: writing %s failed: %s\n", tmp_name, strerror (errno));
+      bad = 1;
+    }
+  }
+  free (buf);
+  if (bad) {
+    gt4_listwriter_abort (&w);
+    unlink (tmp_name);
+    return 1;
+  }
+  if (gt4_listwriter_finish (&w, n_words, total_count)) {
+    fprintf (stderr, "Error: writing %s failed: %s\n", tmp_name, strerror (errno));
+    unlink (tmp_name);
+    return 1;
+  }
+  if (rename (tmp_name, final_name)) {
+    fprintf (stderr, "Error: Cannot rename %s to %s\n", tmp_name, final_name);
+    return 1;
+  }
+  return 0;
+}
+
+int main (int argc, const char *argv[])
+{
+  const char *fnames[MAX_FILES];
+  unsigned int nfiles = 0;
+  int rule = GT4HIP_RULE_DEFAULT;
+  unsigned int cutoff = 1, nmm = 0, count_override = 1;
+  int find_union = 0, find_intrsec = 0, find_diff = 0, find_ddiff = 0, subtraction = 0, countonly = 0, print_operation = 0;
+  int find_subset = 0, stream = 0, debug = 0;
+  const char *outputname = "out";
+  char *end;
+
+  if (argc <= 1) print_help (1);
+
+  /* ---- argv (reference :107-230; every quirk of its hand-rolled loop is kept) */
+  for (int i = 1; i < argc; i++) {
+    const char *arg = argv[i];
+    if (arg[0] != '-') {
+      if (nfiles >= MAX_FILES) {
+        fprintf (stderr, "Too many file arguments (max %d)\n", MAX_FILES);
+        print_help (1);
+      }
+      fnames[nfiles++] = arg;
+      continue;
+    }
+    switch (lookup_option (arg)) {
+      case OPT_VERSION:
+        print_version ();
+        return 0;
+      case OPT_HELP:
+        print_help (0);
+        break;
+      case OPT_OUT:
+        if (!argv[i + 1] || argv[i + 1][0] == '-') {
+          fprintf (stderr, "Warning: No output name specified!\n");
+          i += 1; /* the reference skips the next argument here as well */
+          break;
+        }
+        outputname = argv[++i];
+        break;
+      case OPT_CUTOFF:
+        if (!argv[i + 1]) {
+          fprintf (stderr, "Warning: No frequency cut-off specified! Using the default value: %d.\n", cutoff);
+          break;
+        }
+        cutoff = (unsigned int) strtol (argv[i + 1], &end, 10);
+        if (*end != 0) {
+          fprintf (stderr, "Error: Invalid frequency cut-off: %s! Must be an integer.\n", argv[i + 1]);
+          print_help (1);
+        }
+        i += 1;
+        break;
+      case OPT_MM:
+        if (!argv[i + 1]) {
+          fprintf (stderr, "Warning: No number of mismatches specified!");
+          break;
+        }
+        nmm = (unsigned int) strtol (argv[i + 1], &end, 10);
+        if (*end != 0) {
+          fprintf (stderr, "Error: Invalid number of mismatches: %s! Must be an integer.\n", argv[i + 1]);
+          print_help (1);
+        }
+        i += 1;
+        break;
+      case OPT_UNION: find_union = 1; break;
+      case OPT_INTRSEC: find_intrsec = 1; break;
+      case OPT_DIFF: find_diff = 1; break;
+      case OPT_DDIFF: find_ddiff = 1; break;
+      case OPT_DU:
+        find_diff = 1;
+        subtraction = 1;
+        break;
+      case OPT_COUNT_ONLY: countonly = 1; break;
+      case OPT_RULE: {
+        static const struct { const char *name; int rule; } RULES[] = {
+          { "default", GT4HIP_RULE_DEFAULT }, { "add", GT4HIP_RULE_ADD }, { "sum", GT4HIP_RULE_ADD }, { "subtract", GT4HIP_RULE_SUBTRACT },
+          { "min", GT4HIP_RULE_MIN }, { "max", GT4HIP_RULE_MAX }, { "first", GT4HIP_RULE_FIRST }, { "second", GT4HIP_RULE_SECOND },
+        };
+        i += 1;
+        if (i >= argc) print_help (1);
+        if (argv[i][0] >= '1' && argv[i][0] <= '9') {
+          rule = GT4HIP_RULE_NUMBER;
+          count_override = (unsigned int) strtol (argv[i], &end, 10);
+        } else {
+          for (size_t r = 0; r < sizeof RULES / sizeof RULES[0]; r++)
+            if (!strcmp (argv[i], RULES[r].name)) rule = RULES[r].rule;
+          /* an unknown rule name is silently ignored, as in the reference */
+        }
+        break;
+      }
+      case OPT_SUBSET:
+        find_subset = 1;
+        i += 1;
+        if (i >= argc) print_help (1);
+        if (strcmp (argv[i], "rand") && strcmp (argv[i], "rand_unique") && strcmp (argv[i], "rand_weighted_unique")) print_help (1);
+        i += 1;
+        if (i >= argc) print_help (1);
+        (void) strtoll (argv[i], &end, 10);
+        if (*end != 0) {
+          fprintf (stderr, "Error: Invalid subset size: %s! Must be an integer.\n", argv[i]);
+          print_help (1);
+        }
+        break;
+      case OPT_SEED:
+        i += 1;
+        if (i >= argc) print_help (1);
+        break; /* only --subset draws random numbers */
+      case OPT_PRINT_OP: print_operation = 1; break;
+      case OPT_NOSCOUTS: break;
+      case OPT_STREAM: stream = 1; break;
+      case OPT_DEBUG: debug += 1; break;
+      default:
+        fprintf (stderr, "Unknown argument: %s!\n", arg);
+        print_help (1);
+    }
+  }
+  if (debug) fprintf (stderr, "Rule: %d\n", rule);
+  if (debug) fprintf (stderr, "Num files: %d\n", nfiles);
+  if (nmm || find_subset) {
+    if (stream) fprintf (stderr, "Warning: Subset and mismatches are incompatible with streaming, using mapping\n");
+    stream = 0;
+  }
+
+  /* ---- open the inputs (reference :250-290) */
+  static GT4ListFile files[MAX_FILES];
+  unsigned int wlen = 0, err = 0;
+  for (unsigned int f = 0; f < nfiles; f++) {
+    uint32_t code;
+    files[f].file_map = NULL;
+    if (gt4_listfile_sniff (fnames[f], &code)) {
+      fprintf (stderr, "Error: Cannot open %s\n", fnames[f]);
+      err = 1;
+      continue;
+    }
+    if (code == GT4_INDEX_CODE_VALUE) {
+      fprintf (stderr, "Error: File %s is a GT4I index; index inputs are not supported by the GPU path\n", fnames[f]);
+      err = 1;
+      continue;
+    }
+    if (code != GT4_LIST_CODE_VALUE) {
+      fprintf (stderr, "Error: File %s has unknown format\n", fnames[f]);
+      err = 1;
+      continue;
+    }
+    if (gt4_listfile_open (fnames[f], GT4_VERSION_MAJOR, &files[f])) {
+      fprintf (stderr, "Error: File %s is invalid or corrupted\n", fnames[f]);
+      err = 1;
+      continue;
+    }
+    if (!wlen) {
+      wlen = files[f].header.word_length;
+    } else if (files[f].header.word_length != wlen) {
+      fprintf (stderr, "Error: File %s has different word length (%u != %u)\n", fnames[f], files[f].header.word_length, wlen);
+      err = 1;
+    }
+  }
+  if (err) {
+    fprintf (stderr, "Stopping...\n");
+    exit (1);
+  }
+  if (find_subset) {
+    fprintf (stderr, "Error: --subset is not part of the GPU set-operation path\n");
+    exit (1);
+  }
+
+  /* ---- validity checks, in the reference's order (:317-352) */
+  if (nfiles < 2) {
+    fprintf (stderr, "Error: At least 2 list/index files are needed\n");
+    exit (1);
+  }
+  if (nfiles > 2) {
+    if (!(find_union || find_intrsec) || find_diff || find_ddiff) {
+      fprintf (stderr, "Error: Algorithm incompatible with multiple files!\n");
+      print_help (1);
+    }
+    if (nmm) {
+      fprintf (stderr, "Error: Multiple files are not compatible with mismatches!\n");
+      print_help (1);
+    }
+  }
+  if (find_ddiff) find_diff = 1;
+  if (!find_diff && nmm) fprintf (stderr, "Warning: Number of mismatches are not used!\n");
+  if (!find_diff && subtraction) fprintf (stderr, "Warning: Subtraction is not used!\n");
+  if (strlen (outputname) > 200) {
+    fprintf (stderr, "Error: Output name exceeds the 200 character limit.\n");
+    exit (1);
+  }
+  if (!find_intrsec && (rule == GT4HIP_RULE_MIN || rule == GT4HIP_RULE_FIRST || rule == GT4HIP_RULE_SECOND)) {
+    fprintf (stderr, "Error: Rules min, fist and second can only be used with finding the intersection.\n");
+    exit (1);
+  }
+  if ((!find_intrsec && !find_diff) && (rule == GT4HIP_RULE_SUBTRACT)) {
+    fprintf (stderr, "Error: Rule subtract can only be used with intersection and difference.\n");
+    exit (1);
+  }
+  if (print_operation) {
+    fprintf (stdout, "Operation\t%s%s%s%s\trule\t%u\nFiles\t%u\n", find_union ? "U" : "", find_intrsec ? "I" : "", find_diff ? "D" : "",
+             find_ddiff ? "X" : "", rule, nfiles);
+    for (unsigned int f = 0; f < nfiles; f++) fprintf (stdout, "%u\t%s\n", f, fnames[f]);
+  }
+  if (nmm) {
+    fprintf (stderr, "Error: -mm (mismatch difference) is not part of the GPU set-operation path\n");
+    exit (1);
+  }
+
+  /* ---- the device */
+  gt4hip_context *ctx = NULL;
+  {
+    const char *dev = getenv ("GT4HIP_DEVICE");
+    if (gt4hip_create (dev ? atoi (dev) : 0, &ctx)) {
+      fprintf (stderr, "Error: %s\n", gt4hip_last_error (NULL));
+      exit (1);
+    }
+    if (debug) fprintf (stderr, "Device: %s\n", gt4hip_device_info (ctx));
+  }
+  static gt4hip_list *lists[MAX_FILES];
+  for (unsigned int f = 0; f < nfiles; f++) {
+    if (gt4hip_list_upload (ctx, files[f].records, files[f].header.n_words, wlen, &lists[f])) {
+      fprintf (stderr, "Error: uploading %s to the GPU failed: %s\n", fnames[f], gt4hip_last_error (ctx));
+      exit (1);
+    }
+  }
+
+  int v = 0;
+  if (nfiles == 2) {
+    /* ---- compare_wordmaps (reference :789-955) */
+    static const char *const SUFFIX[4] = { "union", "intrsec", "0_diff1", "0_diff2" };
+    if (debug) {
+      fprintf (stderr, "compare_wordmaps: methods %u/%u/%u/%u\n", find_union, find_intrsec, find_diff, find_ddiff);
+      fprintf (stderr, "compare_wordmaps: List 1: %llu entries\n", (unsigned long long) files[0].header.n_words);
+      fprintf (stderr, "compare_wordmaps; List 2: %llu entries\n", (unsigned long long) files[1].header.n_words);
+    }
+    gt4hip_compare_params prm;
+    memset (&prm, 0, sizeof prm);
+    prm.ops = (find_union ? GT4HIP_OP_UNION : 0) | (find_intrsec ? GT4HIP_OP_INTRSEC : 0) | (find_diff ? GT4HIP_OP_DIFF1 : 0) |
+              (find_ddiff ? GT4HIP_OP_DIFF2 : 0);
+    prm.rule = rule;
+    prm.cutoff = cutoff;
+    prm.subtract = subtraction;
+    prm.count_override = count_override;
+    prm.count_only = countonly;
+    gt4hip_compare_result res;
+    memset (&res, 0, sizeof res);
+    if (prm.ops) {
+      if (gt4hip_compare (ctx, lists[0], lists[1], &prm, &res)) {
+        fprintf (stderr, "Error: %s\n", gt4hip_last_error (ctx));
+        exit (1);
+      }
+      if (debug) fprintf (stderr, "GPU merge kernel: %.3f ms (%llu tiles), device total %.3f ms\n", res.merge_kernel_ms,
+                          (unsigned long long) res.merge_tiles, res.device_ms);
+    }
+    for (int s = 0; s < 4; s++) {
+      if (!((prm.ops >> s) & 1u)) continue;
+      if (countonly) {
+        fprintf (stdout, "NUnique\t%llu\nNTotal\t%llu\n", (unsigned long long) res.n_words[s], (unsigned long long) res.total_count[s]);
+        continue;
+      }
+      char name[2048];
+      snprintf (name, sizeof name, "%s_%d_%s.list", outputname, wlen, SUFFIX[s]);
+      if (debug && s >= 2) fprintf (stderr, "Renaming %s.tmp to %s\n", name, name);
+      /* fopen (.., "w") in the reference: mode 0666 minus umask */
+      if (write_list_file (ctx, res.out[s], wlen, res.n_words[s], res.total_count[s], name, 0666)) exit (1);
+      gt4hip_list_free (res.out[s]);
+    }
+  } else {
+    /* ---- union_multi / intersect_multi (reference :366-422) */
+    for (int pass = 0; pass < 2; pass++) {
+      const int is_union = pass == 0;
+      if (is_union ? !find_union : !find_intrsec) continue;
+      gt4hip_multi_result res;
+      memset (&res, 0, sizeof res);
+      const double t_s = now_seconds ();
+      int rc = is_union ? gt4hip_union_multi (ctx, (const gt4hip_list *const *) lists, nfiles, cutoff, rule, count_override, countonly, &res)
+                        : gt4hip_intersect_multi (ctx, (const gt4hip_list *const *) lists, nfiles, cutoff, rule, count_override, countonly, &res);
+      const double t_e = now_seconds ();
+      if (rc == GT4HIP_ERULE) {
+        fprintf (stderr, "%s\n", gt4hip_last_error (ctx));
+        v = 1; /* the reference returns 1 from the merge and exits 1 without an output file */
+        continue;
+      }
+      if (rc) {
+        fprintf (stderr, "Error: %s\n", gt4hip_last_error (ctx));
+        exit (1);
+      }
+      v = 0;
+      if (debug) {
+        unsigned long long total = 0;
+        for (unsigned int f = 0; f < nfiles; f++) total += files[f].header.n_words;
+        fprintf (stderr, "Combined %u maps: input %llu (%.3f Mwords/s) output %llu (%.3f Mwords/s)\n", nfiles, is_union ? total : 0ull,
+                 (is_union ? total : 0ull) / (1000000 * (t_e - t_s)), (unsigned long long) res.n_words, res.n_words / (1000000 * (t_e - t_s)));
+      }
+      if (!countonly) {
+        char name[2048];
+        snprintf (name, sizeof name, "%s_%d_%s.list", outputname, wlen, is_union ? "union" : "intrsec");
+        /* creat (.., 0644) in the reference */
+        if (write_list_file (ctx, res.out, wlen, res.n_words, res.total_count, name, 0644)) exit (1);
+        gt4hip_list_free (res.out);
+      }
+      if (countonly || debug) fprintf (stdout, "NUnique\t%llu\nNTotal\t%llu\n", (unsigned long long) res.n_words, (unsigned long long) res.total_count);
+    }
+  }
+
+  for (unsigned int f = 0; f < nfiles; f++) {
+    gt4hip_list_free (lists[f]);
+    gt4_listfile_close (&files[f]);
+  }
+  gt4hip_destroy (ctx);
+  return v ? 1 : 0;
+}

@@ -1,0 +1,230 @@
+/*
+ * gt4_setops.c -- gt4_write_union / gt4_union / gt4_is_union (include/gt4_set_operations.h) on top
+ * of the C ABI in include/gt4hip.h.  Host C; the merges run in the HIP kernels.  No CPU fallback:
+ * without a device every entry point fails.
+ */
+#define _GNU_SOURCE
+#include "gt4_set_operations.h"
+
+#include <errno.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+struct _GT4HipWordList {
+  gt4hip_list *dev;
+  uint64_t num_words;
+  uint64_t sum_counts;
+  unsigned int word_length;
+  uint64_t last_key; /* key of the last record (valid when num_words > 0) */
+};
+
+static gt4hip_context *g_ctx = NULL;
+
+gt4hip_context *gt4_hip_default_context (void)
+{
+  if (!g_ctx) {
+    const char *dev = getenv ("GT4HIP_DEVICE");
+    int rc = gt4hip_create (dev ? atoi (dev) : 0, &g_ctx);
+    if (rc) {
+      fprintf (stderr, "Error: GPU set operations unavailable: %s\n", gt4hip_last_error (NULL));
+      g_ctx = NULL;
+    }
+  }
+  return g_ctx;
+}
+
+static GT4HipWordList *wrap_uploaded (gt4hip_context *ctx, gt4hip_list *dev, uint64_t n, unsigned int wl, uint64_t sum, int have_sum)
+{
+  GT4HipWordList *l = (GT4HipWordList *) calloc (1, sizeof *l);
+  if (!l) {
+    gt4hip_list_free (dev);
+    return NULL;
+  }
+  l->dev = dev;
+  l->num_words = n;
+  l->word_length = wl;
+  if (have_sum) l->sum_counts = sum;
+  else if (gt4hip_list_sum_counts (ctx, dev, &l->sum_counts)) l->sum_counts = 0;
+  if (n) {
+    uint32_t c;
+    if (gt4hip_list_get_word (ctx, dev, n - 1, &l->last_key, &c)) l->last_key = 0;
+  }
+  return l;
+}
+
+GT4HipWordList *gt4_hip_word_list_new (const char *listfilename, unsigned int major_version)
+{
+  gt4hip_context *ctx = gt4_hip_default_context ();
+  if (!ctx) return NULL;
+  GT4ListFile lf;
+  if (gt4_listfile_open (listfilename, major_version, &lf)) return NULL;
+  gt4hip_list *dev = NULL;
+  int rc = gt4hip_list_upload (ctx, lf.records, lf.header.n_words, lf.header.word_length, &dev);
+  const uint64_t n = lf.header.n_words, total = lf.header.total_count;
+  const unsigned int wl = lf.header.word_length;
+  gt4_listfile_close (&lf);
+  if (rc) {
+    fprintf (stderr, "gt4_hip_word_list_new: upload of %s failed: %s\n", listfilename, gt4hip_last_error (ctx));
+    return NULL;
+  }
+  return wrap_uploaded (ctx, dev, n, wl, total, 1);
+}
+
+GT4HipWordList *gt4_hip_word_list_new_from_records (const void *records, uint64_t n_words, unsigned int word_length)
+{
+  gt4hip_context *ctx = gt4_hip_default_context ();
+  if (!ctx) return NULL;
+  gt4hip_list *dev = NULL;
+  if (gt4hip_list_upload (ctx, records, n_words, word_length, &dev)) {
+    fprintf (stderr, "gt4_hip_word_list_new_from_records: %s\n", gt4hip_last_error (ctx));
+    return NULL;
+  }
+  return wrap_uploaded (ctx, dev, n_words, word_length, 0, 0);
+}
+
+void gt4_hip_word_list_delete (GT4HipWordList *list)
+{
+  if (!list) return;
+  gt4hip_list_free (list->dev);
+  free (list);
+}
+
+uint64_t gt4_hip_word_list_num_words (const GT4HipWordList *list) { return list ? list->num_words : 0; }
+uint64_t gt4_hip_word_list_sum_counts (const GT4HipWordList *list) { return list ? list->sum_counts : 0; }
+unsigned int gt4_hip_word_list_word_length (const GT4HipWordList *list) { return list ? list->word_length : 0; }
+const gt4hip_list *gt4_hip_word_list_device (const GT4HipWordList *list) { return list ? list->dev : NULL; }
+
+static int write_fully (int fd, const void *buf, size_t len)
+{
+  const char *p = (const char *) buf;
+  while (len) {
+    ssize_t w = write (fd, p, len);
+    if (w < 0) {
+      if (errno == EINTR) continue;
+      return 1;
+    }
+    p += w;
+    len -= (size_t) w;
+  }
+  return 0;
+}
+
+#define DOWNLOAD_CHUNK (4u << 20) /* records per device -> host -> file step (48 MiB) */
+
+unsigned int gt4_write_union (GT4HipWordList *arrays[], unsigned int n_arrays, unsigned int cutoff, int ofile, GT4ListHeader *header)
+{
+  /* src/set-operations.c:49-50 */
+  if (n_arrays == 0 || n_arrays > GT4_MAX_SETS || !arrays || !header) return 1;
+  gt4hip_context *ctx = gt4_hip_default_context ();
+  if (!ctx) return 1;
+  const gt4hip_list **devs = (const gt4hip_list **) malloc (n_arrays * sizeof *devs);
+  if (!devs) return 1;
+  for (unsigned int j = 0; j < n_arrays; j++) devs[j] = arrays[j]->dev;
+  /* the reference takes the word length of the last non-empty list it looked at, or of the last
+   * list when all are empty (:54-63); identical for well-formed input where all lengths agree */
+  gt4_list_header_init (header, arrays[0]->word_length);
+  gt4hip_multi_result res;
+  memset (&res, 0, sizeof res);
+  int rc = gt4hip_union_multi (ctx, devs, n_arrays, cutoff, GT4HIP_RULE_ADD, 0, ofile ? 0 : 1, &res);
+  free (devs);
+  if (rc) {
+    fprintf (stderr, "gt4_write_union: %s\n", gt4hip_last_error (ctx));
+    return 1;
+  }
+  header->n_words = res.n_words;
+  header->total_count = res.total_count;
+  unsigned int bad = 0;
+  if (ofile) {
+    /* header, then the records, streamed device -> host -> fd (:65, :104-121) */
+    bad |= write_fully (ofile, header, sizeof *header);
+    const uint64_t n = res.n_words;
+    void *buf = n ? malloc ((size_t) (n < DOWNLOAD_CHUNK ? n : DOWNLOAD_CHUNK) * 12u) : NULL;
+    if (n && !buf) bad = 1;
+    for (uint64_t first = 0; first < n && !bad; first += DOWNLOAD_CHUNK) {
+      const uint64_t cnt = n - first < DOWNLOAD_CHUNK ? n - first : DOWNLOAD_CHUNK;
+      if (gt4hip_list_download_range (ctx, res.out, first, cnt, buf)) bad = 1;
+      else bad |= write_fully (ofile, buf, (size_t) cnt * 12u);
+    }
+    free (buf);
+  }
+  gt4hip_list_free (res.out);
+  return bad;
+}
+
+#define TABLE_CHUNK (1u << 20) /* table rows per download */
+
+static unsigned int walk_table (gt4hip_context *ctx, gt4hip_count_table *t, GT4HipWordList *objs[], unsigned int n_objs, int quirk,
+                                unsigned int (*callback) (uint64_t, uint32_t *, void *), void *data)
+{
+  const uint64_t n = t->n_keys;
+  unsigned int result = 0;
+  if (!n) return 0;
+  const uint64_t rows = n < TABLE_CHUNK ? n : TABLE_CHUNK;
+  uint64_t *keys = (uint64_t *) malloc ((size_t) rows * 8);
+  uint32_t *counts = (uint32_t *) malloc ((size_t) rows * n_objs * 4);
+  uint32_t *zeros = (uint32_t *) calloc (n_objs, 4);
+  if (!keys || !counts || !zeros) result = 1;
+  uint64_t last_union_key = 0;
+  if (!result && quirk) {
+    /* the union's largest key: after it nothing remains, so no repeated visit there */
+    for (unsigned int j = 0; j < n_objs; j++)
+      if (objs[j]->num_words && objs[j]->last_key > last_union_key) last_union_key = objs[j]->last_key;
+  }
+  for (uint64_t first = 0; first < n && !result; first += TABLE_CHUNK) {
+    const uint64_t cnt = n - first < TABLE_CHUNK ? n - first : TABLE_CHUNK;
+    if (gt4hip_table_download (ctx, t, first, cnt, keys, counts)) {
+      fprintf (stderr, "gt4_union: %s\n", gt4hip_last_error (ctx));
+      result = 1;
+      break;
+    }
+    for (uint64_t i = 0; i < cnt && !result; i++) {
+      result = callback (keys[i], counts + i * n_objs, data);
+      if (result || !quirk || keys[i] == last_union_key) continue;
+      /* src/set-operations.c:166-170: a list that has just run out still feeds its last word into
+       * `next`, so the reference visits that word a second time, with all counts 0 */
+      int exhausted_here = 0;
+      for (unsigned int j = 0; j < n_objs; j++) exhausted_here |= objs[j]->num_words && objs[j]->last_key == keys[i];
+      if (exhausted_here) {
+        memset (zeros, 0, (size_t) n_objs * 4);
+        result = callback (keys[i], zeros, data);
+      }
+    }
+  }
+  free (keys);
+  free (counts);
+  free (zeros);
+  return result;
+}
+
+static unsigned int table_walk (GT4HipWordList *objs[], unsigned int n_objs, int probe,
+                                unsigned int (*callback) (uint64_t, uint32_t *, void *), void *data)
+{
+  if (n_objs == 0 || n_objs > GT4_MAX_SETS || !objs || !callback) return 1; /* src/set-operations.c:140-141 */
+  gt4hip_context *ctx = gt4_hip_default_context ();
+  if (!ctx) return 1;
+  const gt4hip_list **devs = (const gt4hip_list **) malloc (n_objs * sizeof *devs);
+  if (!devs) return 1;
+  for (unsigned int j = 0; j < n_objs; j++) devs[j] = objs[j]->dev;
+  gt4hip_count_table t;
+  int rc = probe ? gt4hip_probe_table (ctx, devs, n_objs, &t) : gt4hip_union_table (ctx, devs, n_objs, &t);
+  free (devs);
+  if (rc) {
+    fprintf (stderr, "%s: %s\n", probe ? "gt4_is_union" : "gt4_union", gt4hip_last_error (ctx));
+    return 1;
+  }
+  unsigned int result = walk_table (ctx, &t, objs, n_objs, !probe, callback, data);
+  gt4hip_table_free (&t);
+  return result;
+}
+
+unsigned int gt4_union (GT4HipWordList *objs[], unsigned int n_objs, unsigned int (*callback) (uint64_t, uint32_t *, void *), void *data)
+{
+  return table_walk (objs, n_objs, 0, callback, data);
+}
+
+unsigned int gt4_is_union (GT4HipWordList *objs[], unsigned int n_objs, unsigned int (*callback) (uint64_t, uint32_t *, void *), void *data)
+{
+  return table_walk (objs, n_objs, 1, callback, data);
+}

@@ -762,6 +762,36 @@ extern "C" int gt4hip_union_table (gt4hip_context *ctx, const gt4hip_list *const
   return GT4HIP_OK;
 }
 
+extern "C" int gt4hip_probe_table (gt4hip_context *ctx, const gt4hip_list *const lists[], uint32_t n_lists, gt4hip_count_table *table)
+{
+  if (!ctx || !lists || !n_lists || !table || !lists[0]) return GT4HIP_EINVAL;
+  memset (table, 0, sizeof *table);
+  table->n_lists = n_lists;
+  const gt4hip_list *base = lists[0];
+  const uint64_t n = base->n_words;
+  table->n_keys = n;
+  if (!n) return GT4HIP_OK;
+  HIPCHK (ctx, hipSetDevice (ctx->device));
+  hipError_t e = hipMalloc (&table->device_keys, (size_t) n * 8);
+  if (e == hipSuccess) e = hipMalloc (&table->device_counts, (size_t) n * n_lists * 4);
+  if (e != hipSuccess) {
+    gt4hip_table_free (table);
+    return fail (ctx, GT4HIP_ENOMEM, "count table allocation failed: %s", hipGetErrorString (e));
+  }
+  e = launch_extract_keys (ctx->stream, (const uint32_t *) base->dev, n, (unsigned long long *) table->device_keys);
+  for (uint32_t j = 0; j < n_lists && e == hipSuccess; j++) {
+    if (!lists[j]) e = hipErrorInvalidValue;
+    else e = launch_counts_table (ctx->stream, (const uint32_t *) base->dev, n, (const uint32_t *) lists[j]->dev, lists[j]->n_words,
+                                  (uint32_t *) table->device_counts, n_lists, j);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize (ctx->stream);
+  if (e != hipSuccess) {
+    gt4hip_table_free (table);
+    return fail (ctx, GT4HIP_EHIP, "count table kernels failed: %s", hipGetErrorString (e));
+  }
+  return GT4HIP_OK;
+}
+
 extern "C" int gt4hip_table_download (gt4hip_context *ctx, const gt4hip_count_table *t, uint64_t first, uint64_t count,
                                        uint64_t *host_keys, uint32_t *host_counts)
 {

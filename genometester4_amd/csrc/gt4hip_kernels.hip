@@ -372,16 +372,6 @@ __device__ __forceinline__ u64 uniform64 (u64 v)
   return (u64) __builtin_amdgcn_readfirstlane ((u32) v) | ((u64) __builtin_amdgcn_readfirstlane ((u32) (v >> 32)) << 32);
 }
 
-__device__ __forceinline__ TileRange load_tile_range (const u64 *__restrict__ part, u64 tile)
-{
-  TileRange t;
-  t.a0 = part[2 * tile];
-  t.b0 = part[2 * tile + 1];
-  t.na = (u32) (part[2 * tile + 2] - t.a0);
-  t.nb = (u32) (part[2 * tile + 3] - t.b0);
-  return t;
-}
-
 /* OPS != 0 fixes the set of output streams at compile time (the common single-output calls get a
  * kernel without the other streams' code and registers); OPS == 0 takes it from p.ops. */
 template <int NT, int IPT, int MODE, int OPS>

@@ -1,0 +1,60 @@
+/*
+ * gt4_set_operations.h -- the three entry points of the reference's set-operations.h with their
+ * exact signatures (reference src/set-operations.h:34, 38, 39), backed by the MI355X engine.
+ *
+ * The only change is the list handle: where the reference takes `AZObject *` objects implementing
+ * GT4WordSList, these take `GT4HipWordList *` (a sorted list resident in HBM).  glistmaker's
+ * collation step (src/glistmaker.c:333, :814) and glistquery's multi-list dump
+ * (src/glistquery.c:95-106) link against them unchanged otherwise; see INTEGRATION.md.
+ */
+#ifndef GT4_SET_OPERATIONS_H
+#define GT4_SET_OPERATIONS_H
+
+#include <stdint.h>
+
+#include "gt4_listfile.h"
+#include "gt4hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GT4_MAX_SETS 4096 /* src/set-operations.h:29 */
+
+typedef struct _GT4HipWordList GT4HipWordList;
+
+/* The device context every GT4HipWordList of this process lives in (created on first use on
+ * device $GT4HIP_DEVICE, default 0).  NULL (and a message on stderr) when there is no GPU. */
+gt4hip_context *gt4_hip_default_context (void);
+
+/* gt4_word_map_new (src/word-map.c:165-241) for the GPU path: map, validate, upload.  NULL on
+ * failure (diagnostic on stderr). */
+GT4HipWordList *gt4_hip_word_list_new (const char *listfilename, unsigned int major_version);
+/* Wraps packed records already in host memory (copied to HBM). */
+GT4HipWordList *gt4_hip_word_list_new_from_records (const void *records, uint64_t n_words, unsigned int word_length);
+void gt4_hip_word_list_delete (GT4HipWordList *list);
+/* GT4WordSListInstance fields, src/word-list-sorted.h:45-57 */
+uint64_t gt4_hip_word_list_num_words (const GT4HipWordList *list);
+uint64_t gt4_hip_word_list_sum_counts (const GT4HipWordList *list);
+unsigned int gt4_hip_word_list_word_length (const GT4HipWordList *list);
+const gt4hip_list *gt4_hip_word_list_device (const GT4HipWordList *list);
+
+/* Combines N lists into one union (counts added, u32 wrap), keeps keys whose sum >= cutoff,
+ * writes header + records to `ofile` when it is non-zero, always fills *header.
+ * Returns 0 on success (reference src/set-operations.c:40-129). */
+unsigned int gt4_write_union (GT4HipWordList *arrays[], unsigned int n_arrays, unsigned int cutoff, int ofile, GT4ListHeader *header);
+
+/* Executes callback for each distinct key ascending with counts[j] = count in list j or 0.
+ * A non-zero callback result stops the walk and is returned (src/set-operations.c:131-183).
+ * Reproduces the reference's observable quirk: after the last key of a list, while other lists
+ * remain, the callback is invoked once more for that key with all-zero counts. */
+unsigned int gt4_union (GT4HipWordList *objs[], unsigned int n_objs, unsigned int (*callback) (uint64_t, uint32_t *, void *), void *data);
+
+/* Walks the keys of list 0 only and reports the other lists' counts for them
+ * (src/set-operations.c:185-228). */
+unsigned int gt4_is_union (GT4HipWordList *objs[], unsigned int n_objs, unsigned int (*callback) (uint64_t, uint32_t *, void *), void *data);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

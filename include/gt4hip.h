@@ -177,6 +177,10 @@ typedef struct {
 } gt4hip_count_table;
 int gt4hip_union_table (gt4hip_context *ctx, const gt4hip_list *const lists[], uint32_t n_lists,
                         gt4hip_count_table *table);
+/* The same table restricted to the keys of lists[0] (what gt4_is_union walks,
+ * src/set-operations.c:207-226): n_keys = n_words of lists[0], column 0 = its own counts. */
+int gt4hip_probe_table (gt4hip_context *ctx, const gt4hip_list *const lists[], uint32_t n_lists,
+                        gt4hip_count_table *table);
 /* Copies rows [first, first+count) of the table to host memory. */
 int gt4hip_table_download (gt4hip_context *ctx, const gt4hip_count_table *table, uint64_t first,
                            uint64_t count, uint64_t *host_keys, uint32_t *host_counts);

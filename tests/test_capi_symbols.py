@@ -22,6 +22,12 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), "%s declared in include/gt4hip.h but not exported" % name
     assert sorted(capi.SYMBOLS) == declared
+    # the host-side C layer: list files and the set-operations.h entry points
+    for header in ("gt4_listfile.h", "gt4_set_operations.h"):
+        names = _declared(header)
+        assert names, header
+        for name in names:
+            assert hasattr(L, name), "%s declared in include/%s but not exported" % (name, header)
 
 
 def test_error_strings_and_no_device_behaviour():

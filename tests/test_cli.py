@@ -1,0 +1,100 @@
+"""The drop-in `glistcompare` CLI (genometester4_amd/glistcompare) against the reference's
+transcripts and output files in tests/golden.
+
+CPU part: everything the CLI decides before it touches the GPU (argv grammar, validation order,
+messages, exit codes, -v/-h) and that it fails loudly without a device.  GPU part: every golden
+invocation replayed through the real binary -- exit code, stdout, stderr and every output file
+byte-identical to what the reference wrote."""
+import os
+import subprocess
+import tempfile
+
+import pytest
+
+import golden_util as G
+from genometester4_amd.listio import write_list, write_list_v40
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "genometester4_amd", "glistcompare")
+SETOPS = os.path.join(ROOT, "genometester4_amd", "setops_driver")
+CASES, INPUTS, OUTPUTS = G.load()
+GL_CASES = [c for c in CASES if c["tool"] == "glistcompare"]
+SETOPS_CASES = [c for c in CASES if c["tool"] == "ref_setops"]
+# decided before any device work
+NO_GPU_IDS = {"version", "help", "err_wordlength", "err_one_file", "err_unknown_flag", "multi_diff_rejected",
+              "pair_only_u_r_min", "pair_only_u_r_subtract"}
+NO_GPU_IDS |= {c["id"] for c in GL_CASES if c["id"].startswith("multi_r") and c["exit"] == 1 and "Invalid rule" not in c["stderr"]}
+
+
+@pytest.fixture(scope="module")
+def workdir():
+    d = tempfile.mkdtemp(prefix="gt4cli_")
+    for name, (rec, k, flavour) in INPUTS.items():
+        (write_list_v40 if flavour == "v40" else write_list)(os.path.join(d, name + ".list"), rec, k)
+    yield d
+    import shutil
+    shutil.rmtree(d, ignore_errors=True)
+
+
+def _run(binary, argv, cwd):
+    before = set(os.listdir(cwd))
+    p = subprocess.run([binary] + argv, cwd=cwd, capture_output=True, timeout=300)
+    created = sorted(set(os.listdir(cwd)) - before)
+    data = {}
+    for f in created:
+        with open(os.path.join(cwd, f), "rb") as fh:
+            data[f] = fh.read()
+        os.remove(os.path.join(cwd, f))
+    return p.returncode, p.stdout.decode("latin-1"), p.stderr.decode("latin-1"), data
+
+
+def _check(case, binary, workdir):
+    rc, out, err, files = _run(binary, case["argv"], workdir)
+    assert rc == case["exit"], (rc, err)
+    assert out == case["stdout"]
+    assert err == case["stderr"]
+    assert sorted(files) == sorted(case["files"])
+    for name, data in files.items():
+        assert data == bytes(OUTPUTS["%s/%s" % (case["id"], name)]), "%s differs from the reference output" % name
+
+
+def test_cli_binary_exists():
+    assert os.access(CLI, os.X_OK), "build it: make -C genometester4_amd/csrc"
+
+
+@pytest.mark.parametrize("case", [c for c in GL_CASES if c["id"] in NO_GPU_IDS], ids=lambda c: c["id"])
+def test_cli_host_logic_matches_reference(case, workdir):
+    _check(case, CLI, workdir)
+
+
+def test_cli_fails_loudly_without_gpu(workdir):
+    from genometester4_amd import capi
+    if capi.lib().gt4hip_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    rc, out, err, files = _run(CLI, ["A8.list", "B8.list", "-u"], workdir)
+    assert rc == 1 and not files and "no HIP device" in err
+
+
+def test_cli_missing_file_is_an_error_not_a_crash(workdir):
+    rc, out, err, files = _run(CLI, ["A8.list", "nope.list", "-u"], workdir)
+    assert rc == 1 and "Error: Cannot open nope.list" in err and "Stopping..." in err
+
+
+def test_cli_count_cutoff_alias_parses(workdir):
+    # BASELINE.json writes --count_cutoff; the reference flag is -c/--cutoff.  Both must parse.
+    rc, out, err, _ = _run(CLI, ["A8.list", "--count_cutoff", "x3"], workdir)
+    assert rc == 1 and "Invalid frequency cut-off: x3" in err
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [c for c in GL_CASES if c["id"] not in NO_GPU_IDS], ids=lambda c: c["id"])
+def test_cli_reproduces_reference_run(case, workdir):
+    _check(case, CLI, workdir)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", SETOPS_CASES, ids=lambda c: c["id"])
+def test_set_operations_entry_points_match_reference(case, workdir):
+    """gt4_write_union / gt4_union / gt4_is_union (include/gt4_set_operations.h) through
+    examples/setops_driver.c vs the reference's set-operations.c through oracle/ref_setops_driver.c."""
+    _check(case, SETOPS, workdir)
