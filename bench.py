@@ -97,6 +97,72 @@ def cpu_baseline(ctx, a, b, k, sample_records):
                 sample=sample + "; oracle/gt4_oracle.c scalar restatement, median of 3 runs")
 
 
+def bench_union8(args, ctx, capi, rank, local_rank, world):
+    """BASELINE configs[3]: 8-way union (MakeUnion.pl replacement) of eight lists, key-range sharded
+    over the ranks; per step every rank unions its eight slices (pairwise tree in HBM), the header
+    totals are all-gathered and the payload is gathered on rank 0 over RCCL (grouped send/recv)."""
+    import torch
+    import torch.distributed as dist
+    from genometester4_amd import distributed as D
+    n_list = args.n8 // world  # this rank's slice of each of the eight lists
+    lists = []
+    for j in range(8):
+        lst = ctx.alloc(n_list, args.k)
+        # disjoint residue classes mod 16 for half of the lists' keys, shared class 0 for the rest:
+        # every key of class 0 is present in all lists that draw it (same key seed)
+        shared = j % 2 == 0
+        ctx.generate_ex(lst, n_list, (7 if shared else 100 + j) + 1000 * rank, 50 + j, 8, 16, 0 if shared else 1 + j)
+        lists.append(lst)
+    cap = 8 * n_list
+    buf = torch.empty(3 * cap + 4, dtype=torch.int32, device="cuda")
+    out = ctx.wrap(buf.data_ptr(), cap, args.k)
+
+    def step():
+        rc, n, total, _ = ctx.union_multi(lists, out=out)
+        assert rc == 0
+        totals = D.exchange_totals(n, total, device="cuda") if world > 1 else [(n, total)]
+        g = D.gatherv_records(buf[: 3 * n], [t[0] for t in totals], root=0) if world > 1 else buf[: 3 * n]
+        return totals, g
+
+    def fence():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        totals, g = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        n_in = 8 * n_list * world
+        n_out = sum(t[0] for t in totals)
+        print(json.dumps({
+            "metric": "k-mers merged/sec, 8-way k=%d union (MakeUnion.pl replacement), lists resident in HBM, result gathered on rank 0" % args.k,
+            "value": n_in * args.steps / elapsed, "unit": "k-mers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u64 keys + u32 counts", "data": "synthetic",
+            "config": {"workload": "8-way union, eight %d-entry k=%d lists, key-range sharded over %d GPU(s), RCCL gatherv" % (n_list * world, args.k, world),
+                       "entries_per_list": n_list * world, "output_records": n_out, "device": ctx.device_info()},
+            "roofline": {"bound": "hbm", "kernel": "k_pair_merge (3-level pairwise tree)", "achieved": None, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": None, "traffic": None,
+                         "note": "tree moves 12*(sum n_i)*~3 + 12*sum(level outputs) bytes; see DESIGN.md"},
+        }), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -106,7 +172,11 @@ def main():
     ap.add_argument("--k", type=int, default=25)
     ap.add_argument("--cpu-sample", type=int, default=200_000_000, help="records per list timed on the CPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--two-pass", action="store_true", help="count+scan+write instead of single-pass look-back")
+    ap.add_argument("--two-pass", action="store_true", help="count+scan+write instead of the single-pass kernel")
+    ap.add_argument("--workload", choices=["intersect", "union8"], default="intersect",
+                    help="intersect: BASELINE configs[1] (default, the headline metric); union8: configs[3], 8-way union "
+                         "sharded by key range over the ranks with an RCCL gatherv to rank 0 (strong scaling)")
+    ap.add_argument("--n8", type=int, default=500_000_000, help="union8: entries per list (whole job)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -122,6 +192,8 @@ def main():
     ctx = capi.Context(local_rank)
     if args.two_pass:
         ctx.set_option("two_pass", 1)
+    if args.workload == "union8":
+        return bench_union8(args, ctx, capi, rank, local_rank, world)
     n = args.n
     while True:
         try:

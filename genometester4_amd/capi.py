@@ -247,21 +247,29 @@ class Context:
         timing = dict(merge_kernel_ms=res.merge_kernel_ms, device_ms=res.device_ms, merge_tiles=res.merge_tiles)
         return stats, lists, timing
 
-    def _multi(self, fn, lists, cutoff, rule, count_override, count_only):
+    def _multi(self, fn, lists, cutoff, rule, count_override, count_only, out=None):
         arr = (C.c_void_p * len(lists))(*[l.h for l in lists])
         res = MultiResult()
+        if out is not None:
+            res.out = out.h.value
         rc = fn(self.h, arr, len(lists), cutoff, rule, count_override, 1 if count_only else 0, C.byref(res))
         if rc == ERULE:
             return rc, None, None, None
         self._chk(rc)
-        out = None if count_only else DeviceList(self, C.c_void_p(res.out))
-        return 0, res.n_words, res.total_count, out
+        if count_only:
+            result = None
+        elif out is not None:
+            result = out
+        else:
+            result = DeviceList(self, C.c_void_p(res.out))
+        self.last_multi_device_ms = res.device_ms
+        return 0, res.n_words, res.total_count, result
 
-    def union_multi(self, lists, cutoff=1, rule=0, count_override=1, count_only=False):
-        return self._multi(lib().gt4hip_union_multi, lists, cutoff, rule, count_override, count_only)
+    def union_multi(self, lists, cutoff=1, rule=0, count_override=1, count_only=False, out=None):
+        return self._multi(lib().gt4hip_union_multi, lists, cutoff, rule, count_override, count_only, out)
 
-    def intersect_multi(self, lists, cutoff=1, rule=0, count_override=1, count_only=False):
-        return self._multi(lib().gt4hip_intersect_multi, lists, cutoff, rule, count_override, count_only)
+    def intersect_multi(self, lists, cutoff=1, rule=0, count_override=1, count_only=False, out=None):
+        return self._multi(lib().gt4hip_intersect_multi, lists, cutoff, rule, count_override, count_only, out)
 
     def union_table(self, lists, probe=False):
         arr = (C.c_void_p * len(lists))(*[l.h for l in lists])

@@ -1,0 +1,149 @@
+"""Key-range sharding of the set operations across the GPUs of one node.
+
+Every set operation is key-local, so the key space is cut into `world` contiguous prefix ranges;
+rank g merges only the slices of the input lists that fall into range g, and concatenating the
+per-rank outputs in rank order is the globally sorted result.  The only exchanges are
+
+  1. an all-gather of each rank's (n_words, total_count)  -> header totals and file offsets
+  2. a gatherv of the record payloads to the writer rank  -> RCCL has no native gatherv, so it is
+     a grouped send/recv (`batch_isend_irecv` = ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd);
+     on the fully connected xGMI node every non-root rank sends over its own link to the root.
+
+One process per GPU, `torch.distributed` with the "nccl" backend (= RCCL on ROCm).  The same code
+runs under "gloo" on CPU tensors, which is how the CPU test-suite covers it (world_size 2, with
+the CPU oracle standing in for the per-shard merge).  Plumbing only: the per-shard merge itself is
+the C ABI call (`capi.Context.union_multi` / `compare`).
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .listio import RECORD_DTYPE
+
+
+def key_range_bounds(word_length: int, world: int) -> List[int]:
+    """world+1 ascending key bounds; shard g owns keys in [bounds[g], bounds[g+1]).
+
+    Equal-width prefix ranges of the 4^k key space (2^64 for k = 32); the last bound is 2^64 so
+    that the all-ones key belongs to the last shard."""
+    space = 1 << 64 if word_length >= 32 else 1 << (2 * word_length)
+    b = [(space * g) // world for g in range(world)]
+    b.append(1 << 64)
+    return b
+
+
+def slice_indices(keys: np.ndarray, bounds: Sequence[int]) -> List[Tuple[int, int]]:
+    """[first, last) record index of every shard in an ascending key array (two binary searches
+    per shard boundary; slices are contiguous in the file)."""
+    keys = np.asarray(keys, dtype=np.uint64)
+    cuts = [0]
+    for b in bounds[1:-1]:
+        cuts.append(int(np.searchsorted(keys, np.uint64(b), side="left")))
+    cuts.append(len(keys))
+    return [(cuts[g], cuts[g + 1]) for g in range(len(bounds) - 1)]
+
+
+def exchange_totals(n_words: int, total_count: int, device=None, group=None) -> List[Tuple[int, int]]:
+    """All-gather of the per-shard header totals.  Returns [(n_words, total_count)] by rank."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    # total_count is a u64 header field; carry it as two non-negative int64 halves
+    mine = torch.tensor([n_words, total_count & 0xFFFFFFFF, total_count >> 32], dtype=torch.int64, device=device)
+    out = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(out, mine, group=group)
+    return [(int(t[0]), int(t[1]) | (int(t[2]) << 32)) for t in out]
+
+
+def gatherv_records(local, counts: Sequence[int], root: int = 0, group=None):
+    """Gathers per-rank record payloads of different lengths on `root`.
+
+    `local`: 1-D int32 tensor holding this rank's packed records (3 words per record) on the
+    device the backend communicates from.  `counts[r]`: records of rank r (from exchange_totals).
+    Returns the concatenated int32 tensor on root (rank order = key order), None elsewhere."""
+    import torch
+    import torch.distributed as dist
+    rank = dist.get_rank(group)
+    world = dist.get_world_size(group)
+    assert local.dtype == torch.int32 and local.numel() == 3 * counts[rank]
+    if rank != root:
+        if counts[rank]:
+            for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, local, root, group=group)]):
+                w.wait()
+        return None
+    total = sum(counts)
+    out = torch.empty(3 * total, dtype=torch.int32, device=local.device)
+    offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    ops = []
+    for r in range(world):
+        if not counts[r]:
+            continue
+        dst = out[3 * offs[r]: 3 * offs[r + 1]]
+        if r == root:
+            dst.copy_(local)
+        else:
+            ops.append(dist.P2POp(dist.irecv, dst, r, group=group))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    return out
+
+
+def records_to_tensor(records: np.ndarray, device=None):
+    """Packed records -> int32 tensor view (3 words per record)."""
+    import torch
+    a = np.ascontiguousarray(records, dtype=RECORD_DTYPE).view(np.int32)
+    t = torch.from_numpy(a.copy())
+    return t.to(device) if device is not None else t
+
+
+def tensor_to_records(t) -> np.ndarray:
+    return t.detach().cpu().numpy().view(RECORD_DTYPE)
+
+
+def sharded_nway(lists_host: Sequence[np.ndarray], word_length: int,
+                 local_op: Callable[[List[np.ndarray]], Tuple[int, int, np.ndarray]],
+                 root: int = 0, device=None, group=None) -> Optional[Tuple[int, int, np.ndarray]]:
+    """Generic sharded N-way operation over host-resident sorted lists.
+
+    Every rank holds (or can map) all input lists, takes its key-range slice of each, runs
+    `local_op(slices) -> (n_words, total_count, records)` on them, and the results are gathered
+    on `root`.  Returns (n_words, total_count, records) on root, None elsewhere.  `local_op` is
+    the GPU merge in production and the CPU oracle in the CPU tests."""
+    import torch.distributed as dist
+    rank = dist.get_rank(group)
+    world = dist.get_world_size(group)
+    bounds = key_range_bounds(word_length, world)
+    mine = []
+    for rec in lists_host:
+        lo, hi = slice_indices(rec["key"], bounds)[rank]
+        mine.append(rec[lo:hi])
+    n, total, out = local_op(mine)
+    totals = exchange_totals(n, total, device=device, group=group)
+    gathered = gatherv_records(records_to_tensor(out, device), [t[0] for t in totals], root=root, group=group)
+    if rank != root:
+        return None
+    return sum(t[0] for t in totals), sum(t[1] for t in totals) & 0xFFFFFFFFFFFFFFFF, tensor_to_records(gathered)
+
+
+def gpu_union_multi_op(ctx, word_length: int, cutoff: int = 1, rule: int = 0, count_override: int = 1):
+    """local_op for sharded_nway: N-way union of the slices on this rank's GPU (C ABI)."""
+    def op(slices):
+        dev = [ctx.upload(s, word_length) for s in slices]
+        rc, n, total, out = ctx.union_multi(dev, cutoff, rule, count_override)
+        if rc:
+            raise RuntimeError("union_multi rejected rule %d" % rule)
+        return n, total, out.download()
+    return op
+
+
+def gpu_intersect_multi_op(ctx, word_length: int, cutoff: int = 1, rule: int = 0, count_override: int = 1):
+    def op(slices):
+        dev = [ctx.upload(s, word_length) for s in slices]
+        rc, n, total, out = ctx.intersect_multi(dev, cutoff, rule, count_override)
+        if rc:
+            raise RuntimeError("intersect_multi rejected rule %d" % rule)
+        return n, total, out.download()
+    return op
