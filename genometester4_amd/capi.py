@@ -116,6 +116,7 @@ class DeviceList:
     def __init__(self, ctx, handle):
         self.ctx = ctx
         self.h = handle
+        ctx._lists.add(self)
 
     @property
     def n_words(self):
@@ -167,9 +168,10 @@ class DeviceList:
         return v
 
     def free(self):
-        if self.h:
+        # lists return their storage to the context's pool, so they must not outlive it
+        if self.h and self.ctx.h:
             lib().gt4hip_list_free(self.h)
-            self.h = None
+        self.h = None
 
     def __del__(self):
         try:
@@ -180,6 +182,8 @@ class DeviceList:
 
 class Context:
     def __init__(self, device=0):
+        import weakref
+        self._lists = weakref.WeakSet()
         self.h = C.c_void_p()
         rc = lib().gt4hip_create(device, C.byref(self.h))
         if rc:
@@ -191,6 +195,8 @@ class Context:
 
     def close(self):
         if self.h:
+            for l in list(self._lists):
+                l.free()
             lib().gt4hip_destroy(self.h)
             self.h = None
 

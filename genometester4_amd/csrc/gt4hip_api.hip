@@ -13,6 +13,7 @@
 #include <string.h>
 
 #include <new>
+#include <utility>
 #include <vector>
 
 using namespace gt4;
@@ -25,6 +26,10 @@ struct gt4hip_context {
   int two_pass;
   int64_t grid_override;
   uint64_t single_pass_fallbacks; /* calls that had to be rerun on the two-pass path */
+  /* freed list storage kept for reuse: hipMalloc / hipFree of tens of GB cost far more than the
+   * merges themselves (an 8-way union tree allocates seven outputs per call) */
+  std::vector<std::pair<void *, size_t>> *pool;
+  int pool_enabled;
   /* workspace, grown on demand */
   uint64_t *part;
   size_t part_bytes;
@@ -43,6 +48,7 @@ struct gt4hip_context {
 struct gt4hip_list {
   gt4hip_context *ctx;
   void *dev;
+  size_t bytes; /* size of the allocation behind dev when owned */
   uint64_t n_words;
   uint64_t capacity;
   uint32_t word_length;
@@ -110,6 +116,8 @@ extern "C" int gt4hip_create (int device, gt4hip_context **out)
   if (!ctx) return fail (NULL, GT4HIP_ENOMEM, "gt4hip_create: host allocation failed");
   memset (ctx, 0, sizeof *ctx);
   ctx->device = device;
+  ctx->pool = new (std::nothrow) std::vector<std::pair<void *, size_t>> ();
+  ctx->pool_enabled = ctx->pool != NULL;
   hipDeviceProp_t prop;
   if ((e = hipGetDeviceProperties (&prop, device)) != hipSuccess) {
     delete ctx;
@@ -138,6 +146,10 @@ extern "C" void gt4hip_destroy (gt4hip_context *ctx)
   if (!ctx) return;
   hipSetDevice (ctx->device);
   if (ctx->stream) hipStreamSynchronize (ctx->stream);
+  if (ctx->pool) {
+    for (auto &b : *ctx->pool) hipFree (b.first);
+    delete ctx->pool;
+  }
   if (ctx->part) hipFree (ctx->part);
   if (ctx->desc) hipFree (ctx->desc);
   if (ctx->block_sums) hipFree (ctx->block_sums);
@@ -159,6 +171,13 @@ extern "C" int gt4hip_set_option (gt4hip_context *ctx, const char *name, int64_t
 {
   if (!ctx || !name) return GT4HIP_EINVAL;
   if (!strcmp (name, "two_pass")) ctx->two_pass = value != 0;
+  else if (!strcmp (name, "pool")) {
+    ctx->pool_enabled = value != 0 && ctx->pool;
+    if (!ctx->pool_enabled && ctx->pool) {
+      for (auto &b : *ctx->pool) hipFree (b.first);
+      ctx->pool->clear ();
+    }
+  }
   else if (!strcmp (name, "grid")) ctx->grid_override = value;
   else return fail (ctx, GT4HIP_EINVAL, "unknown option %s", name);
   return GT4HIP_OK;
@@ -184,11 +203,38 @@ static int list_new (gt4hip_context *ctx, uint64_t capacity, uint32_t word_lengt
   l->word_length = word_length;
   l->owns = 1;
   /* 16 bytes of slack so that 16-byte vector loads that straddle the end stay inside the allocation */
-  size_t bytes = (size_t) capacity * GT4HIP_RECORD_BYTES + 16;
-  hipError_t e = hipMalloc (&l->dev, bytes);
-  if (e != hipSuccess) {
-    delete l;
-    return fail (ctx, GT4HIP_ENOMEM, "hipMalloc of %zu bytes failed: %s", bytes, hipGetErrorString (e));
+  const size_t bytes = (((size_t) capacity * GT4HIP_RECORD_BYTES + 16) + 255) & ~(size_t) 255;
+  /* reuse a pooled block that fits without wasting more than half of it */
+  if (ctx->pool_enabled) {
+    size_t best = (size_t) -1, best_i = 0;
+    for (size_t i = 0; i < ctx->pool->size (); i++) {
+      const size_t b = (*ctx->pool)[i].second;
+      if (b >= bytes && b / 2 <= bytes && b < best) {
+        best = b;
+        best_i = i;
+      }
+    }
+    if (best != (size_t) -1) {
+      l->dev = (*ctx->pool)[best_i].first;
+      l->bytes = best;
+      ctx->pool->erase (ctx->pool->begin () + (long) best_i);
+    }
+  }
+  if (!l->dev) {
+    hipError_t e = hipMalloc (&l->dev, bytes);
+    if (e != hipSuccess && ctx->pool && !ctx->pool->empty ()) {
+      /* give the pooled blocks back and try again */
+      (void) hipGetLastError ();
+      for (auto &b : *ctx->pool) hipFree (b.first);
+      ctx->pool->clear ();
+      e = hipMalloc (&l->dev, bytes);
+    }
+    if (e != hipSuccess) {
+      (void) hipGetLastError ();
+      delete l;
+      return fail (ctx, GT4HIP_ENOMEM, "hipMalloc of %zu bytes failed: %s", bytes, hipGetErrorString (e));
+    }
+    l->bytes = bytes;
   }
   *out = l;
   return GT4HIP_OK;
@@ -264,8 +310,12 @@ extern "C" void gt4hip_list_free (gt4hip_list *l)
 {
   if (!l) return;
   if (l->owns && l->dev) {
-    hipSetDevice (l->ctx->device);
-    hipFree (l->dev);
+    if (l->ctx->pool_enabled) {
+      l->ctx->pool->push_back (std::make_pair (l->dev, l->bytes));
+    } else {
+      hipSetDevice (l->ctx->device);
+      hipFree (l->dev);
+    }
   }
   delete l;
 }
