@@ -510,6 +510,8 @@ static int run_pair (gt4hip_context *ctx, const uint32_t *A, uint64_t nA, const 
     fprintf (stderr, "[phases] tiles %llu merge %.3f ms:", (unsigned long long) tiles, run->merge_ms);
     for (int i = 0; i < 8; i++) fprintf (stderr, " %s %.1f%%", names[i], tot ? 100.0 * ctx->ctl_host->phase_cycles[i] / tot : 0.0);
     fprintf (stderr, " | avg cycles/tile %.0f\n", tiles ? (double) tot / tiles : 0.0);
+    const unsigned long long *rs = ctx->ctl_host->resolve_stats;
+    if (rs[0]) fprintf (stderr, "[resolve] sampled %llu avg spins %.2f first-look agg-not-ready %.1f%% carry-not-ready %.1f%% | [scanner] rows %llu polling rounds %llu rows complete at batch load %llu\n", rs[0], (double) rs[1] / rs[0], 100.0 * rs[3] / rs[0], 100.0 * rs[4] / rs[0], rs[7], rs[5], rs[6]);
   }
 #endif
   if (ctx->ctl_host->error) {

@@ -172,6 +172,27 @@ __device__ __forceinline__ u64 wave_sum (u64 v)
   return v;
 }
 
+/* Inclusive prefix sum over the 64 lanes with DPP (no LDS crossbar, no dependent ds_bpermute
+ * chain: ~12 VALU instructions instead of ~1000 cycles of shuffles).  gfx9 data-parallel
+ * primitives: row_shr:n inside each row of 16 lanes, then row_bcast:15 / row_bcast:31 carry the
+ * row totals into the following rows; lanes without a source contribute 0.  Lane 63 ends up
+ * with the wave total. */
+__device__ __forceinline__ u32 dpp_inclusive_scan_u32 (u32 v)
+{
+  v += (u32) __builtin_amdgcn_update_dpp (0, (int) v, 0x111, 0xf, 0xf, false); /* row_shr:1 */
+  v += (u32) __builtin_amdgcn_update_dpp (0, (int) v, 0x112, 0xf, 0xf, false); /* row_shr:2 */
+  v += (u32) __builtin_amdgcn_update_dpp (0, (int) v, 0x114, 0xf, 0xf, false); /* row_shr:4 */
+  v += (u32) __builtin_amdgcn_update_dpp (0, (int) v, 0x118, 0xf, 0xf, false); /* row_shr:8 */
+  v += (u32) __builtin_amdgcn_update_dpp (0, (int) v, 0x142, 0xa, 0xf, false); /* row_bcast:15 -> rows 1, 3 */
+  v += (u32) __builtin_amdgcn_update_dpp (0, (int) v, 0x143, 0xc, 0xf, false); /* row_bcast:31 -> rows 2, 3 */
+  return v;
+}
+
+__device__ __forceinline__ u32 dpp_wave_sum_u32 (u32 v)
+{
+  return (u32) __builtin_amdgcn_readlane ((int) dpp_inclusive_scan_u32 (v), WAVE - 1);
+}
+
 /* ------------------------------------------------------------------ tile descriptors (chained scan) */
 
 /* Two-level chained scan of the tiles' output counts.  Per output stream s, zeroed before every
@@ -206,13 +227,6 @@ __device__ __forceinline__ u64 peek_u64 (u64 *p) { return __hip_atomic_load (p, 
 constexpr u32 SPIN_LIMIT = 1u << 22; /* bounded: ~seconds; sets ctl->error instead of hanging */
 constexpr int SCAN_ROWS = 16;        /* rows of 64 tiles a scanner wavefront keeps in flight */
 
-__device__ __forceinline__ u32 wave_sum_u32 (u32 v)
-{
-#pragma unroll
-  for (int m = WAVE / 2; m > 0; m >>= 1) v += __shfl_xor (v, m, WAVE);
-  return v;
-}
-
 /* The scanner: one wavefront per stream.  Loads SCAN_ROWS x 64 tile counts at once (so that its
  * rate is set by L2 bandwidth, not by one round trip per row), waits for each row to be complete,
  * publishes the carry into the next row. */
@@ -231,16 +245,31 @@ __device__ void scanner_wave (u32 *agg, u64 *carry_out, u64 num_tiles, PairContr
     }
     int done = 0;
     u32 spins = 0;
+#ifdef GT4_PROFILE_PHASES
+    u64 st_rounds = 0, st_first = 0;
+#endif
     for (;;) {
+#ifdef GT4_PROFILE_PHASES
+      const int done_before = done;
+#endif
       /* retire, in order, every row that is complete */
 #pragma unroll
       for (int j = 0; j < SCAN_ROWS; j++) {
         if (j == done && j < n && __all ((v[j] & AGG_READY) != 0)) {
-          carry += wave_sum_u32 (v[j] & ~AGG_READY);
+          carry += dpp_wave_sum_u32 (v[j] & ~AGG_READY);
           if (lane == 0) publish_u64 (&carry_out[r0 + j + 1], CARRY_READY | carry);
           done++;
         }
       }
+#ifdef GT4_PROFILE_PHASES
+      st_rounds++;
+      if (spins == 0) st_first += (u64) (done - done_before);
+      if (done >= n && lane == 0) {
+        atomicAdd (&ctl->resolve_stats[5], st_rounds);
+        atomicAdd (&ctl->resolve_stats[6], st_first);
+        atomicAdd (&ctl->resolve_stats[7], (u64) n);
+      }
+#endif
       if (done >= n) break;
       if (++spins > SPIN_LIMIT) {
         if (lane == 0) atomicOr (&ctl->error, 4u);
@@ -267,6 +296,9 @@ __device__ __forceinline__ u64 resolve_offset (u32 *agg, u64 *carry, u64 tile, i
   u64 *const wc = &carry[row];
   const bool mine = (u32) lane < pos;
   u32 spins = 0;
+#ifdef GT4_PROFILE_PHASES
+  const bool agg_ok0 = __all (!mine || (a & AGG_READY) != 0), carry_ok0 = (c & CARRY_READY) != 0;
+#endif
   while (!__all (!mine || (a & AGG_READY) != 0) || !(c & CARRY_READY)) {
     if (++spins > SPIN_LIMIT) {
       if (lane == 0) atomicOr (&ctl->error, 1u);
@@ -276,7 +308,15 @@ __device__ __forceinline__ u64 resolve_offset (u32 *agg, u64 *carry, u64 tile, i
     if (mine && !(a & AGG_READY)) a = peek_u32 (wa);
     if (!(c & CARRY_READY)) c = peek_u64 (wc);
   }
-  return (c & ~CARRY_READY) + wave_sum_u32 (mine ? (a & ~AGG_READY) : 0u);
+#ifdef GT4_PROFILE_PHASES
+  if (lane == 0 && (tile & 63) == 17) { /* sample 1 in 64 so that the statistics do not perturb the run */
+    atomicAdd (&ctl->resolve_stats[0], 1ull);
+    atomicAdd (&ctl->resolve_stats[1], (u64) spins);
+    atomicAdd (&ctl->resolve_stats[3], agg_ok0 ? 0ull : 1ull);
+    atomicAdd (&ctl->resolve_stats[4], carry_ok0 ? 0ull : 1ull);
+  }
+#endif
+  return (c & ~CARRY_READY) + dpp_wave_sum_u32 (mine ? (a & ~AGG_READY) : 0u);
 }
 
 /* ------------------------------------------------------------------ K2: tile merge by rank search */
@@ -314,8 +354,10 @@ struct RankShared {
   static constexpr int CAP = NT * IPT;
   static constexpr int NCH = CAP / WAVE;
   /* deferred staging: an intersection keeps at most one record per pair, a union at most CAP */
-  static constexpr int STAGE_DW = OPS == 2 ? 3 * (CAP / 2 + 1) : (OPS == 1 ? 3 * CAP : 4);
-  static constexpr int STAGE_SLOTS = 2; /* write-out lags two tiles behind ranking */
+  static constexpr int STAGE_DW = OPS == 2 ? ((3 * (CAP / 2 + 1) + 3) & ~3) : (OPS == 1 ? 3 * CAP : 4); /* 16-byte multiples */
+  /* write-out lags this many tiles behind ranking; an intersection's staging slots are half the
+   * size of a union's, so it can afford three within the LDS of two workgroups per CU */
+  static constexpr int STAGE_SLOTS = OPS == 2 ? 4 : 2;
   u64 keys[CAP];          /* input view; OPS == 0: the output view (3 * CAP dwords) starts here too */
   u32 cnts[CAP];
   u32 stage[STAGE_SLOTS][STAGE_DW];
@@ -359,6 +401,20 @@ __device__ __forceinline__ void scatter_stream (RankShared<NT, IPT, OPS> &sh, u3
   }
 }
 
+/* Tile write-out: `tot` packed records from an LDS staging slot (16-byte aligned) to the output
+ * list at record offset `excl`, as 16-byte buffer stores (dword alignment suffices; the
+ * range-checked descriptor drops the dwords past the last record of the partial last chunk). */
+template <int NT>
+__device__ __forceinline__ void write_out_tile (u32 *out_rec, u64 excl, u32 tot, const u32 *slot, int tid)
+{
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc ((void *) (out_rec + 3 * excl), 0, (int) (12 * tot), 0x00020000);
+  const u32 chunks = (3 * tot + 3) >> 2;
+  for (u32 c = (u32) tid; c < chunks; c += NT) {
+    const u32x4 w = *reinterpret_cast<const u32x4 *> (slot + 4 * c);
+    __builtin_amdgcn_raw_buffer_store_b128 (w, r, 16 * c, 0, 0);
+  }
+}
+
 struct TileRange {
   u64 a0, b0;
   u32 na, nb;
@@ -390,7 +446,8 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
   __shared__ RankShared<NT, IPT, OPS> sh;
   u32 *const lds32 = reinterpret_cast<u32 *> (&sh.keys[0]);
 
-  const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+  const int wid = __builtin_amdgcn_readfirstlane (tid / WAVE); /* wave-uniform: scalar branches on it */
   const u32 ops = OPS ? (u32) OPS : p.ops;
   /* every "both" pair is evaluated at its A record, so A records always matter; B records only
    * where a B-only key can be kept (union, diff2) */
@@ -466,20 +523,16 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
     for (int j = 0; j < NLOAD4; j++) {
       const u32 q0 = (u32) j * NT + (u32) wid * WAVE; /* first chunk of this wavefront */
       const u32 q = q0 + (u32) lane;
-      u32x4 w;
-      if (q0 + WAVE <= cA) {
-        w = __builtin_amdgcn_raw_buffer_load_b128 (ra, 16 * q, 0, 0);
-      } else if (q0 >= cA) {
-        w = __builtin_amdgcn_raw_buffer_load_b128 (rb, 16 * (q - cA), 0, 0);
-      } else {
-        /* lanes below cA are out of range of rb (the offset wraps), the others out of range of ra:
-         * the two results are OR-ed when they are consumed (phase 0), not here -- combining them
-         * now would put a full memory round trip on this wavefront's critical path */
-        w = __builtin_amdgcn_raw_buffer_load_b128 (ra, 16 * q, 0, 0);
-        pre_x = __builtin_amdgcn_raw_buffer_load_b128 (rb, 16 * (q - cA), 0, 0);
-      }
-      pre[j] = w;
+      /* all-A and straddling wavefronts read the A range (lanes past it get zeros), all-B ones the B range */
+      if (q0 < cA) pre[j] = __builtin_amdgcn_raw_buffer_load_b128 (ra, 16 * q, 0, 0);
+      else pre[j] = __builtin_amdgcn_raw_buffer_load_b128 (rb, 16 * (q - cA), 0, 0);
     }
+    /* the one wave-instruction per tile that straddles the two ranges also needs its B half; the
+     * two halves are OR-ed when they are consumed (phase 0): combining them here, or loading the
+     * B half from inside the loop above (three static writers of one register), would make this
+     * wavefront wait for its loads on the spot -- a full memory round trip per tile */
+    const u32 qs = cA & ~(u32) (WAVE - 1); /* first chunk of the straddling wave-instruction */
+    if ((cA & (WAVE - 1)) && (qs / WAVE) % NW == (u32) wid) pre_x = __builtin_amdgcn_raw_buffer_load_b128 (rb, 16 * (qs + (u32) lane - cA), 0, 0);
   };
 
   if (cur < num_tiles) fetch (tr);
@@ -489,11 +542,29 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
   asm volatile ("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_last) :: "memory");
 #endif
   /* DEFER: the two tiles whose output is staged in LDS but not yet written (slot = iteration parity) */
-  u64 older_tile = 0, newer_tile = 0;
-  u32 older_tot = 0, newer_tot = 0;
-  bool have_older = false, have_newer = false;
-  u32 xagg = 0;   /* wave 4: speculative loads of the older tile's row counts and row carry */
-  u64 xcarry = 0;
+  constexpr int LAG = RankShared<NT, IPT, OPS>::STAGE_SLOTS;
+  u64 pend_tile[LAG]; /* per staging slot: the tile staged there (wave-uniform) */
+  u32 pend_tot[LAG];
+  bool pend_have[LAG];
+#pragma unroll
+  for (int q = 0; q < LAG; q++) {
+    pend_tile[q] = 0;
+    pend_tot[q] = 0;
+    pend_have[q] = false;
+  }
+  /* static-index accessor (the arrays must stay in registers) */
+  auto pend_get = [&] (int slot, u64 &tile, u32 &tot, bool &have) {
+    tile = pend_tile[0];
+    tot = pend_tot[0];
+    have = pend_have[0];
+#pragma unroll
+    for (int q = 1; q < LAG; q++)
+      if (slot == q) {
+        tile = pend_tile[q];
+        tot = pend_tot[q];
+        have = pend_have[q];
+      }
+  };
   int it = 0;
 
   while (cur < num_tiles) {
@@ -528,14 +599,6 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
         }
       }
     }
-    if (DEFER && have_older && wid == 4) {
-      /* global offset of the tile ranked two iterations ago: its words were requested at the end
-       * of the previous iteration and are normally complete by now */
-      u64 x;
-      if (MODE == MODE_LOOKBACK) x = resolve_offset (agg + (u64) S0 * n_rows * WAVE, carry + (u64) S0 * (n_rows + 1), older_tile, lane, xagg, xcarry, ctl);
-      else x = desc[4 * older_tile + S0];
-      if (lane == 0) sh.excl[S0] = x;
-    }
     PHASE_STAMP (0); /* phase 0: wait for the prefetched records, LDS writes */
     __syncthreads (); /* B0 */
     PHASE_STAMP (1); /* barrier B0 */
@@ -563,14 +626,26 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
         for (int i = 0; i < 4; i++) hk_rng[i] = __hip_atomic_load (&part[2 * tnn + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
-    /* DEFER: write out the tile staged two iterations ago BEFORE the next fetch is issued: the
-     * memory counter retires in order, so the wait for the fetched records at the next phase 0
-     * then only ever waits on stores that are a whole iteration old */
-    if (DEFER && have_older) {
-      const u32 *const slot = sh.stage[it & 1];
-      u32 *__restrict__ dst = outs.rec[S0] + 3 * sh.excl[S0];
-      const u32 nd = 3 * older_tot;
-      for (u32 d = tid; d < nd; d += NT) dst[d] = slot[d];
+    /* DEFER: write out the tile staged LAG iterations ago (its offset was resolved during phase 2
+     * of the previous iteration) BEFORE the next fetch is issued: the memory counter retires in
+     * order, so the wait for the fetched records at the next phase 0 then only ever waits on
+     * stores that are a whole iteration old */
+    u64 w_tile, n_tile;
+    u32 w_tot, n_tot;
+    bool w_have, n_have;
+    pend_get (it % LAG, w_tile, w_tot, w_have);       /* written out now                */
+    pend_get ((it + 1) % LAG, n_tile, n_tot, n_have); /* written out next iteration     */
+    if (DEFER && w_have) {
+      write_out_tile<NT> (outs.rec[S0], uniform64 (sh.excl[S0]), w_tot, sh.stage[it % LAG], tid);
+    }
+    /* wave 4 asks now for the words the next write-out needs (row counts and row carry of the
+     * tile in the next slot, published LAG - 1 iterations ago) and resolves them in phase 2 */
+    u32 xagg = 0;
+    u64 xcarry = 0;
+    if (DEFER && MODE == MODE_LOOKBACK && n_have && wid == 4) {
+      const u64 prow = n_tile / WAVE;
+      if ((u32) lane < (u32) (n_tile % WAVE)) xagg = peek_u32 (&agg[(u64) S0 * n_rows * WAVE + prow * WAVE + lane]);
+      xcarry = peek_u64 (&carry[(u64) S0 * (n_rows + 1) + prow]);
     }
     if (nxt < num_tiles) fetch (tn); /* in flight until the next iteration's phase 0 */
 
@@ -680,12 +755,28 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
     __syncthreads (); /* B1: all input reads done */
     PHASE_STAMP (4); /* barrier B1 */
 
-    /* ---- phase 2: wavefront s owns stream s: chunk scan, tile total, publish for the scanner */
-    if (wid < 4 && ((ops >> wid) & 1u)) {
+    /* ---- phase 2.  Single-output (deferred) kernels: EVERY wavefront scans the chunk ballots
+     * itself and writes the same prefix table to LDS, so nobody has to wait for anybody -- no
+     * barrier between ranking and staging; wavefront 0 also publishes the tile total. */
+    u32 my_total = 0;
+    if (DEFER) {
+      const u32 v = lane < NCH ? (u32) __popcll (sh.kmask[S0][lane]) : 0u;
+      const u32 incl = dpp_inclusive_scan_u32 (v);
+      my_total = (u32) __builtin_amdgcn_readlane ((int) incl, WAVE - 1);
+      if (lane < NCH) sh.cpre[S0][lane] = incl - v;
+      if (lane == 0) {
+        sh.cpre[S0][NCH] = my_total;
+        sh.kmask[S0][NCH] = 0;
+        if (wid == S0) blk_cnt += my_total; /* the kernel-total reduction reads it from lane 0 of wave S0 */
+        if (wid == 0 && MODE == MODE_LOOKBACK) publish_u32 (&agg[(u64) S0 * n_rows * WAVE + cur], AGG_READY | my_total);
+      }
+    }
+    /* any-combination kernel: wavefront s owns stream s: chunk scan, tile total, publish */
+    if (!DEFER && wid < 4 && ((ops >> wid) & 1u)) {
       const int s = wid;
       const u32 v = lane < NCH ? (u32) __popcll (sh.kmask[s][lane]) : 0u;
-      const u32 incl = (u32) wave_inclusive_scan (v, lane);
-      const u32 total = __shfl (incl, WAVE - 1, WAVE);
+      const u32 incl = dpp_inclusive_scan_u32 (v);
+      const u32 total = (u32) __builtin_amdgcn_readlane ((int) incl, WAVE - 1);
       if (lane < NCH) sh.cpre[s][lane] = incl - v;
       if (lane == 0) {
         sh.cpre[s][NCH] = total;
@@ -710,25 +801,27 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
 
     PHASE_STAMP (5); /* phase 2 */
     if (MODE != MODE_COUNT) {
-      __syncthreads (); /* B2 */
+      if (!DEFER) __syncthreads (); /* B2 */
       if (DEFER) {
         /* stage this tile in the slot the write-out at the top of this iteration freed */
-        u32 *const slot = sh.stage[it & 1];
-        const u32 my_tot = sh.tot[S0];
+        u32 *const slot = sh.stage[it % LAG];
+        const u32 my_tot = my_total;
         if (S0 == 0) scatter_stream<0, NT, IPT, OPS> (sh, slot, p, na, lane, wid, key, fa, fb, meta);
         else scatter_stream<1, NT, IPT, OPS> (sh, slot, p, na, lane, wid, key, fa, fb, meta);
-        older_tile = newer_tile;
-        older_tot = newer_tot;
-        have_older = have_newer;
-        newer_tile = cur;
-        newer_tot = my_tot;
-        have_newer = true;
-        /* ask now for the words the next iteration's write-out needs: row counts and row carry
-         * of the tile staged one iteration ago (published a whole iteration ago) */
-        if (MODE == MODE_LOOKBACK && have_older && wid == 4) {
-          const u64 prow = older_tile / WAVE;
-          xagg = (u32) lane < (u32) (older_tile % WAVE) ? peek_u32 (&agg[(u64) S0 * n_rows * WAVE + prow * WAVE + lane]) : 0u;
-          xcarry = peek_u64 (&carry[(u64) S0 * (n_rows + 1) + prow]);
+#pragma unroll
+        for (int q = 0; q < LAG; q++)
+          if (it % LAG == q) {
+            pend_tile[q] = cur;
+            pend_tot[q] = my_tot;
+            pend_have[q] = true;
+          }
+        if (n_have && wid == 4) {
+          /* global offset of the tile the next iteration writes out (this iteration's write-out,
+           * which read sh.excl, finished before B1) */
+          u64 x;
+          if (MODE == MODE_LOOKBACK) x = resolve_offset (agg + (u64) S0 * n_rows * WAVE, carry + (u64) S0 * (n_rows + 1), n_tile, lane, xagg, xcarry, ctl);
+          else x = desc[4 * n_tile + S0];
+          if (lane == 0) sh.excl[S0] = x;
         }
       } else {
 #pragma unroll
@@ -767,12 +860,13 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
 #endif
 
   if (DEFER) {
-    /* drain: the (up to two) tiles still staged, oldest first */
+    /* drain: the tiles still staged, oldest first */
 #pragma unroll
-    for (int q = 0; q < 2; q++) {
-      const bool have = q == 0 ? have_older : have_newer;
-      const u64 tile = q == 0 ? older_tile : newer_tile;
-      const u32 tot = q == 0 ? older_tot : newer_tot;
+    for (int q = 0; q < LAG; q++) {
+      u64 tile;
+      u32 tot;
+      bool have;
+      pend_get ((it + q) % LAG, tile, tot, have);
       if (!have) continue;
       __syncthreads ();
       if (wid == 0) {
@@ -782,10 +876,7 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
         if (lane == 0) sh.excl[S0] = x;
       }
       __syncthreads ();
-      const u32 *const slot = sh.stage[(it + q) & 1];
-      u32 *__restrict__ dst = outs.rec[S0] + 3 * sh.excl[S0];
-      const u32 nd = 3 * tot;
-      for (u32 d = tid; d < nd; d += NT) dst[d] = slot[d];
+      write_out_tile<NT> (outs.rec[S0], uniform64 (sh.excl[S0]), tot, sh.stage[(it + q) % LAG], tid);
     }
   }
 
