@@ -25,6 +25,7 @@ struct gt4hip_context {
   int n_cus;
   int two_pass;
   int64_t grid_override;
+  int force_geom; /* option "geom1": count-only calls use the large geometry too (experiments) */
   uint64_t single_pass_fallbacks; /* calls that had to be rerun on the two-pass path */
   /* freed list storage kept for reuse: hipMalloc / hipFree of tens of GB cost far more than the
    * merges themselves (an 8-way union tree allocates seven outputs per call) */
@@ -179,6 +180,7 @@ extern "C" int gt4hip_set_option (gt4hip_context *ctx, const char *name, int64_t
     }
   }
   else if (!strcmp (name, "grid")) ctx->grid_override = value;
+  else if (!strcmp (name, "geom1")) ctx->force_geom = value != 0;
   else return fail (ctx, GT4HIP_EINVAL, "unknown option %s", name);
   return GT4HIP_OK;
 }
@@ -458,10 +460,13 @@ static int run_pair (gt4hip_context *ctx, const uint32_t *A, uint64_t nA, const 
   memset (run, 0, sizeof *run);
   const uint64_t total = nA + nB;
   if (!total || !p.ops) return GT4HIP_OK;
-  const uint64_t tiles = (total + MERGE_TILE - 1) / MERGE_TILE;
+  /* count-only calls: 512-thread workgroups; everything that materialises records: 1024 */
+  const int geom = (count_only && !ctx->force_geom) ? 0 : 1;
+  const uint64_t tile_records = merge_tile_records (geom);
+  const uint64_t tiles = (total + tile_records - 1) / tile_records;
   run->tiles = tiles;
   int rc;
-  if ((rc = grow (ctx, (void **) &ctx->part, &ctx->part_bytes, (size_t) (tiles + 1) * 16))) return rc;
+  if ((rc = grow (ctx, (void **) &ctx->part, &ctx->part_bytes, (size_t) (tiles + 1) * 16 + (size_t) (tiles / 64 + 3) * 8))) return rc; /* tile ranges + coarse co-ranks */
   const bool two_pass = (ctx->two_pass || force_two_pass) && !count_only;
   const bool need_desc = !count_only;
   if (need_desc && (rc = grow (ctx, (void **) &ctx->desc, &ctx->desc_bytes, desc_bytes_for (tiles)))) return rc;
@@ -470,10 +475,10 @@ static int run_pair (gt4hip_context *ctx, const uint32_t *A, uint64_t nA, const 
     if ((rc = grow (ctx, (void **) &ctx->block_sums, &ctx->block_sums_bytes, nb))) return rc;
   }
   const int first_mode = count_only ? MODE_COUNT : (two_pass ? MODE_COUNT : MODE_LOOKBACK);
-  int grid = ctx->n_cus * merge_blocks_per_cu (first_mode, p.ops);
+  int grid = ctx->n_cus * merge_blocks_per_cu (geom, first_mode, p.ops);
   if (ctx->grid_override > 0) grid = (int) ctx->grid_override;
   if ((uint64_t) grid > tiles + 1) grid = (int) tiles + 1; /* workers + the scanner workgroup */
-  int grid2 = ctx->n_cus * merge_blocks_per_cu (MODE_OFFSETS, p.ops);
+  int grid2 = ctx->n_cus * merge_blocks_per_cu (geom, MODE_OFFSETS, p.ops);
   if ((uint64_t) grid2 > tiles) grid2 = (int) tiles;
 
   PairOutputs outs;
@@ -483,17 +488,17 @@ static int run_pair (gt4hip_context *ctx, const uint32_t *A, uint64_t nA, const 
   HIPCHK (ctx, hipEventRecord (ctx->ev[0], st));
   HIPCHK (ctx, hipMemsetAsync (ctx->ctl, 0, sizeof (PairControl), st));
   if (need_desc && !two_pass) HIPCHK (ctx, hipMemsetAsync (ctx->desc, 0, desc_bytes_for (tiles), st));
-  HIPCHK (ctx, launch_partition (st, A, nA, B, nB, tiles, ctx->part));
+  HIPCHK (ctx, launch_partition (st, A, nA, B, nB, tiles, tile_records, ctx->part));
   HIPCHK (ctx, hipEventRecord (ctx->ev[1], st));
   if (count_only) {
-    HIPCHK (ctx, launch_pair_merge (st, MODE_COUNT, grid, A, nA, B, nB, ctx->part, tiles, p, outs, NULL, ctx->ctl));
+    HIPCHK (ctx, launch_pair_merge (st, geom, MODE_COUNT, grid, A, nA, B, nB, ctx->part, tiles, p, outs, NULL, ctx->ctl));
   } else if (two_pass) {
-    HIPCHK (ctx, launch_pair_merge (st, MODE_COUNT, grid, A, nA, B, nB, ctx->part, tiles, p, outs, ctx->desc, ctx->ctl));
+    HIPCHK (ctx, launch_pair_merge (st, geom, MODE_COUNT, grid, A, nA, B, nB, ctx->part, tiles, p, outs, ctx->desc, ctx->ctl));
     HIPCHK (ctx, launch_scan_tiles (st, ctx->desc, tiles, ctx->block_sums));
     HIPCHK (ctx, hipMemsetAsync (ctx->ctl, 0, sizeof (PairControl), st));
-    HIPCHK (ctx, launch_pair_merge (st, MODE_OFFSETS, grid2, A, nA, B, nB, ctx->part, tiles, p, outs, ctx->desc, ctx->ctl));
+    HIPCHK (ctx, launch_pair_merge (st, geom, MODE_OFFSETS, grid2, A, nA, B, nB, ctx->part, tiles, p, outs, ctx->desc, ctx->ctl));
   } else {
-    HIPCHK (ctx, launch_pair_merge (st, MODE_LOOKBACK, grid, A, nA, B, nB, ctx->part, tiles, p, outs, ctx->desc, ctx->ctl));
+    HIPCHK (ctx, launch_pair_merge (st, geom, MODE_LOOKBACK, grid, A, nA, B, nB, ctx->part, tiles, p, outs, ctx->desc, ctx->ctl));
   }
   HIPCHK (ctx, hipEventRecord (ctx->ev[2], st));
   HIPCHK (ctx, hipMemcpyAsync (ctx->ctl_host, ctx->ctl, sizeof (PairControl), hipMemcpyDeviceToHost, st));

@@ -36,7 +36,7 @@ struct PairOutputs {
 struct PairControl {
   unsigned long long n_words[4];
   unsigned long long total_count[4];
-  unsigned int ticket;     /* (unused, kept for layout) */
+  unsigned int ticket;     /* tile-group counter of the single-pass kernel */
   unsigned int error;      /* non-zero: a bounded spin gave up / consistency check tripped */
   unsigned int role;       /* first workgroup to arrive becomes the scanner */
   unsigned int pad;
@@ -50,17 +50,18 @@ enum MergeMode : int {
   MODE_OFFSETS = 2    /* pass 2 of the two-pass path: tile offsets already scanned                       */
 };
 
-/* Geometry of the merge kernel. */
-constexpr int MERGE_NT = 512;               /* threads per workgroup (8 wavefronts)      */
-constexpr int MERGE_VT = 4;                 /* records per thread (one per lane per pass)  */
-constexpr int MERGE_CAP = MERGE_NT * MERGE_VT; /* LDS capacity in records                 */
-constexpr int MERGE_TILE = MERGE_CAP - 3;   /* nominal tile; pair fix-up makes it +-1; both ranges in 16-byte chunks fit */
-constexpr int MERGE_WAVES_PER_SIMD = 4;     /* single-output kernels: <= 80 VGPRs, 3 workgroups (24 waves) per CU */
-constexpr int MERGE_WAVES_PER_SIMD_GENERIC = 4; /* any-combination kernel: <= 128 VGPRs                     */
+/* Geometry of the merge kernel: 4 records per thread; workgroups of 512 threads
+ * (2048-record tiles, geom 0: count-only calls) or 1024 threads (4096-record tiles, geom 1: calls
+ * that materialise records).  A tile holds CAP - 3 records: the pair fix-up makes it +-1 and both
+ * record ranges must fit in 16-byte chunks. */
+constexpr int MERGE_VT = 4;
+constexpr int MERGE_WAVES_PER_SIMD = 4;         /* 512-thread geometry, single-output kernels: <= 128 VGPRs */
+constexpr int MERGE_WAVES_PER_SIMD_GENERIC = 4; /* any-combination kernel                                     */
 
+uint64_t merge_tile_records (int geom);
 hipError_t launch_partition (hipStream_t s, const uint32_t *A, uint64_t nA, const uint32_t *B, uint64_t nB,
-                             uint64_t num_tiles, uint64_t *part);
-hipError_t launch_pair_merge (hipStream_t s, int mode, int grid, const uint32_t *A, uint64_t nA,
+                             uint64_t num_tiles, uint64_t tile_records, uint64_t *part);
+hipError_t launch_pair_merge (hipStream_t s, int geom, int mode, int grid, const uint32_t *A, uint64_t nA,
                               const uint32_t *B, uint64_t nB, const uint64_t *part, uint64_t num_tiles,
                               const PairParams &p, const PairOutputs &o, unsigned long long *desc,
                               PairControl *ctl);
@@ -76,7 +77,7 @@ hipError_t launch_counts_table (hipStream_t s, const uint32_t *keys_rec, uint64_
                                 uint64_t n_list, uint32_t *counts, uint32_t n_lists, uint32_t column);
 hipError_t launch_extract_keys (hipStream_t s, const uint32_t *rec, uint64_t n, unsigned long long *keys);
 
-int merge_blocks_per_cu (int mode, uint32_t ops);
+int merge_blocks_per_cu (int geom, int mode, uint32_t ops);
 
 }  // namespace gt4
 

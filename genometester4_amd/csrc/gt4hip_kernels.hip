@@ -112,10 +112,13 @@ __device__ __forceinline__ bool eval_stream (u32 kind, u32 fa, u32 fb, const Str
 
 /* ------------------------------------------------------------------ K1: partition */
 
-/* Number of A records among the first `diag` records of merge(A, B) with A first on ties. */
-__device__ __forceinline__ u64 merge_path (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 nB, u64 diag)
+/* Number of A records among the first `diag` records of merge(A, B) with A first on ties,
+ * searched inside [lo, hi] (the caller's bracket must contain the answer). */
+__device__ __forceinline__ u64 merge_path (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 nB, u64 diag, u64 lo, u64 hi)
 {
-  u64 lo = diag > nB ? diag - nB : 0, hi = diag < nA ? diag : nA;
+  const u64 lo0 = diag > nB ? diag - nB : 0, hi0 = diag < nA ? diag : nA;
+  if (lo < lo0) lo = lo0;
+  if (hi > hi0) hi = hi0;
   while (lo < hi) {
     const u64 mid = (lo + hi) >> 1;
     if (load_key (A, mid) <= load_key (B, diag - 1 - mid)) lo = mid + 1;
@@ -124,15 +127,33 @@ __device__ __forceinline__ u64 merge_path (const u32 *__restrict__ A, u64 nA, co
   return lo;
 }
 
+constexpr u64 PART_COARSE = 64; /* tiles per coarse partition interval */
+
+/* level 1: the co-rank of every PART_COARSE-th tile boundary, full-range search (few threads) */
+__global__ void k_partition_coarse (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 nB, u64 num_tiles, u64 tile_records, u64 *__restrict__ coarse)
+{
+  const u64 c = (u64) blockIdx.x * blockDim.x + threadIdx.x;
+  const u64 n_coarse = (num_tiles + PART_COARSE - 1) / PART_COARSE;
+  if (c > n_coarse) return;
+  const u64 total = nA + nB;
+  u64 diag = c * PART_COARSE * tile_records;
+  if (diag > total) diag = total;
+  coarse[c] = merge_path (A, nA, B, nB, diag, 0, nA);
+}
+
+/* level 2: every tile boundary, searched only between its two coarse neighbours (the co-rank
+ * is monotone in the diagonal): ~17 dependent reads instead of ~31, and the threads of one
+ * coarse interval probe the same few cache lines */
 __global__ void k_partition (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 nB,
-                             u64 num_tiles, u64 *__restrict__ part)
+                             u64 num_tiles, u64 tile_records, const u64 *__restrict__ coarse, u64 *__restrict__ part)
 {
   const u64 t = (u64) blockIdx.x * blockDim.x + threadIdx.x;
   if (t > num_tiles) return;
   const u64 total = nA + nB;
-  u64 diag = t * (u64) MERGE_TILE;
+  u64 diag = t * tile_records;
   if (diag > total) diag = total;
-  u64 a = merge_path (A, nA, B, nB, diag), b = diag - a;
+  const u64 c = t / PART_COARSE;
+  u64 a = (t % PART_COARSE) ? merge_path (A, nA, B, nB, diag, coarse[c], coarse[c + 1]) : coarse[c], b = diag - a;
   /* keys are unique inside a list, so a key present in both lists sits as an adjacent (A, B)
    * pair in the merged order; if the diagonal falls between them pull the B record back into
    * the earlier tile so that one tile owns the pair. */
@@ -232,17 +253,26 @@ constexpr int SCAN_ROWS = 16;        /* rows of 64 tiles a scanner wavefront kee
  * publishes the carry into the next row. */
 __device__ void scanner_wave (u32 *agg, u64 *carry_out, u64 num_tiles, PairControl *ctl, int lane)
 {
+  /* the scanner shares its SIMD with worker wavefronts and is the one serial resource of the
+   * kernel: it must win the instruction arbitration */
+  __builtin_amdgcn_s_setprio (3);
   u64 carry = 0;
   const u64 rows = (num_tiles + WAVE - 1) / WAVE;
   if (lane == 0) publish_u64 (&carry_out[0], CARRY_READY);
-  for (u64 r0 = 0; r0 < rows; r0 += SCAN_ROWS) {
-    const int n = rows - r0 < (u64) SCAN_ROWS ? (int) (rows - r0) : SCAN_ROWS;
-    u32 v[SCAN_ROWS];
+  /* two batches of SCAN_ROWS rows in flight: while one is summed and published, the loads of the
+   * next are already under way (a batch costs one memory round trip otherwise) */
+  u32 v[SCAN_ROWS], w[SCAN_ROWS];
+  auto load_batch = [&] (u32 (&dst)[SCAN_ROWS], u64 r0) {
 #pragma unroll
     for (int j = 0; j < SCAN_ROWS; j++) {
       const u64 idx = (r0 + j) * WAVE + lane;
-      v[j] = (j < n && idx < num_tiles) ? peek_u32 (&agg[idx]) : AGG_READY;
+      dst[j] = (r0 + j < rows && idx < num_tiles) ? peek_u32 (&agg[idx]) : AGG_READY;
     }
+  };
+  load_batch (v, 0);
+  for (u64 r0 = 0; r0 < rows; r0 += SCAN_ROWS) {
+    const int n = rows - r0 < (u64) SCAN_ROWS ? (int) (rows - r0) : SCAN_ROWS;
+    load_batch (w, r0 + SCAN_ROWS);
     int done = 0;
     u32 spins = 0;
 #ifdef GT4_PROFILE_PHASES
@@ -283,6 +313,8 @@ __device__ void scanner_wave (u32 *agg, u64 *carry_out, u64 num_tiles, PairContr
         if (j >= done && j < n && !(v[j] & AGG_READY)) v[j] = peek_u32 (&agg[idx]);
       }
     }
+#pragma unroll
+    for (int j = 0; j < SCAN_ROWS; j++) v[j] = w[j];
   }
 }
 
@@ -358,8 +390,10 @@ struct RankShared {
   /* write-out lags this many tiles behind ranking; an intersection's staging slots are half the
    * size of a union's, so it can afford three within the LDS of two workgroups per CU */
   static constexpr int STAGE_SLOTS = OPS == 2 ? 4 : 2;
-  u64 keys[CAP];          /* input view; OPS == 0: the output view (3 * CAP dwords) starts here too */
-  u32 cnts[CAP];
+  /* input view: the tile's packed records exactly as they lie in HBM (12-byte AoS), the A range
+   * from dword 0, the B range from the next 16-byte boundary; OPS == 0: the output view (3 * CAP
+   * dwords) starts here too */
+  alignas (16) u32 raw[3 * CAP];
   u32 stage[STAGE_SLOTS][STAGE_DW];
   u64 kmask[4][NCH + 1];  /* keep-flag ballot per 64-record chunk, per stream (+1: empty sentinel chunk) */
   u32 cpre[4][NCH + 1];   /* exclusive prefix of popcount(kmask) over chunks, per stream               */
@@ -431,7 +465,7 @@ __device__ __forceinline__ u64 uniform64 (u64 v)
 /* OPS != 0 fixes the set of output streams at compile time (the common single-output calls get a
  * kernel without the other streams' code and registers); OPS == 0 takes it from p.ops. */
 template <int NT, int IPT, int MODE, int OPS>
-__global__ __launch_bounds__ (NT, OPS ? MERGE_WAVES_PER_SIMD : MERGE_WAVES_PER_SIMD_GENERIC) void
+__global__ __launch_bounds__ (NT, NT == 1024 ? 4 : (OPS ? MERGE_WAVES_PER_SIMD : MERGE_WAVES_PER_SIMD_GENERIC)) void
 k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 nB, u64 *part, u64 num_tiles,
               PairParams p, PairOutputs outs, u64 *desc, PairControl *ctl)
 {
@@ -444,7 +478,7 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
   static_assert (NW >= 4, "one wavefront per output stream in phase 2");
   static_assert (NCH <= WAVE, "chunk scan is a single wavefront pass");
   __shared__ RankShared<NT, IPT, OPS> sh;
-  u32 *const lds32 = reinterpret_cast<u32 *> (&sh.keys[0]);
+  u32 *const lds32 = sh.raw;
 
   const int tid = threadIdx.x, lane = tid & (WAVE - 1);
   const int wid = __builtin_amdgcn_readfirstlane (tid / WAVE); /* wave-uniform: scalar branches on it */
@@ -476,11 +510,12 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
 
   /* Tiles are dealt round-robin: worker w processes tiles w, w + W, w + 2W, ...  (A shared ticket
    * counter saturates near 88 returning atomics per microsecond -- MI355X_MICROARCH.md, row
-   * dequeue -- which capped the whole kernel; counters sharded by worker class drift apart and
-   * leave every worker waiting for the slowest class.)  With the scanner this needs every worker
-   * resident, which the host guarantees by sizing the grid from the kernel's occupancy; worker
-   * ids come from arrival order, and every spin is bounded, so a non-resident worker shows up as
-   * an error flag (the host then reruns the call on the two-pass path), never as a hang.
+   * dequeue -- which capped the whole kernel; counters sharded by worker class drift apart;
+   * claiming tiles in groups puts a group's last tile behind the next group's write-out.)  With
+   * the scanner this needs every worker resident, which the host guarantees by sizing the grid
+   * from the kernel's occupancy; worker ids come from arrival order, and every spin is bounded,
+   * so a non-resident worker shows up as an error flag (the host then reruns the call on the
+   * two-pass path), never as a hang.
    * A three-deep ring keeps every dependent global round trip off the critical path: while tile i
    * is processed, the records of tile i+1 are in flight and the range of tile i+2 is being read. */
   const u32 n_workers = MODE == MODE_LOOKBACK ? gridDim.x - 1 : gridDim.x;
@@ -573,29 +608,19 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
       if (tid == 0) atomicOr (&ctl->error, 2u);
       break;
     }
-    /* ---- phase 0: registers -> LDS, AoS dwords -> SoA (an 8-byte key read at a 4-byte aligned
-     * LDS address would replay at 64 cycles, Guideline 17).  Dword d of a range belongs to record
-     * d / 3, field d % 3 (0, 1: key halves, 2: count). */
+    /* ---- phase 0: registers -> LDS, a raw copy: chunk q of the tile lands at LDS byte 16 q, so the
+     * A records sit at dword 3 i and the B records at dword OB + 3 j with OB = 4 cA.  Keys are
+     * then read as two dwords (a 12-byte stride is conflict-free across lanes); no AoS -> SoA pass. */
+    const u32 OB = 4 * ((3 * na + 3) >> 2);
     {
-      const u32 da = 3 * na, db = 3 * nb, cA = (da + 3) >> 2, cB = (db + 3) >> 2;
+      const u32 cA = OB >> 2, cB = (3 * nb + 3) >> 2;
 #pragma unroll
       for (int j = 0; j < NLOAD4; j++) {
         const u32 q = (u32) j * NT + (u32) tid;
         if (q < cA + cB) {
-          const bool in_a = q < cA;
-          const u32 d0 = 4 * (in_a ? q : q - cA), lim = in_a ? da : db, rbase = in_a ? 0u : na;
-          const u32 r0 = d0 / 3, f0 = d0 - 3 * r0;
           const u32 q0 = (u32) j * NT + (u32) wid * WAVE;
           const bool straddle = q0 < cA && q0 + WAVE > cA; /* wave-uniform */
-          const u32x4 pj = straddle ? (pre[j] | pre_x) : pre[j];
-          const u32 w[4] = { pj.x, pj.y, pj.z, pj.w };
-#pragma unroll
-          for (int i = 0; i < 4; i++) {
-            const u32 fi = f0 + (u32) i;                       /* 0 .. 5 */
-            const u32 r = rbase + r0 + (fi >= 3 ? 1u : 0u);    /* f0 + i < 6: at most one wrap */
-            const u32 f = fi >= 3 ? fi - 3 : fi;
-            if (d0 + (u32) i < lim) lds32[(f == 2) ? (2 * CAP + r) : (2 * r + f)] = w[i];
-          }
+          *reinterpret_cast<u32x4 *> (lds32 + 4 * q) = straddle ? (pre[j] | pre_x) : pre[j];
         }
       }
     }
@@ -660,7 +685,7 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
 #pragma unroll
       for (int kk = 0; kk < IPT; kk += 2) {
         bool live[2], valid[2];
-        u32 is_a[2], own[2], obase[2], on[2], lim_n[2], lo[2];
+        u32 is_a[2], own[2], ob[2], lim3[2], lo3[2]; /* ob: dword base of the other list; *3: in dwords */
         u64 ky[2];
 #pragma unroll
         for (int u = 0; u < 2; u++) {
@@ -670,12 +695,12 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
           valid[u] = live[u] && e < nt;
           const u32 ec = valid[u] ? e : 0u;
           is_a[u] = ec < na ? 1u : 0u;
-          ky[u] = sh.keys[ec];
-          own[u] = sh.cnts[ec];
-          obase[u] = is_a[u] ? na : 0u;
-          on[u] = is_a[u] ? nb : na;
-          lim_n[u] = valid[u] ? on[u] : 0u;
-          lo[u] = 0;
+          const u32 at = is_a[u] ? 3 * ec : OB + 3 * (ec - na);
+          ky[u] = (u64) lds32[at] | ((u64) lds32[at + 1] << 32);
+          own[u] = lds32[at + 2];
+          ob[u] = is_a[u] ? OB : 0u;
+          lim3[u] = valid[u] ? 3 * (is_a[u] ? nb : na) : 0u;
+          lo3[u] = 0;
         }
         if (live[0] || live[1]) {
           /* lower bound of ky in the other list: greedy bit-by-bit search with a fixed step
@@ -686,11 +711,14 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
           for (u32 step = CAP / 2; step >= 1; step >>= 1) {
             u64 pv[2];
 #pragma unroll
-            for (int u = 0; u < 2; u++) pv[u] = sh.keys[obase[u] + lo[u] + step - 1];
+            for (int u = 0; u < 2; u++) {
+              const u32 *const pr = lds32 + ob[u] + lo3[u] + 3 * (step - 1);
+              pv[u] = (u64) pr[0] | ((u64) pr[1] << 32);
+            }
 #pragma unroll
             for (int u = 0; u < 2; u++) {
-              const bool lt = (lo[u] + step - 1 < lim_n[u]) & (pv[u] < ky[u]);
-              lo[u] += lt ? step : 0u;
+              const bool lt = (lo3[u] + 3 * (step - 1) < lim3[u]) & (pv[u] < ky[u]);
+              lo3[u] += lt ? 3 * step : 0u;
             }
           }
         }
@@ -698,11 +726,11 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
         for (int u = 0; u < 2; u++) {
           const int k = kk + u;
           const u32 chunk = (u32) k * NW + (u32) wid;
-          const u32 r = lo[u];
-          const bool in = r < lim_n[u];
-          const u32 oat = obase[u] + (in ? r : 0u);
-          const u64 okey = sh.keys[oat];
-          const u32 ocnt = sh.cnts[oat];
+          const u32 r = (lo3[u] * 43691u) >> 17; /* lo3 / 3, exact for multiples of 3 below 2^16 */
+          const bool in = lo3[u] < lim3[u];
+          const u32 oat = ob[u] + (in ? lo3[u] : 0u);
+          const u64 okey = (u64) lds32[oat] | ((u64) lds32[oat + 1] << 32);
+          const u32 ocnt = lds32[oat + 2];
           const bool matched = in & (okey == ky[u]);
           u32 kind, xa, xb;
           if (is_a[u]) {
@@ -1037,65 +1065,88 @@ inline int grid_for (u64 n, int block, int cap)
 /* ------------------------------------------------------------------ host launchers */
 
 hipError_t launch_partition (hipStream_t s, const uint32_t *A, uint64_t nA, const uint32_t *B, uint64_t nB,
-                             uint64_t num_tiles, uint64_t *part)
+                             uint64_t num_tiles, uint64_t tile_records, uint64_t *part)
 {
+  /* the coarse table lives behind the (num_tiles + 1) tile ranges in the same workspace */
+  u64 *const coarse = (u64 *) part + 2 * (num_tiles + 1);
+  const u64 n_coarse = (num_tiles + PART_COARSE - 1) / PART_COARSE + 1;
+  hipLaunchKernelGGL (k_partition_coarse, dim3 ((unsigned) ((n_coarse + 255) / 256)), dim3 (256), 0, s, A, nA, B, nB, num_tiles, tile_records, coarse);
   const u64 threads = num_tiles + 1;
-  const unsigned grid = (unsigned) ((threads + 255) / 256);
-  hipLaunchKernelGGL (k_partition, dim3 (grid), dim3 (256), 0, s, A, nA, B, nB, num_tiles, (u64 *) part);
+  hipLaunchKernelGGL (k_partition, dim3 ((unsigned) ((threads + 255) / 256)), dim3 (256), 0, s, A, nA, B, nB, num_tiles, tile_records,
+                      (const u64 *) coarse, (u64 *) part);
   return hipGetLastError ();
 }
 
-template <int OPS>
+/* Two workgroup geometries (measured): count-only calls run fastest with 512 threads
+ * and 2048-record tiles (two workgroups per CU overlap their phases); calls that materialise
+ * records run fastest with 1024 threads and 4096-record tiles (half as many tiles on the scan
+ * chain, whose hop latency is fixed, and room for the staging slots in one workgroup per CU). */
+template <int NT> struct GeomWaves {
+  static constexpr int single = NT == 1024 ? 4 : MERGE_WAVES_PER_SIMD;
+  static constexpr int generic = NT == 1024 ? 4 : MERGE_WAVES_PER_SIMD_GENERIC;
+};
+
+template <int NT, int OPS>
 static hipError_t launch_pair_merge_ops (hipStream_t s, int mode, int grid, const uint32_t *A, uint64_t nA, const uint32_t *B, uint64_t nB,
                                          const uint64_t *part, uint64_t num_tiles, const PairParams &p, const PairOutputs &o,
                                          unsigned long long *desc, PairControl *ctl)
 {
   if (mode == MODE_COUNT)
-    hipLaunchKernelGGL ((k_pair_merge<MERGE_NT, MERGE_VT, MODE_COUNT, OPS>), dim3 (grid), dim3 (MERGE_NT), 0, s, A, nA, B, nB,
-                        (u64 *) part, num_tiles, p, o, desc, ctl);
-  else if (mode == MODE_LOOKBACK)
-    hipLaunchKernelGGL ((k_pair_merge<MERGE_NT, MERGE_VT, MODE_LOOKBACK, OPS>), dim3 (grid), dim3 (MERGE_NT), 0, s, A, nA, B, nB,
-                        (u64 *) part, num_tiles, p, o, desc, ctl);
+    hipLaunchKernelGGL ((k_pair_merge<NT, MERGE_VT, MODE_COUNT, OPS>), dim3 (grid), dim3 (NT), 0, s, A, nA, B, nB, (u64 *) part, num_tiles, p, o, desc, ctl);
+  else if (NT == 1024 && mode == MODE_LOOKBACK)
+    hipLaunchKernelGGL ((k_pair_merge<1024, MERGE_VT, MODE_LOOKBACK, OPS>), dim3 (grid), dim3 (1024), 0, s, A, nA, B, nB, (u64 *) part, num_tiles, p, o, desc, ctl);
+  else if (NT == 1024)
+    hipLaunchKernelGGL ((k_pair_merge<1024, MERGE_VT, MODE_OFFSETS, OPS>), dim3 (grid), dim3 (1024), 0, s, A, nA, B, nB, (u64 *) part, num_tiles, p, o, desc, ctl);
   else
-    hipLaunchKernelGGL ((k_pair_merge<MERGE_NT, MERGE_VT, MODE_OFFSETS, OPS>), dim3 (grid), dim3 (MERGE_NT), 0, s, A, nA, B, nB,
-                        (u64 *) part, num_tiles, p, o, desc, ctl);
+    return hipErrorInvalidValue; /* the small geometry only counts */
   return hipGetLastError ();
 }
 
-template <int OPS>
+template <int NT, int OPS>
 static int blocks_per_cu_ops (int mode)
 {
   int n = 0;
   hipError_t e;
-  if (mode == MODE_COUNT) e = hipOccupancyMaxActiveBlocksPerMultiprocessor (&n, k_pair_merge<MERGE_NT, MERGE_VT, MODE_COUNT, OPS>, MERGE_NT, 0);
-  else if (mode == MODE_LOOKBACK) e = hipOccupancyMaxActiveBlocksPerMultiprocessor (&n, k_pair_merge<MERGE_NT, MERGE_VT, MODE_LOOKBACK, OPS>, MERGE_NT, 0);
-  else e = hipOccupancyMaxActiveBlocksPerMultiprocessor (&n, k_pair_merge<MERGE_NT, MERGE_VT, MODE_OFFSETS, OPS>, MERGE_NT, 0);
+  if (mode == MODE_COUNT) e = hipOccupancyMaxActiveBlocksPerMultiprocessor (&n, k_pair_merge<NT, MERGE_VT, MODE_COUNT, OPS>, NT, 0);
+  else if (mode == MODE_LOOKBACK) e = hipOccupancyMaxActiveBlocksPerMultiprocessor (&n, k_pair_merge<1024, MERGE_VT, MODE_LOOKBACK, OPS>, 1024, 0);
+  else e = hipOccupancyMaxActiveBlocksPerMultiprocessor (&n, k_pair_merge<1024, MERGE_VT, MODE_OFFSETS, OPS>, 1024, 0);
   if (e != hipSuccess || n < 1) n = 1;
   /* never more than the register file admits for the declared launch bounds */
-  const int by_regs = (OPS ? MERGE_WAVES_PER_SIMD : MERGE_WAVES_PER_SIMD_GENERIC) * 4 / (MERGE_NT / 64);
+  const int by_regs = (OPS ? GeomWaves<NT>::single : GeomWaves<NT>::generic) * 4 / (NT / 64);
   if (by_regs >= 1 && n > by_regs) n = by_regs;
   return n;
 }
 
+uint64_t merge_tile_records (int geom) { return (uint64_t) (geom ? 1024 : 512) * MERGE_VT - 3; }
+
 /* workgroups of the merge kernel that are resident per CU (the single-pass path needs every
  * worker resident: see k_pair_merge) */
-int merge_blocks_per_cu (int mode, uint32_t ops)
+int merge_blocks_per_cu (int geom, int mode, uint32_t ops)
 {
-  static int cache[3][3];
+  static int cache[2][3][3];
   const int oi = ops == 1u ? 1 : (ops == 2u ? 2 : 0);
-  if (!cache[mode][oi]) cache[mode][oi] = oi == 1 ? blocks_per_cu_ops<1> (mode) : (oi == 2 ? blocks_per_cu_ops<2> (mode) : blocks_per_cu_ops<0> (mode));
-  return cache[mode][oi];
+  int &c = cache[geom ? 1 : 0][mode][oi];
+  if (!c) {
+    if (geom) c = oi == 1 ? blocks_per_cu_ops<1024, 1> (mode) : (oi == 2 ? blocks_per_cu_ops<1024, 2> (mode) : blocks_per_cu_ops<1024, 0> (mode));
+    else c = oi == 1 ? blocks_per_cu_ops<512, 1> (mode) : (oi == 2 ? blocks_per_cu_ops<512, 2> (mode) : blocks_per_cu_ops<512, 0> (mode));
+  }
+  return c;
 }
 
-hipError_t launch_pair_merge (hipStream_t s, int mode, int grid, const uint32_t *A, uint64_t nA,
+hipError_t launch_pair_merge (hipStream_t s, int geom, int mode, int grid, const uint32_t *A, uint64_t nA,
                               const uint32_t *B, uint64_t nB, const uint64_t *part, uint64_t num_tiles,
                               const PairParams &p, const PairOutputs &o, unsigned long long *desc,
                               PairControl *ctl)
 {
   /* single-output calls (glistcompare -u / -i, every N-way level) take a specialised kernel */
-  if (p.ops == 1u) return launch_pair_merge_ops<1> (s, mode, grid, A, nA, B, nB, part, num_tiles, p, o, desc, ctl);
-  if (p.ops == 2u) return launch_pair_merge_ops<2> (s, mode, grid, A, nA, B, nB, part, num_tiles, p, o, desc, ctl);
-  return launch_pair_merge_ops<0> (s, mode, grid, A, nA, B, nB, part, num_tiles, p, o, desc, ctl);
+  if (geom) {
+    if (p.ops == 1u) return launch_pair_merge_ops<1024, 1> (s, mode, grid, A, nA, B, nB, part, num_tiles, p, o, desc, ctl);
+    if (p.ops == 2u) return launch_pair_merge_ops<1024, 2> (s, mode, grid, A, nA, B, nB, part, num_tiles, p, o, desc, ctl);
+    return launch_pair_merge_ops<1024, 0> (s, mode, grid, A, nA, B, nB, part, num_tiles, p, o, desc, ctl);
+  }
+  if (p.ops == 1u) return launch_pair_merge_ops<512, 1> (s, mode, grid, A, nA, B, nB, part, num_tiles, p, o, desc, ctl);
+  if (p.ops == 2u) return launch_pair_merge_ops<512, 2> (s, mode, grid, A, nA, B, nB, part, num_tiles, p, o, desc, ctl);
+  return launch_pair_merge_ops<512, 0> (s, mode, grid, A, nA, B, nB, part, num_tiles, p, o, desc, ctl);
 }
 
 hipError_t launch_scan_tiles (hipStream_t s, unsigned long long *desc, uint64_t num_tiles, unsigned long long *block_sums)

@@ -16,9 +16,8 @@ def merge_tile():
         import re
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         txt = open(os.path.join(root, "genometester4_amd", "csrc", "gt4hip_internal.h")).read()
-        nt = int(re.search(r"MERGE_NT\s*=\s*(\d+)", txt).group(1))
         vt = int(re.search(r"MERGE_VT\s*=\s*(\d+)", txt).group(1))
-        MERGE_TILE = nt * vt - 1
+        MERGE_TILE = 512 * vt - 3  # the small geometry; sizes around it and its double are exercised
     return MERGE_TILE
 
 
