@@ -475,6 +475,7 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
   constexpr int NLOAD4 = (3 * IPT + 3) / 4;      /* 16-byte chunks each thread fetches per tile */
   constexpr bool DEFER = (OPS == 1 || OPS == 2) && MODE != MODE_COUNT;
   constexpr int S0 = OPS == 2 ? 1 : 0;           /* the stream of a single-output kernel */
+  constexpr bool STAGGER = NT >= 1024;           /* spread the fetch over the iteration (measured: helps 16-wave workgroups only) */
   static_assert (NW >= 4, "one wavefront per output stream in phase 2");
   static_assert (NCH <= WAVE, "chunk scan is a single wavefront pass");
   __shared__ RankShared<NT, IPT, OPS> sh;
@@ -550,24 +551,35 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
    * as is; one range-checked descriptor per range makes every byte past the range read as 0
    * without touching memory, so the last, partial chunk needs no special case.  A wavefront is
    * all-A, all-B, or (once per tile) straddles the two ranges; the choice is wave-uniform. */
-  auto fetch = [&] (const TileRange &t) {
+  /* fetch_part (t, j): the j-th of the NLOAD4 wave-instructions (j == NLOAD4: the straddling
+   * half); fetch (t): all of them.  In the main loop the parts are issued at different points of
+   * the iteration: sixteen wavefronts issuing everything right behind the same barrier only queue
+   * up in front of the CU's one address unit. */
+  auto fetch_part = [&] (const TileRange &t, int j) {
     const u32 da = 3 * t.na, db = 3 * t.nb, cA = (da + 3) >> 2;
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc ((void *) (A + 3 * t.a0), 0, (int) (4 * da), 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc ((void *) (B + 3 * t.b0), 0, (int) (4 * db), 0x00020000);
 #pragma unroll
-    for (int j = 0; j < NLOAD4; j++) {
-      const u32 q0 = (u32) j * NT + (u32) wid * WAVE; /* first chunk of this wavefront */
+    for (int jj = 0; jj < NLOAD4; jj++) {
+      if (jj != j) continue;
+      const u32 q0 = (u32) jj * NT + (u32) wid * WAVE; /* first chunk of this wavefront */
       const u32 q = q0 + (u32) lane;
       /* all-A and straddling wavefronts read the A range (lanes past it get zeros), all-B ones the B range */
-      if (q0 < cA) pre[j] = __builtin_amdgcn_raw_buffer_load_b128 (ra, 16 * q, 0, 0);
-      else pre[j] = __builtin_amdgcn_raw_buffer_load_b128 (rb, 16 * (q - cA), 0, 0);
+      if (q0 < cA) pre[jj] = __builtin_amdgcn_raw_buffer_load_b128 (ra, 16 * q, 0, 0);
+      else pre[jj] = __builtin_amdgcn_raw_buffer_load_b128 (rb, 16 * (q - cA), 0, 0);
     }
-    /* the one wave-instruction per tile that straddles the two ranges also needs its B half; the
-     * two halves are OR-ed when they are consumed (phase 0): combining them here, or loading the
-     * B half from inside the loop above (three static writers of one register), would make this
-     * wavefront wait for its loads on the spot -- a full memory round trip per tile */
-    const u32 qs = cA & ~(u32) (WAVE - 1); /* first chunk of the straddling wave-instruction */
-    if ((cA & (WAVE - 1)) && (qs / WAVE) % NW == (u32) wid) pre_x = __builtin_amdgcn_raw_buffer_load_b128 (rb, 16 * (qs + (u32) lane - cA), 0, 0);
+    if (j == NLOAD4) {
+      /* the one wave-instruction per tile that straddles the two ranges also needs its B half; the
+       * two halves are OR-ed when they are consumed (phase 0): combining them here, or loading
+       * the B half from inside the loop above (several static writers of one register), would
+       * make this wavefront wait for its loads on the spot -- a full memory round trip per tile */
+      const u32 qs = cA & ~(u32) (WAVE - 1); /* first chunk of the straddling wave-instruction */
+      if ((cA & (WAVE - 1)) && (qs / WAVE) % NW == (u32) wid) pre_x = __builtin_amdgcn_raw_buffer_load_b128 (rb, 16 * (qs + (u32) lane - cA), 0, 0);
+    }
+  };
+  auto fetch = [&] (const TileRange &t) {
+#pragma unroll
+    for (int j = 0; j <= NLOAD4; j++) fetch_part (t, j);
   };
 
   if (cur < num_tiles) fetch (tr);
@@ -661,7 +673,9 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
     pend_get (it % LAG, w_tile, w_tot, w_have);       /* written out now                */
     pend_get ((it + 1) % LAG, n_tile, n_tot, n_have); /* written out next iteration     */
     if (DEFER && w_have) {
+#ifndef GT4_EXP_NO_WRITEOUT
       write_out_tile<NT> (outs.rec[S0], uniform64 (sh.excl[S0]), w_tot, sh.stage[it % LAG], tid);
+#endif
     }
     /* wave 4 asks now for the words the next write-out needs (row counts and row carry of the
      * tile in the next slot, published LAG - 1 iterations ago) and resolves them in phase 2 */
@@ -672,7 +686,11 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
       if ((u32) lane < (u32) (n_tile % WAVE)) xagg = peek_u32 (&agg[(u64) S0 * n_rows * WAVE + prow * WAVE + lane]);
       xcarry = peek_u64 (&carry[(u64) S0 * (n_rows + 1) + prow]);
     }
-    if (nxt < num_tiles) fetch (tn); /* in flight until the next iteration's phase 0 */
+    /* in flight until the next iteration's phase 0; the large geometry staggers the parts */
+    if (nxt < num_tiles) {
+      if (STAGGER) fetch_part (tn, 0);
+      else fetch (tn);
+    }
 
     PHASE_STAMP (2); /* ring read, housekeeping issue, fetch issue */
     /* ---- phase 1: rank, classify, predicates.  Chunks are handled two at a time so that every
@@ -684,6 +702,7 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
       static_assert (IPT % 2 == 0, "chunks are searched in pairs");
 #pragma unroll
       for (int kk = 0; kk < IPT; kk += 2) {
+        if (STAGGER && kk == 2 && nxt < num_tiles) fetch_part (tn, 1); /* staggered fetch: see fetch_part */
         bool live[2], valid[2];
         u32 is_a[2], own[2], ob[2], lim3[2], lo3[2]; /* ob: dword base of the other list; *3: in dwords */
         u64 ky[2];
@@ -779,6 +798,10 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
      * stream's count of every record alive across phase 2 instead of recomputing it (2x the VGPRs) */
 #pragma unroll
     for (int k = 0; k < IPT; k++) asm volatile ("" : "+v"(fa[k]), "+v"(fb[k]), "+v"(meta[k]));
+    if (STAGGER && nxt < num_tiles) {
+#pragma unroll
+      for (int j = 2; j <= NLOAD4; j++) fetch_part (tn, j);
+    }
     PHASE_STAMP (3); /* phase 1 */
     __syncthreads (); /* B1: all input reads done */
     PHASE_STAMP (4); /* barrier B1 */
