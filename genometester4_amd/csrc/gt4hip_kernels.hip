@@ -459,7 +459,8 @@ struct TileRange {
 __device__ __forceinline__ u32 uniform32 (u32 v) { return __builtin_amdgcn_readfirstlane (v); }
 __device__ __forceinline__ u64 uniform64 (u64 v)
 {
-  return (u64) __builtin_amdgcn_readfirstlane ((u32) v) | ((u64) __builtin_amdgcn_readfirstlane ((u32) (v >> 32)) << 32);
+  /* the builtin returns int: go through u32 or a low word >= 2^31 sign-extends into the high half */
+  return (u64) uniform32 ((u32) v) | ((u64) uniform32 ((u32) (v >> 32)) << 32);
 }
 
 /* OPS != 0 fixes the set of output streams at compile time (the common single-output calls get a
@@ -574,7 +575,10 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
        * the B half from inside the loop above (several static writers of one register), would
        * make this wavefront wait for its loads on the spot -- a full memory round trip per tile */
       const u32 qs = cA & ~(u32) (WAVE - 1); /* first chunk of the straddling wave-instruction */
-      if ((cA & (WAVE - 1)) && (qs / WAVE) % NW == (u32) wid) pre_x = __builtin_amdgcn_raw_buffer_load_b128 (rb, 16 * (qs + (u32) lane - cA), 0, 0);
+      /* lanes that hold A chunks must read nothing: give them an offset that is out of range
+       * without wrapping (a "negative" 32-bit offset may wrap inside the range check) */
+      const u32 qx = qs + (u32) lane;
+      if ((cA & (WAVE - 1)) && (qs / WAVE) % NW == (u32) wid) pre_x = __builtin_amdgcn_raw_buffer_load_b128 (rb, qx >= cA ? 16 * (qx - cA) : 0x7ffffff0u, 0, 0);
     }
   };
   auto fetch = [&] (const TileRange &t) {

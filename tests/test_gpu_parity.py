@@ -234,3 +234,33 @@ def test_medium_generated_pair_properties(ctx):
     for bit in (1, 2, 4, 8):
         assert st[bit] == exp[bit][:2]
         assert out[bit].download().tobytes() == exp[bit][2].tobytes()
+
+
+def test_offsets_beyond_2_pow_31_records(ctx):
+    """Lists and outputs longer than 2^31 records (26 GB each): every record index, tile range and
+    output offset past the 32-bit boundary.  Checked through size-independent identities and
+    rank-addressed spot checks, since no CPU oracle finishes at this size."""
+    n = 2_200_000_000
+    a, b = ctx.alloc(n, 25), ctx.alloc(n, 25)
+    ctx.generate_ex(a, n, 7, 50, 8, 16, 1)
+    ctx.generate_ex(b, n, 7, 50, 8, 16, 1)          # B == A
+    sa = a.sum_counts()
+    st, out, _ = ctx.compare(a, b, 3)
+    assert st[1] == (n, 2 * sa) and st[2] == (n, sa)
+    assert out[1].is_sorted() and out[2].is_sorted()
+    for i in (0, (1 << 31) - 1, 1 << 31, (1 << 31) + 4093, n - 1):
+        k, c = a.get_word(i)
+        assert out[2].get_word(i) == (k, c) and out[1].get_word(i) == (k, 2 * c)
+    del out
+    m = 300_000_000
+    b = ctx.alloc(m, 25)
+    ctx.generate_ex(b, m, 8, 51, 8, 16, 2)           # disjoint residue class: A n B is empty
+    st, out, _ = ctx.compare(a, b, 1 | 2 | 8)
+    assert st[2][0] == 0 and st[8] == (m, b.sum_counts())
+    assert st[1] == (n + m, sa + b.sum_counts()) and out[1].is_sorted()
+    for i in (1 << 30, (1 << 31) - 7, (1 << 31) + 12345, n - 1):
+        k, c = a.get_word(i)
+        assert out[1].get_word(i + b.lower_bound(k)) == (k, c)
+    for j in (0, m // 2, m - 1):
+        k, c = b.get_word(j)
+        assert out[1].get_word(j + a.lower_bound(k)) == (k, c)
