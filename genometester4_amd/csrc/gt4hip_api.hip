@@ -25,7 +25,7 @@ struct gt4hip_context {
   int n_cus;
   int two_pass;
   int64_t grid_override;
-  int force_geom; /* option "geom1": count-only calls use the large geometry too (experiments) */
+  int force_geom; /* options "geom1" / "geom0": force the large / small geometry for every call (experiments); 0 = automatic */
   uint64_t single_pass_fallbacks; /* calls that had to be rerun on the two-pass path */
   /* freed list storage kept for reuse: hipMalloc / hipFree of tens of GB cost far more than the
    * merges themselves (an 8-way union tree allocates seven outputs per call) */
@@ -180,7 +180,8 @@ extern "C" int gt4hip_set_option (gt4hip_context *ctx, const char *name, int64_t
     }
   }
   else if (!strcmp (name, "grid")) ctx->grid_override = value;
-  else if (!strcmp (name, "geom1")) ctx->force_geom = value != 0;
+  else if (!strcmp (name, "geom1")) ctx->force_geom = value != 0 ? 1 : 0;
+  else if (!strcmp (name, "geom0")) ctx->force_geom = value != 0 ? -1 : 0;
   else return fail (ctx, GT4HIP_EINVAL, "unknown option %s", name);
   return GT4HIP_OK;
 }
@@ -461,7 +462,7 @@ static int run_pair (gt4hip_context *ctx, const uint32_t *A, uint64_t nA, const 
   const uint64_t total = nA + nB;
   if (!total || !p.ops) return GT4HIP_OK;
   /* count-only calls: 512-thread workgroups; everything that materialises records: 1024 */
-  const int geom = (count_only && !ctx->force_geom) ? 0 : 1;
+  const int geom = ctx->force_geom ? (ctx->force_geom > 0 ? 1 : 0) : (count_only ? 0 : 1);
   const uint64_t tile_records = merge_tile_records (geom);
   const uint64_t tiles = (total + tile_records - 1) / tile_records;
   run->tiles = tiles;

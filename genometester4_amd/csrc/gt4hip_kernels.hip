@@ -592,9 +592,12 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
   u64 t_last;
   asm volatile ("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_last) :: "memory");
 #endif
-  /* DEFER: the two tiles whose output is staged in LDS but not yet written (slot = iteration parity) */
+  /* DEFER: the LAG tiles whose output is staged in LDS but not yet written.  A queue shifted once per
+   * iteration with static indices only (entry 0 = oldest = staged LAG iterations ago, in slot
+   * it % LAG); indexing it by it % LAG instead turns the arrays into scratch memory, which cost a
+   * second copy of the output in HBM traffic. */
   constexpr int LAG = RankShared<NT, IPT, OPS>::STAGE_SLOTS;
-  u64 pend_tile[LAG]; /* per staging slot: the tile staged there (wave-uniform) */
+  u64 pend_tile[LAG];
   u32 pend_tot[LAG];
   bool pend_have[LAG];
 #pragma unroll
@@ -603,19 +606,6 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
     pend_tot[q] = 0;
     pend_have[q] = false;
   }
-  /* static-index accessor (the arrays must stay in registers) */
-  auto pend_get = [&] (int slot, u64 &tile, u32 &tot, bool &have) {
-    tile = pend_tile[0];
-    tot = pend_tot[0];
-    have = pend_have[0];
-#pragma unroll
-    for (int q = 1; q < LAG; q++)
-      if (slot == q) {
-        tile = pend_tile[q];
-        tot = pend_tot[q];
-        have = pend_have[q];
-      }
-  };
   int it = 0;
 
   while (cur < num_tiles) {
@@ -674,8 +664,8 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
     u64 w_tile, n_tile;
     u32 w_tot, n_tot;
     bool w_have, n_have;
-    pend_get (it % LAG, w_tile, w_tot, w_have);       /* written out now                */
-    pend_get ((it + 1) % LAG, n_tile, n_tot, n_have); /* written out next iteration     */
+    w_tile = pend_tile[0], w_tot = pend_tot[0], w_have = pend_have[0];                            /* written out now            */
+    n_tile = pend_tile[1 % LAG], n_tot = pend_tot[1 % LAG], n_have = LAG > 1 && pend_have[1 % LAG]; /* written out next iteration */
     if (DEFER && w_have) {
 #ifndef GT4_EXP_NO_WRITEOUT
       write_out_tile<NT> (outs.rec[S0], uniform64 (sh.excl[S0]), w_tot, sh.stage[it % LAG], tid);
@@ -864,12 +854,14 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
         if (S0 == 0) scatter_stream<0, NT, IPT, OPS> (sh, slot, p, na, lane, wid, key, fa, fb, meta);
         else scatter_stream<1, NT, IPT, OPS> (sh, slot, p, na, lane, wid, key, fa, fb, meta);
 #pragma unroll
-        for (int q = 0; q < LAG; q++)
-          if (it % LAG == q) {
-            pend_tile[q] = cur;
-            pend_tot[q] = my_tot;
-            pend_have[q] = true;
-          }
+        for (int q = 0; q + 1 < LAG; q++) {
+          pend_tile[q] = pend_tile[q + 1];
+          pend_tot[q] = pend_tot[q + 1];
+          pend_have[q] = pend_have[q + 1];
+        }
+        pend_tile[LAG - 1] = cur;
+        pend_tot[LAG - 1] = my_tot;
+        pend_have[LAG - 1] = true;
         if (n_have && wid == 4) {
           /* global offset of the tile the next iteration writes out (this iteration's write-out,
            * which read sh.excl, finished before B1) */
@@ -918,11 +910,9 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
     /* drain: the tiles still staged, oldest first */
 #pragma unroll
     for (int q = 0; q < LAG; q++) {
-      u64 tile;
-      u32 tot;
-      bool have;
-      pend_get ((it + q) % LAG, tile, tot, have);
-      if (!have) continue;
+      const u64 tile = pend_tile[q];
+      const u32 tot = pend_tot[q];
+      if (!pend_have[q]) continue;
       __syncthreads ();
       if (wid == 0) {
         u64 x;

@@ -1,0 +1,85 @@
+"""Summarises a tools/collect_profiles.sh output directory into small CSV/JSON files.
+
+    python3 tools/summarize_profiles.py gpurun_out/prof_<tag> <tag>
+
+Writes next to the raw data (directory `summary/`): <tag>_bench.json, <tag>_kernel_stats.csv,
+<tag>_pmc_fetch_size.csv, <tag>_pmc_write_size.csv and traffic_latest.json.  FETCH_SIZE / WRITE_SIZE
+are in KiB; FETCH_SIZE is doubled on gfx950 as /opt/skills/guides/MI355X_MICROARCH.md (HBM section)
+prescribes."""
+import csv, glob, json, os, sys
+
+src, tag = sys.argv[1], sys.argv[2]
+dst = os.path.join(src, "summary")
+os.makedirs(dst, exist_ok=True)
+
+
+def find(sub, suffix):
+    hits = glob.glob(os.path.join(src, sub, "**", "*" + suffix), recursive=True)
+    return hits[0] if hits else None
+
+
+bench = None
+try:
+    with open(os.path.join(src, "bench.json")) as f:
+        for line in f:
+            if line.startswith("{"):
+                bench = json.loads(line)
+    with open(os.path.join(dst, tag + "_bench.json"), "w") as f:
+        json.dump(bench, f, indent=1)
+except Exception as e:  # noqa
+    print("no bench line:", e)
+
+p = find("stats", "_kernel_stats.csv")
+if p:
+    with open(p) as f, open(os.path.join(dst, tag + "_kernel_stats.csv"), "w") as g:
+        g.write(f.read())
+    print("kernel stats:", p)
+
+
+def pmc(sub, counter):
+    p = find(sub, "_counter_collection.csv")
+    if not p:
+        print("no counter file for", counter)
+        return None, None
+    per = {}
+    with open(p) as f:
+        for row in csv.DictReader(f):
+            if row.get("Counter_Name") != counter:
+                continue
+            name = row["Kernel_Name"]
+            short = name.replace("(anonymous namespace)::", "").replace("void ", "").replace("gt4::", "").split("(")[0]
+            per.setdefault(short, {}).setdefault(row.get("Dispatch_Id"), 0.0)
+            per[short][row.get("Dispatch_Id")] += float(row["Counter_Value"])
+    out = os.path.join(dst, "%s_pmc_%s.csv" % (tag, counter.lower()))
+    with open(out, "w") as g:
+        g.write("kernel,counter,per_launch_values_KiB\n")
+        for k, d in sorted(per.items()):
+            g.write("%s,%s,%s\n" % (k.replace(",", ";"), counter, " ".join("%.1f" % v for v in d.values())))
+    return per, out
+
+
+fetch, fpath = pmc("fetch", "FETCH_SIZE")
+write, wpath = pmc("write", "WRITE_SIZE")
+if fetch and write:
+    # dominant kernel = the k_pair_merge instantiation with the most fetched bytes in total
+    cand = [k for k in fetch if k.startswith("k_pair_merge")]
+    dom = max(cand, key=lambda k: sum(fetch[k].values()))
+    fv = list(fetch[dom].values())
+    wv = list(write.get(dom, {}).values())
+    fb = 2.0 * 1024.0 * sum(fv) / len(fv)
+    wb = 1024.0 * sum(wv) / len(wv) if wv else 0.0
+    tj = {
+        "n_per_list": (bench or {}).get("config", {}).get("entries_per_list_per_gpu"),
+        "kernel": dom,
+        "hbm_bytes_per_launch": fb + wb,
+        "fetch_bytes_corrected": fb,
+        "write_bytes": wb,
+        "launches_averaged": [len(fv), len(wv)],
+        "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python3 bench.py "
+                  "--steps 2 --warmup 1 --no-cpu-baseline`; KiB units; FETCH_SIZE doubled per the gfx950 "
+                  "correction of MI355X_MICROARCH.md (HBM section); WRITE_SIZE as is",
+        "source": ["profiles/round1/" + os.path.basename(fpath), "profiles/round1/" + os.path.basename(wpath)],
+    }
+    with open(os.path.join(dst, "traffic_latest.json"), "w") as f:
+        json.dump(tj, f, indent=1)
+    print(json.dumps(tj))
