@@ -411,12 +411,12 @@ __device__ __forceinline__ u32 kept_before (const u64 *km, const u32 *cp, u32 z)
 }
 
 template <int S, int NT, int IPT, int OPS>
-__device__ __forceinline__ void scatter_stream (RankShared<NT, IPT, OPS> &sh, u32 *dst32, const PairParams &p, u32 na, int lane, int wid,
+__device__ __forceinline__ void scatter_stream (RankShared<NT, IPT, OPS> &sh, u32 *dst32, const PairParams &p, u32 nbs, int lane, int wid,
                                                 const u64 (&key)[IPT], const u32 (&fa)[IPT], const u32 (&fb)[IPT], const u32 (&meta)[IPT])
 {
   constexpr int NW = NT / WAVE;
   const StreamCoef c = make_coef<S> (p);
-  const u32 pna = kept_before (sh.kmask[S], sh.cpre[S], na);
+  const u32 pna = kept_before (sh.kmask[S], sh.cpre[S], nbs); /* nbs: tile position of the first B record */
 #pragma unroll
   for (int k = 0; k < IPT; k++) {
     const u32 chunk = (u32) k * NW + (u32) wid;
@@ -424,7 +424,7 @@ __device__ __forceinline__ void scatter_stream (RankShared<NT, IPT, OPS> &sh, u3
     if ((m >> lane) & 1ull) {
       const u32 own = sh.cpre[S][chunk] + (u32) __popcll (m & ((1ull << lane) - 1ull));
       const u32 r = meta[k] & 0xffffu;
-      const u32 z = ((meta[k] >> 18) & 1u) ? na + r : r;
+      const u32 z = ((meta[k] >> 18) & 1u) ? nbs + r : r;
       const u32 slot = own + kept_before (sh.kmask[S], sh.cpre[S], z) - pna;
       u32 f;
       eval_stream<S> ((meta[k] >> 16) & 3u, fa[k], fb[k], c, f);
@@ -433,6 +433,51 @@ __device__ __forceinline__ void scatter_stream (RankShared<NT, IPT, OPS> &sh, u3
       dst32[3 * slot + 2] = f;
     }
   }
+}
+
+/* Ranks of two keys, each in its own sorted run of packed records in LDS (lower bound: the number
+ * of records with a smaller key), as byte offsets 12 * rank into the run.  The runs' starts and
+ * lengths are wave-uniform, which makes the whole search plan scalar: with P = 2^bitlen(n) > n,
+ * the first probe is record n - P/2 and leaves a window of exactly P/2 - 1 records on either side,
+ * then every probe is the middle of a window of 2h - 1 records (h = P/4 ... 1).  bitlen(n) probes
+ * in all, every one of them inside the run -- no bounds test -- and for h <= 64 the probe's offset
+ * from the running position fits the LDS instruction's offset field: compare, select, add per
+ * step.  Steps a short run does not need add 0 (their probes read this workgroup's LDS beyond
+ * the run, and the value is ignored).  The two searches are interleaved for two LDS reads in flight. */
+template <int CAP>
+__device__ __forceinline__ void rank_pair (const u32 *lds32, const u32 (&sbase)[2], const u32 (&sn)[2], const u64 (&ky)[2], u32 (&lo)[2])
+{
+  auto key_at = [&] (u32 byte_off) -> u64 {
+    const u32 *const q = reinterpret_cast<const u32 *> (reinterpret_cast<const char *> (lds32) + byte_off);
+    return (u64) q[0] | ((u64) q[1] << 32);
+  };
+  u32 q4[2], at[2];
+#pragma unroll
+  for (int u = 0; u < 2; u++) {
+    const u32 n = sn[u];
+    const u32 half = n ? 1u << (31 - __builtin_clz (n)) : 0u; /* P/2 = the largest power of two <= n */
+    q4[u] = half >> 1;
+    const u32 i0 = n - half;
+    const u32 inc = n ? 12u * (i0 + 1u) : 0u;
+    const u64 pv = key_at (4u * sbase[u] + 12u * i0);
+    at[u] = 4u * sbase[u] + (pv < ky[u] ? inc : 0u);
+  }
+#pragma unroll
+  for (u32 h = CAP / 4; h >= 1; h >>= 1) {
+    if (h > 64 && h > q4[0] && h > q4[1]) continue; /* wave-uniform */
+    u64 pv[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) pv[u] = key_at (at[u] + 12u * (h - 1u));
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const u32 hs = h <= q4[u] ? 12u * h : 0u; /* scalar */
+      u32 cand = at[u] + hs;                   /* independent of the probe: issued under its latency */
+      asm volatile ("" : "+v"(cand));          /* keep add + select (the folded form needs a move of hs per step) */
+      at[u] = pv[u] < ky[u] ? cand : at[u];
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 2; u++) lo[u] = at[u] - 4u * sbase[u];
 }
 
 /* Tile write-out: `tot` packed records from an LDS staging slot (16-byte aligned) to the output
@@ -609,8 +654,10 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
   int it = 0;
 
   while (cur < num_tiles) {
-    const u32 na = tr.na, nb = tr.nb, nt = na + nb;
-    if (nt > (u32) CAP) {
+    /* position space of the tile: A records at [0, na), B records from the next multiple of 64 on, so
+     * that every 64-position chunk (one wavefront pass) holds records of one list only */
+    const u32 na = tr.na, nb = tr.nb, nbs = (na + (u32) WAVE - 1u) & ~((u32) WAVE - 1u), npos = nbs + nb;
+    if (npos > (u32) CAP) {
       if (tid == 0) atomicOr (&ctl->error, 2u);
       break;
     }
@@ -698,50 +745,32 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
       for (int kk = 0; kk < IPT; kk += 2) {
         if (STAGGER && kk == 2 && nxt < num_tiles) fetch_part (tn, 1); /* staggered fetch: see fetch_part */
         bool live[2], valid[2];
-        u32 is_a[2], own[2], ob[2], lim3[2], lo3[2]; /* ob: dword base of the other list; *3: in dwords */
+        u32 is_a[2], own[2], lim[2], lo[2]; /* is_a: wave-uniform (chunks never mix the lists); lim, lo: bytes (12 per record) */
+        u32 sbase[2], sn[2];                /* wave-uniform: dword base and length of the run this chunk is ranked in */
         u64 ky[2];
 #pragma unroll
         for (int u = 0; u < 2; u++) {
           const u32 e = (u32) (kk + u) * NT + (u32) tid;
           const u32 cbeg = ((u32) (kk + u) * NW + (u32) wid) * WAVE; /* wave-uniform */
-          live[u] = cbeg < nt && (need_b || cbeg < na);
-          valid[u] = live[u] && e < nt;
-          const u32 ec = valid[u] ? e : 0u;
-          is_a[u] = ec < na ? 1u : 0u;
-          const u32 at = is_a[u] ? 3 * ec : OB + 3 * (ec - na);
+          is_a[u] = cbeg < nbs ? 1u : 0u;
+          live[u] = is_a[u] ? cbeg < na : (need_b && cbeg < npos);
+          valid[u] = live[u] && (is_a[u] ? e < na : e < npos);
+          const u32 at = valid[u] ? (is_a[u] ? 3 * e : OB + 3 * (e - nbs)) : 0u;
           ky[u] = (u64) lds32[at] | ((u64) lds32[at + 1] << 32);
           own[u] = lds32[at + 2];
-          ob[u] = is_a[u] ? OB : 0u;
-          lim3[u] = valid[u] ? 3 * (is_a[u] ? nb : na) : 0u;
-          lo3[u] = 0;
+          sbase[u] = is_a[u] ? OB : 0u;
+          sn[u] = is_a[u] ? nb : na;
+          lim[u] = valid[u] ? 12 * sn[u] : 0u;
+          lo[u] = 0;
         }
-        if (live[0] || live[1]) {
-          /* lower bound of ky in the other list: greedy bit-by-bit search with a fixed step
-           * sequence -- wave-uniform control, no per-step branching, LDS offsets folded into the
-           * instruction.  A probe beyond the list reads in-bounds garbage of this workgroup's LDS
-           * and is masked out. */
-#pragma unroll
-          for (u32 step = CAP / 2; step >= 1; step >>= 1) {
-            u64 pv[2];
-#pragma unroll
-            for (int u = 0; u < 2; u++) {
-              const u32 *const pr = lds32 + ob[u] + lo3[u] + 3 * (step - 1);
-              pv[u] = (u64) pr[0] | ((u64) pr[1] << 32);
-            }
-#pragma unroll
-            for (int u = 0; u < 2; u++) {
-              const bool lt = (lo3[u] + 3 * (step - 1) < lim3[u]) & (pv[u] < ky[u]);
-              lo3[u] += lt ? 3 * step : 0u;
-            }
-          }
-        }
+        if (live[0] || live[1]) rank_pair<CAP> (lds32, sbase, sn, ky, lo);
 #pragma unroll
         for (int u = 0; u < 2; u++) {
           const int k = kk + u;
           const u32 chunk = (u32) k * NW + (u32) wid;
-          const u32 r = (lo3[u] * 43691u) >> 17; /* lo3 / 3, exact for multiples of 3 below 2^16 */
-          const bool in = lo3[u] < lim3[u];
-          const u32 oat = ob[u] + (in ? lo3[u] : 0u);
+          const u32 r = (lo[u] * 43691u) >> 19; /* lo / 12, exact for multiples of 12 below 2^16 */
+          const bool in = lo[u] < lim[u];
+          const u32 oat = sbase[u] + (in ? lo[u] >> 2 : 0u);
           const u64 okey = (u64) lds32[oat] | ((u64) lds32[oat + 1] << 32);
           const u32 ocnt = lds32[oat + 2];
           const bool matched = in & (okey == ky[u]);
@@ -851,8 +880,8 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
         /* stage this tile in the slot the write-out at the top of this iteration freed */
         u32 *const slot = sh.stage[it % LAG];
         const u32 my_tot = my_total;
-        if (S0 == 0) scatter_stream<0, NT, IPT, OPS> (sh, slot, p, na, lane, wid, key, fa, fb, meta);
-        else scatter_stream<1, NT, IPT, OPS> (sh, slot, p, na, lane, wid, key, fa, fb, meta);
+        if (S0 == 0) scatter_stream<0, NT, IPT, OPS> (sh, slot, p, nbs, lane, wid, key, fa, fb, meta);
+        else scatter_stream<1, NT, IPT, OPS> (sh, slot, p, nbs, lane, wid, key, fa, fb, meta);
 #pragma unroll
         for (int q = 0; q + 1 < LAG; q++) {
           pend_tile[q] = pend_tile[q + 1];
@@ -875,10 +904,10 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
         for (int s = 0; s < 4; s++) {
           if (!((ops >> s) & 1u)) continue;
           switch (s) {
-            case 0: scatter_stream<0, NT, IPT, OPS> (sh, lds32, p, na, lane, wid, key, fa, fb, meta); break;
-            case 1: scatter_stream<1, NT, IPT, OPS> (sh, lds32, p, na, lane, wid, key, fa, fb, meta); break;
-            case 2: scatter_stream<2, NT, IPT, OPS> (sh, lds32, p, na, lane, wid, key, fa, fb, meta); break;
-            default: scatter_stream<3, NT, IPT, OPS> (sh, lds32, p, na, lane, wid, key, fa, fb, meta); break;
+            case 0: scatter_stream<0, NT, IPT, OPS> (sh, lds32, p, nbs, lane, wid, key, fa, fb, meta); break;
+            case 1: scatter_stream<1, NT, IPT, OPS> (sh, lds32, p, nbs, lane, wid, key, fa, fb, meta); break;
+            case 2: scatter_stream<2, NT, IPT, OPS> (sh, lds32, p, nbs, lane, wid, key, fa, fb, meta); break;
+            default: scatter_stream<3, NT, IPT, OPS> (sh, lds32, p, nbs, lane, wid, key, fa, fb, meta); break;
           }
           __syncthreads ();
           u32 *__restrict__ dst = outs.rec[s] + 3 * sh.excl[s];
@@ -1110,12 +1139,10 @@ static hipError_t launch_pair_merge_ops (hipStream_t s, int mode, int grid, cons
 {
   if (mode == MODE_COUNT)
     hipLaunchKernelGGL ((k_pair_merge<NT, MERGE_VT, MODE_COUNT, OPS>), dim3 (grid), dim3 (NT), 0, s, A, nA, B, nB, (u64 *) part, num_tiles, p, o, desc, ctl);
-  else if (NT == 1024 && mode == MODE_LOOKBACK)
-    hipLaunchKernelGGL ((k_pair_merge<1024, MERGE_VT, MODE_LOOKBACK, OPS>), dim3 (grid), dim3 (1024), 0, s, A, nA, B, nB, (u64 *) part, num_tiles, p, o, desc, ctl);
-  else if (NT == 1024)
-    hipLaunchKernelGGL ((k_pair_merge<1024, MERGE_VT, MODE_OFFSETS, OPS>), dim3 (grid), dim3 (1024), 0, s, A, nA, B, nB, (u64 *) part, num_tiles, p, o, desc, ctl);
+  else if (mode == MODE_LOOKBACK)
+    hipLaunchKernelGGL ((k_pair_merge<NT, MERGE_VT, MODE_LOOKBACK, OPS>), dim3 (grid), dim3 (NT), 0, s, A, nA, B, nB, (u64 *) part, num_tiles, p, o, desc, ctl);
   else
-    return hipErrorInvalidValue; /* the small geometry only counts */
+    hipLaunchKernelGGL ((k_pair_merge<NT, MERGE_VT, MODE_OFFSETS, OPS>), dim3 (grid), dim3 (NT), 0, s, A, nA, B, nB, (u64 *) part, num_tiles, p, o, desc, ctl);
   return hipGetLastError ();
 }
 
@@ -1125,8 +1152,8 @@ static int blocks_per_cu_ops (int mode)
   int n = 0;
   hipError_t e;
   if (mode == MODE_COUNT) e = hipOccupancyMaxActiveBlocksPerMultiprocessor (&n, k_pair_merge<NT, MERGE_VT, MODE_COUNT, OPS>, NT, 0);
-  else if (mode == MODE_LOOKBACK) e = hipOccupancyMaxActiveBlocksPerMultiprocessor (&n, k_pair_merge<1024, MERGE_VT, MODE_LOOKBACK, OPS>, 1024, 0);
-  else e = hipOccupancyMaxActiveBlocksPerMultiprocessor (&n, k_pair_merge<1024, MERGE_VT, MODE_OFFSETS, OPS>, 1024, 0);
+  else if (mode == MODE_LOOKBACK) e = hipOccupancyMaxActiveBlocksPerMultiprocessor (&n, k_pair_merge<NT, MERGE_VT, MODE_LOOKBACK, OPS>, NT, 0);
+  else e = hipOccupancyMaxActiveBlocksPerMultiprocessor (&n, k_pair_merge<NT, MERGE_VT, MODE_OFFSETS, OPS>, NT, 0);
   if (e != hipSuccess || n < 1) n = 1;
   /* never more than the register file admits for the declared launch bounds */
   const int by_regs = (OPS ? GeomWaves<NT>::single : GeomWaves<NT>::generic) * 4 / (NT / 64);
@@ -1134,7 +1161,7 @@ static int blocks_per_cu_ops (int mode)
   return n;
 }
 
-uint64_t merge_tile_records (int geom) { return (uint64_t) (geom ? 1024 : 512) * MERGE_VT - 3; }
+uint64_t merge_tile_records (int geom) { return (uint64_t) (geom ? 1024 : 512) * MERGE_VT - MERGE_TILE_SLACK; }
 
 /* workgroups of the merge kernel that are resident per CU (the single-pass path needs every
  * worker resident: see k_pair_merge) */

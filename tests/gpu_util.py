@@ -8,8 +8,8 @@ from genometester4_amd.listio import make_records
 MERGE_TILE = None  # filled lazily from the header the kernels were built with
 
 
-def merge_tile():
-    """Nominal merge tile size (MERGE_NT * MERGE_VT - 1) parsed from the kernel header."""
+def merge_tile(geom=0):
+    """Nominal merge tile size (512 * MERGE_VT - MERGE_TILE_SLACK) parsed from the kernel header."""
     global MERGE_TILE
     if MERGE_TILE is None:
         import os
@@ -17,8 +17,9 @@ def merge_tile():
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         txt = open(os.path.join(root, "genometester4_amd", "csrc", "gt4hip_internal.h")).read()
         vt = int(re.search(r"MERGE_VT\s*=\s*(\d+)", txt).group(1))
-        MERGE_TILE = 512 * vt - 3  # the small geometry; sizes around it and its double are exercised
-    return MERGE_TILE
+        slack = int(re.search(r"MERGE_TILE_SLACK\s*=\s*(\d+)", txt).group(1))
+        MERGE_TILE = 512 * vt - slack  # the small geometry; sizes around it and its double are exercised
+    return MERGE_TILE if geom == 0 else 2 * MERGE_TILE + (2 * 512 * 4 - 2 * MERGE_TILE) // 2
 
 
 def random_pair(seed, n_universe, p_a, p_b, k=16, max_count=8, special=True):

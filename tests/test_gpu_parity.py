@@ -104,7 +104,7 @@ def test_tile_boundary_sizes(ctx):
     """Sizes straddling the merge tile; identical lists put a matched pair on every boundary."""
     T = U.merge_tile()
     rng = np.random.default_rng(5)
-    T2 = 2 * T + 3  # the large geometry's tile (1024 threads x 4 records - 3)
+    T2 = U.merge_tile(1)  # the large geometry's tile (1024 threads x 4 records - slack)
     for n in (1, 2, T // 2 - 1, T // 2, T // 2 + 1, T - 1, T, T + 1, 2 * T, 3 * T + 1, 10 * T - 1,
               T2 // 2, T2 // 2 + 1, T2 - 1, T2, T2 + 1, 3 * T2 + 1):
         keys = np.unique(rng.integers(0, 1 << 40, size=n, dtype=np.uint64))

@@ -9,12 +9,17 @@ from bench import build_lists
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 500_000_000
 ctx = capi.Context(0)
+for opt in ("geom0", "geom1", "grid"):
+    if os.environ.get("GT4_" + opt.upper()):
+        ctx.set_option(opt, int(os.environ["GT4_" + opt.upper()]))
 a, b = build_lists(ctx, capi, n, 25, 0)
 out_i = ctx.alloc(n, 25)
 out_u = ctx.alloc(2 * n, 25)
 
 
 def run(tag, ops, out=None, count_only=False, two_pass=0, reps=3):
+    if two_pass and os.environ.get("GT4_SKIP_TWO_PASS"):
+        return
     ctx.set_option("two_pass", two_pass)
     ms = []
     for _ in range(reps):

@@ -10,6 +10,9 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 500_000_000
 ops = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 count_only = len(sys.argv) > 3 and sys.argv[3] == "count"
 ctx = capi.Context(0)
+for opt in ("geom0", "geom1", "grid", "two_pass"):
+    if os.environ.get("GT4_" + opt.upper()):
+        ctx.set_option(opt, int(os.environ["GT4_" + opt.upper()]))
 a, b = build_lists(ctx, capi, n, 25, 0)
 out = None if count_only else {ops: ctx.alloc(2 * n if ops == 1 else n, 25)}
 for _ in range(3):
