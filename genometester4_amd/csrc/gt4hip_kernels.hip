@@ -603,8 +603,13 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
    * up in front of the CU's one address unit. */
   auto fetch_part = [&] (const TileRange &t, int j) {
     const u32 da = 3 * t.na, db = 3 * t.nb, cA = (da + 3) >> 2;
+#ifdef GT4_EXP_SAME_TILE /* timing experiment: every fetch hits the same (cached) addresses; results are wrong */
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc ((void *) (A + 3 * (t.a0 & 0xfffff)), 0, (int) (4 * da), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc ((void *) (B + 3 * (t.b0 & 0xfffff)), 0, (int) (4 * db), 0x00020000);
+#else
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc ((void *) (A + 3 * t.a0), 0, (int) (4 * da), 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc ((void *) (B + 3 * t.b0), 0, (int) (4 * db), 0x00020000);
+#endif
 #pragma unroll
     for (int jj = 0; jj < NLOAD4; jj++) {
       if (jj != j) continue;
@@ -750,10 +755,31 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
         u64 ky[2];
 #pragma unroll
         for (int u = 0; u < 2; u++) {
-          const u32 e = (u32) (kk + u) * NT + (u32) tid;
           const u32 cbeg = ((u32) (kk + u) * NW + (u32) wid) * WAVE; /* wave-uniform */
           is_a[u] = cbeg < nbs ? 1u : 0u;
           live[u] = is_a[u] ? cbeg < na : (need_b && cbeg < npos);
+        }
+        if (!live[0] && !live[1]) {
+          /* nothing in these two chunks can be kept (padding, or B records of a call that keeps none
+           * of them on their own: pairs are found from the A side): empty keep masks, no other work */
+#pragma unroll
+          for (int u = 0; u < 2; u++) {
+            const int k = kk + u;
+            key[k] = 0;
+            fa[k] = fb[k] = 0;
+            meta[k] = KIND_SKIP << 16;
+            if (lane == 0) {
+              const u32 chunk = (u32) k * NW + (u32) wid;
+#pragma unroll
+              for (int s = 0; s < 4; s++)
+                if ((ops >> s) & 1u) sh.kmask[s][chunk] = 0;
+            }
+          }
+          continue;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+          const u32 e = (u32) (kk + u) * NT + (u32) tid;
           valid[u] = live[u] && (is_a[u] ? e < na : e < npos);
           const u32 at = valid[u] ? (is_a[u] ? 3 * e : OB + 3 * (e - nbs)) : 0u;
           ky[u] = (u64) lds32[at] | ((u64) lds32[at + 1] << 32);
