@@ -416,16 +416,19 @@ __device__ __forceinline__ void scatter_stream (RankShared<NT, IPT, OPS> &sh, u3
 {
   constexpr int NW = NT / WAVE;
   const StreamCoef c = make_coef<S> (p);
-  const u32 pna = kept_before (sh.kmask[S], sh.cpre[S], nbs); /* nbs: tile position of the first B record */
+  const u32 pna = (OPS == 2 && S == 1) ? 0u : kept_before (sh.kmask[S], sh.cpre[S], nbs); /* nbs: tile position of the first B record */
 #pragma unroll
   for (int k = 0; k < IPT; k++) {
     const u32 chunk = (u32) k * NW + (u32) wid;
     const u64 m = sh.kmask[S][chunk];
     if ((m >> lane) & 1ull) {
       const u32 own = sh.cpre[S][chunk] + (u32) __popcll (m & ((1ull << lane) - 1ull));
-      const u32 r = meta[k] & 0xffffu;
-      const u32 z = ((meta[k] >> 18) & 1u) ? nbs + r : r;
-      const u32 slot = own + kept_before (sh.kmask[S], sh.cpre[S], z) - pna;
+      u32 slot = own;
+      if (!(OPS == 2 && S == 1)) { /* an intersection keeps A records only: nothing of the other list comes before */
+        const u32 r = meta[k] & 0xffffu;
+        const u32 z = ((meta[k] >> 18) & 1u) ? nbs + r : r;
+        slot += kept_before (sh.kmask[S], sh.cpre[S], z) - pna;
+      }
       u32 f;
       eval_stream<S> ((meta[k] >> 16) & 3u, fa[k], fb[k], c, f);
       dst32[3 * slot] = (u32) key[k];
@@ -463,8 +466,8 @@ __device__ __forceinline__ void rank_pair (const u32 *lds32, const u32 (&sbase)[
     at[u] = 4u * sbase[u] + (pv < ky[u] ? inc : 0u);
   }
 #pragma unroll
-  for (u32 h = CAP / 4; h >= 1; h >>= 1) {
-    if (h > 64 && h > q4[0] && h > q4[1]) continue; /* wave-uniform */
+  for (u32 h = CAP / 4; h > 64; h >>= 1) {
+    if (h > q4[0] && h > q4[1]) continue; /* wave-uniform */
     u64 pv[2];
 #pragma unroll
     for (int u = 0; u < 2; u++) pv[u] = key_at (at[u] + 12u * (h - 1u));
@@ -474,6 +477,34 @@ __device__ __forceinline__ void rank_pair (const u32 *lds32, const u32 (&sbase)[
       u32 cand = at[u] + hs;                   /* independent of the probe: issued under its latency */
       asm volatile ("" : "+v"(cand));          /* keep add + select (the folded form needs a move of hs per step) */
       at[u] = pv[u] < ky[u] ? cand : at[u];
+    }
+  }
+  if (q4[0] >= 64 && q4[1] >= 64) { /* both runs hold >= 256 records (the usual tile): every remaining step is live */
+#pragma unroll
+    for (u32 h = 64; h >= 1; h >>= 1) {
+      u64 pv[2];
+#pragma unroll
+      for (int u = 0; u < 2; u++) pv[u] = key_at (at[u] + 12u * (h - 1u));
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        u32 cand = at[u] + 12u * h;
+        asm volatile ("" : "+v"(cand));
+        at[u] = pv[u] < ky[u] ? cand : at[u];
+      }
+    }
+  } else {
+#pragma unroll
+    for (u32 h = 64; h >= 1; h >>= 1) {
+      u64 pv[2];
+#pragma unroll
+      for (int u = 0; u < 2; u++) pv[u] = key_at (at[u] + 12u * (h - 1u));
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const u32 hs = h <= q4[u] ? 12u * h : 0u;
+        u32 cand = at[u] + hs;
+        asm volatile ("" : "+v"(cand));
+        at[u] = pv[u] < ky[u] ? cand : at[u];
+      }
     }
   }
 #pragma unroll
