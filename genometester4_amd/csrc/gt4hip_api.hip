@@ -465,6 +465,7 @@ static int run_pair (gt4hip_context *ctx, const uint32_t *A, uint64_t nA, const 
   const int geom = ctx->force_geom ? (ctx->force_geom > 0 ? 1 : 0) : (count_only ? 0 : 1);
   const uint64_t tile_records = merge_tile_records (geom);
   const uint64_t tiles = (total + tile_records - 1) / tile_records;
+  if (tiles >= 0xffffffffull) return fail (ctx, GT4HIP_EINVAL, "lists too long: %llu merge tiles", (unsigned long long) tiles);
   run->tiles = tiles;
   int rc;
   if ((rc = grow (ctx, (void **) &ctx->part, &ctx->part_bytes, (size_t) (tiles + 1) * 16 + (size_t) (tiles / 64 + 3) * 8))) return rc; /* tile ranges + coarse co-ranks */

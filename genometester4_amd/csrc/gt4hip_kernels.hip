@@ -599,6 +599,7 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
   const u32 n_workers = MODE == MODE_LOOKBACK ? gridDim.x - 1 : gridDim.x;
   const u32 wk = MODE == MODE_LOOKBACK ? role - 1 : blockIdx.x;
   u32 n_claimed = 0; /* thread 0 */
+  const u32 ntl = (u32) num_tiles; /* the host refuses calls with 2^32 - 1 tiles or more */
   auto claim = [&] () -> u32 {
     const u64 t = (u64) wk + (u64) (n_claimed++) * n_workers;
     return t < num_tiles ? (u32) t : 0xffffffffu;
@@ -607,14 +608,14 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
     for (int q = 0; q < 3; q++) {
       const u32 t = claim ();
       sh.tick[q] = t;
-      if (q < 2 && t < num_tiles)
+      if (q < 2 && t < ntl)
         for (int i = 0; i < 4; i++) sh.rng[q][i] = part[2 * (u64) t + i];
     }
   }
   __syncthreads ();
-  u64 cur = uniform32 (sh.tick[0]);
+  u32 cur = uniform32 (sh.tick[0]);
   TileRange tr = { 0, 0, 0, 0 };
-  if (cur < num_tiles) {
+  if (cur < ntl) {
     tr.a0 = uniform64 (sh.rng[0][0]);
     tr.b0 = uniform64 (sh.rng[0][1]);
     tr.na = uniform32 ((u32) (sh.rng[0][2] - sh.rng[0][0]));
@@ -667,29 +668,25 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
     for (int j = 0; j <= NLOAD4; j++) fetch_part (t, j);
   };
 
-  if (cur < num_tiles) fetch (tr);
+  if (cur < ntl) fetch (tr);
 #ifdef GT4_PROFILE_PHASES
   u64 ph[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
   u64 t_last;
   asm volatile ("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_last) :: "memory");
 #endif
-  /* DEFER: the LAG tiles whose output is staged in LDS but not yet written.  A queue shifted once per
-   * iteration with static indices only (entry 0 = oldest = staged LAG iterations ago, in slot
-   * it % LAG); indexing it by it % LAG instead turns the arrays into scratch memory, which cost a
-   * second copy of the output in HBM traffic. */
+  /* DEFER: the LAG tiles whose output is staged in LDS but not yet written.  Tiles are dealt
+   * statically, so the tile staged j iterations ago is known (tile_of_iter); only its record count
+   * has to be remembered: a queue shifted once per iteration with static indices only (entry 0 =
+   * oldest = staged LAG iterations ago, in slot it % LAG) -- indexing it by it % LAG instead turns
+   * the array into scratch memory, which cost a second copy of the output in HBM traffic. */
   constexpr int LAG = RankShared<NT, IPT, OPS>::STAGE_SLOTS;
-  u64 pend_tile[LAG];
   u32 pend_tot[LAG];
-  bool pend_have[LAG];
 #pragma unroll
-  for (int q = 0; q < LAG; q++) {
-    pend_tile[q] = 0;
-    pend_tot[q] = 0;
-    pend_have[q] = false;
-  }
+  for (int q = 0; q < LAG; q++) pend_tot[q] = 0;
+  auto tile_of_iter = [&] (int j) -> u32 { return wk + (u32) j * n_workers; };
   int it = 0;
 
-  while (cur < num_tiles) {
+  while (cur < ntl) {
     /* position space of the tile: A records at [0, na), B records from the next multiple of 64 on, so
      * that every 64-position chunk (one wavefront pass) holds records of one list only */
     const u32 na = tr.na, nb = tr.nb, nbs = (na + (u32) WAVE - 1u) & ~((u32) WAVE - 1u), npos = nbs + nb;
@@ -717,9 +714,9 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
     __syncthreads (); /* B0 */
     PHASE_STAMP (1); /* barrier B0 */
     const int s_nxt = (it + 1) % 3, s_nn = (it + 2) % 3, s_cur = it % 3;
-    const u64 nxt = uniform32 (sh.tick[s_nxt]);
+    const u32 nxt = uniform32 (sh.tick[s_nxt]);
     TileRange tn = { 0, 0, 0, 0 };
-    if (nxt < num_tiles) {
+    if (nxt < ntl) {
       tn.a0 = uniform64 (sh.rng[s_nxt][0]);
       tn.b0 = uniform64 (sh.rng[s_nxt][1]);
       tn.na = uniform32 ((u32) (sh.rng[s_nxt][2] - sh.rng[s_nxt][0]));
@@ -731,24 +728,23 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
     bool hk_have_rng = false;
     if (tid == 0) {
       hk_ticket = claim ();
-      const u64 tnn = sh.tick[s_nn];
-      if (tnn < num_tiles) {
+      const u32 tnn = sh.tick[s_nn];
+      if (tnn < ntl) {
         hk_have_rng = true;
 #pragma unroll
         /* relaxed atomic loads: plain vector loads the wave does not wait for here (a scalar load
          * of this uniform address would be waited for on the spot) */
-        for (int i = 0; i < 4; i++) hk_rng[i] = __hip_atomic_load (&part[2 * tnn + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = 0; i < 4; i++) hk_rng[i] = __hip_atomic_load (&part[2 * (u64) tnn + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     /* DEFER: write out the tile staged LAG iterations ago (its offset was resolved during phase 2
      * of the previous iteration) BEFORE the next fetch is issued: the memory counter retires in
      * order, so the wait for the fetched records at the next phase 0 then only ever waits on
      * stores that are a whole iteration old */
-    u64 w_tile, n_tile;
-    u32 w_tot, n_tot;
-    bool w_have, n_have;
-    w_tile = pend_tile[0], w_tot = pend_tot[0], w_have = pend_have[0];                            /* written out now            */
-    n_tile = pend_tile[1 % LAG], n_tot = pend_tot[1 % LAG], n_have = LAG > 1 && pend_have[1 % LAG]; /* written out next iteration */
+    const u32 w_tot = pend_tot[0];                       /* written out now */
+    const bool w_have = it >= LAG;
+    const bool n_have = LAG > 1 && it >= LAG - 1;        /* written out next iteration */
+    const u32 n_tile = tile_of_iter (it - (LAG - 1));
     if (DEFER && w_have) {
 #ifndef GT4_EXP_NO_WRITEOUT
       write_out_tile<NT> (outs.rec[S0], uniform64 (sh.excl[S0]), w_tot, sh.stage[it % LAG], tid);
@@ -760,11 +756,11 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
     u64 xcarry = 0;
     if (DEFER && MODE == MODE_LOOKBACK && n_have && wid == 4) {
       const u64 prow = n_tile / WAVE;
-      if ((u32) lane < (u32) (n_tile % WAVE)) xagg = peek_u32 (&agg[(u64) S0 * n_rows * WAVE + prow * WAVE + lane]);
+      if ((u32) lane < n_tile % WAVE) xagg = peek_u32 (&agg[(u64) S0 * n_rows * WAVE + prow * WAVE + lane]);
       xcarry = peek_u64 (&carry[(u64) S0 * (n_rows + 1) + prow]);
     }
     /* in flight until the next iteration's phase 0; the large geometry staggers the parts */
-    if (nxt < num_tiles) {
+    if (nxt < ntl) {
       if (STAGGER) fetch_part (tn, 0);
       else fetch (tn);
     }
@@ -779,7 +775,7 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
       static_assert (IPT % 2 == 0, "chunks are searched in pairs");
 #pragma unroll
       for (int kk = 0; kk < IPT; kk += 2) {
-        if (STAGGER && kk == 2 && nxt < num_tiles) fetch_part (tn, 1); /* staggered fetch: see fetch_part */
+        if (STAGGER && kk == 2 && nxt < ntl) fetch_part (tn, 1); /* staggered fetch: see fetch_part */
         bool live[2], valid[2];
         u32 is_a[2], own[2], lim[2], lo[2]; /* is_a: wave-uniform (chunks never mix the lists); lim, lo: bytes (12 per record) */
         u32 sbase[2], sn[2];                /* wave-uniform: dword base and length of the run this chunk is ranked in */
@@ -878,7 +874,7 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
      * stream's count of every record alive across phase 2 instead of recomputing it (2x the VGPRs) */
 #pragma unroll
     for (int k = 0; k < IPT; k++) asm volatile ("" : "+v"(fa[k]), "+v"(fb[k]), "+v"(meta[k]));
-    if (STAGGER && nxt < num_tiles) {
+    if (STAGGER && nxt < ntl) {
 #pragma unroll
       for (int j = 2; j <= NLOAD4; j++) fetch_part (tn, j);
     }
@@ -915,7 +911,7 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
         sh.tot[s] = total;
         blk_cnt += total;
         if (MODE == MODE_COUNT) {
-          if (desc) desc[4 * cur + s] = total; /* pass 1 of the two-pass path: counts for the scan kernel */
+          if (desc) desc[4 * (u64) cur + s] = total; /* pass 1 of the two-pass path: counts for the scan kernel */
         } else if (MODE == MODE_LOOKBACK) {
           publish_u32 (&agg[(u64) s * n_rows * WAVE + cur], AGG_READY | total);
         }
@@ -925,7 +921,7 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
          * (or the pre-scanned offsets of the two-pass path) */
         u64 x;
         if (MODE == MODE_LOOKBACK) x = resolve_offset (agg + (u64) s * n_rows * WAVE, carry + (u64) s * (n_rows + 1), cur, lane, 0, 0, ctl);
-        else x = desc[4 * cur + s];
+        else x = desc[4 * (u64) cur + s];
         if (lane == 0) sh.excl[s] = x;
       }
     }
@@ -940,20 +936,14 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
         if (S0 == 0) scatter_stream<0, NT, IPT, OPS> (sh, slot, p, nbs, lane, wid, key, fa, fb, meta);
         else scatter_stream<1, NT, IPT, OPS> (sh, slot, p, nbs, lane, wid, key, fa, fb, meta);
 #pragma unroll
-        for (int q = 0; q + 1 < LAG; q++) {
-          pend_tile[q] = pend_tile[q + 1];
-          pend_tot[q] = pend_tot[q + 1];
-          pend_have[q] = pend_have[q + 1];
-        }
-        pend_tile[LAG - 1] = cur;
+        for (int q = 0; q + 1 < LAG; q++) pend_tot[q] = pend_tot[q + 1];
         pend_tot[LAG - 1] = my_tot;
-        pend_have[LAG - 1] = true;
         if (n_have && wid == 4) {
           /* global offset of the tile the next iteration writes out (this iteration's write-out,
            * which read sh.excl, finished before B1) */
           u64 x;
           if (MODE == MODE_LOOKBACK) x = resolve_offset (agg + (u64) S0 * n_rows * WAVE, carry + (u64) S0 * (n_rows + 1), n_tile, lane, xagg, xcarry, ctl);
-          else x = desc[4 * n_tile + S0];
+          else x = desc[4 * (u64) n_tile + S0];
           if (lane == 0) sh.excl[S0] = x;
         }
       } else {
@@ -996,14 +986,14 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
     /* drain: the tiles still staged, oldest first */
 #pragma unroll
     for (int q = 0; q < LAG; q++) {
-      const u64 tile = pend_tile[q];
+      if (it - LAG + q < 0) continue;
+      const u32 tile = tile_of_iter (it - LAG + q);
       const u32 tot = pend_tot[q];
-      if (!pend_have[q]) continue;
       __syncthreads ();
       if (wid == 0) {
         u64 x;
         if (MODE == MODE_LOOKBACK) x = resolve_offset (agg + (u64) S0 * n_rows * WAVE, carry + (u64) S0 * (n_rows + 1), tile, lane, 0, 0, ctl);
-        else x = desc[4 * tile + S0];
+        else x = desc[4 * (u64) tile + S0];
         if (lane == 0) sh.excl[S0] = x;
       }
       __syncthreads ();
