@@ -381,6 +381,10 @@ __device__ __forceinline__ u64 resolve_offset (u32 *agg, u64 *carry, u64 tile, i
  * Keys are unique inside a list (reference precondition), so "both" pairs are found by the match
  * test alone; the B record of a pair keeps nothing (its A partner carries both counts).
  */
+/* launch bound (waves per SIMD): count-only kernels of the small geometry fit 85 VGPRs and 26 KB of
+ * LDS -> three workgroups per CU; everything else runs at 4 waves per SIMD */
+__host__ __device__ constexpr int merge_waves_per_simd (int nt, int mode) { return (nt == 512 && mode == MODE_COUNT) ? 6 : 4; }
+
 template <int NT, int IPT, int OPS>
 struct RankShared {
   static constexpr int CAP = NT * IPT;
@@ -410,8 +414,8 @@ __device__ __forceinline__ u32 kept_before (const u64 *km, const u32 *cp, u32 z)
   return cp[c] + (u32) __popcll (km[c] & ((1ull << (z & 63u)) - 1ull));
 }
 
-template <int S, int NT, int IPT, int OPS>
-__device__ __forceinline__ void scatter_stream (RankShared<NT, IPT, OPS> &sh, u32 *dst32, const PairParams &p, u32 nbs, int lane, int wid,
+template <int S, int NT, int IPT, int OPS, class Shared>
+__device__ __forceinline__ void scatter_stream (Shared &sh, u32 *dst32, const PairParams &p, u32 nbs, int lane, int wid,
                                                 const u64 (&key)[IPT], const u32 (&fa)[IPT], const u32 (&fb)[IPT], const u32 (&meta)[IPT])
 {
   constexpr int NW = NT / WAVE;
@@ -542,7 +546,7 @@ __device__ __forceinline__ u64 uniform64 (u64 v)
 /* OPS != 0 fixes the set of output streams at compile time (the common single-output calls get a
  * kernel without the other streams' code and registers); OPS == 0 takes it from p.ops. */
 template <int NT, int IPT, int MODE, int OPS>
-__global__ __launch_bounds__ (NT, NT == 1024 ? 4 : (OPS ? MERGE_WAVES_PER_SIMD : MERGE_WAVES_PER_SIMD_GENERIC)) void
+__global__ __launch_bounds__ (NT, merge_waves_per_simd (NT, MODE)) void
 k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 nB, u64 *part, u64 num_tiles,
               PairParams p, PairOutputs outs, u64 *desc, PairControl *ctl)
 {
@@ -555,7 +559,9 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
   constexpr bool STAGGER = NT >= 1024;           /* spread the fetch over the iteration (measured: helps 16-wave workgroups only) */
   static_assert (NW >= 4, "one wavefront per output stream in phase 2");
   static_assert (NCH <= WAVE, "chunk scan is a single wavefront pass");
-  __shared__ RankShared<NT, IPT, OPS> sh;
+  /* count-only kernels stage nothing: no staging slots in their LDS */
+  typedef RankShared<NT, IPT, (MODE == MODE_COUNT ? 0 : OPS)> Shared;
+  __shared__ Shared sh;
   u32 *const lds32 = sh.raw;
 
   const int tid = threadIdx.x, lane = tid & (WAVE - 1);
@@ -679,7 +685,7 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
    * has to be remembered: a queue shifted once per iteration with static indices only (entry 0 =
    * oldest = staged LAG iterations ago, in slot it % LAG) -- indexing it by it % LAG instead turns
    * the array into scratch memory, which cost a second copy of the output in HBM traffic. */
-  constexpr int LAG = RankShared<NT, IPT, OPS>::STAGE_SLOTS;
+  constexpr int LAG = Shared::STAGE_SLOTS;
   u32 pend_tot[LAG];
 #pragma unroll
   for (int q = 0; q < LAG; q++) pend_tot[q] = 0;
@@ -1174,11 +1180,6 @@ hipError_t launch_partition (hipStream_t s, const uint32_t *A, uint64_t nA, cons
  * and 2048-record tiles (two workgroups per CU overlap their phases); calls that materialise
  * records run fastest with 1024 threads and 4096-record tiles (half as many tiles on the scan
  * chain, whose hop latency is fixed, and room for the staging slots in one workgroup per CU). */
-template <int NT> struct GeomWaves {
-  static constexpr int single = NT == 1024 ? 4 : MERGE_WAVES_PER_SIMD;
-  static constexpr int generic = NT == 1024 ? 4 : MERGE_WAVES_PER_SIMD_GENERIC;
-};
-
 template <int NT, int OPS>
 static hipError_t launch_pair_merge_ops (hipStream_t s, int mode, int grid, const uint32_t *A, uint64_t nA, const uint32_t *B, uint64_t nB,
                                          const uint64_t *part, uint64_t num_tiles, const PairParams &p, const PairOutputs &o,
@@ -1203,7 +1204,7 @@ static int blocks_per_cu_ops (int mode)
   else e = hipOccupancyMaxActiveBlocksPerMultiprocessor (&n, k_pair_merge<NT, MERGE_VT, MODE_OFFSETS, OPS>, NT, 0);
   if (e != hipSuccess || n < 1) n = 1;
   /* never more than the register file admits for the declared launch bounds */
-  const int by_regs = (OPS ? GeomWaves<NT>::single : GeomWaves<NT>::generic) * 4 / (NT / 64);
+  const int by_regs = merge_waves_per_simd (NT, mode) * 4 / (NT / 64);
   if (by_regs >= 1 && n > by_regs) n = by_regs;
   return n;
 }
