@@ -463,7 +463,7 @@ static int run_pair (gt4hip_context *ctx, const uint32_t *A, uint64_t nA, const 
   if (!total || !p.ops) return GT4HIP_OK;
   /* count-only calls: 512-thread workgroups; everything that materialises records: 1024 */
   const int geom = ctx->force_geom ? (ctx->force_geom > 0 ? 1 : 0) : (count_only ? 0 : 1);
-  const uint64_t tile_records = merge_tile_records (geom);
+  const uint64_t tile_records = merge_tile_records (geom, p.ops);
   const uint64_t tiles = (total + tile_records - 1) / tile_records;
   if (tiles >= 0xffffffffull) return fail (ctx, GT4HIP_EINVAL, "lists too long: %llu merge tiles", (unsigned long long) tiles);
   run->tiles = tiles;

@@ -60,7 +60,7 @@ constexpr int MERGE_TILE_SLACK = 64;
 constexpr int MERGE_WAVES_PER_SIMD = 4;         /* 512-thread geometry, single-output kernels: <= 128 VGPRs */
 constexpr int MERGE_WAVES_PER_SIMD_GENERIC = 4; /* any-combination kernel                                     */
 
-uint64_t merge_tile_records (int geom);
+uint64_t merge_tile_records (int geom, uint32_t ops);
 hipError_t launch_partition (hipStream_t s, const uint32_t *A, uint64_t nA, const uint32_t *B, uint64_t nB,
                              uint64_t num_tiles, uint64_t tile_records, uint64_t *part);
 hipError_t launch_pair_merge (hipStream_t s, int geom, int mode, int grid, const uint32_t *A, uint64_t nA,

@@ -18,6 +18,10 @@
  */
 #include "gt4hip_internal.h"
 
+#ifndef GT4_IPT_INTERSECT
+#define GT4_IPT_INTERSECT 6
+#endif
+
 namespace gt4 {
 
 namespace {
@@ -214,6 +218,27 @@ __device__ __forceinline__ u32 dpp_wave_sum_u32 (u32 v)
   return (u32) __builtin_amdgcn_readlane ((int) dpp_inclusive_scan_u32 (v), WAVE - 1);
 }
 
+/* Exclusive prefix of the chunk ballots' popcounts (up to 128 chunks: two per lane, packed into
+ * the halves of one dword for a single scan) and the empty sentinel chunk behind them; returns the
+ * tile total.  Every lane of the calling wavefront takes part. */
+template <int NCH>
+__device__ __forceinline__ u32 chunk_scan (u64 *km, u32 *cp, int lane)
+{
+  static_assert (NCH <= 2 * WAVE, "two chunks per lane");
+  const u32 v0 = lane < NCH ? (u32) __popcll (km[lane]) : 0u;
+  const u32 v1 = (NCH > WAVE && lane + WAVE < NCH) ? (u32) __popcll (km[NCH > WAVE ? lane + WAVE : 0]) : 0u;
+  const u32 incl = dpp_inclusive_scan_u32 (v0 | (v1 << 16));
+  const u32 last = (u32) __builtin_amdgcn_readlane ((int) incl, WAVE - 1);
+  const u32 t0 = last & 0xffffu, total = t0 + (last >> 16);
+  if (lane < NCH) cp[lane] = (incl & 0xffffu) - v0;
+  if (NCH > WAVE && lane + WAVE < NCH) cp[lane + WAVE] = t0 + (incl >> 16) - v1;
+  if (lane == 0) {
+    cp[NCH] = total;
+    km[NCH] = 0;
+  }
+  return total;
+}
+
 /* ------------------------------------------------------------------ tile descriptors (chained scan) */
 
 /* Two-level chained scan of the tiles' output counts.  Per output stream s, zeroed before every
@@ -385,6 +410,11 @@ __device__ __forceinline__ u64 resolve_offset (u32 *agg, u64 *carry, u64 tile, i
  * LDS -> three workgroups per CU; everything else runs at 4 waves per SIMD */
 __host__ __device__ constexpr int merge_waves_per_simd (int nt, int mode) { return (nt == 512 && mode == MODE_COUNT) ? 6 : 4; }
 
+/* records per thread: an intersection does per-record work on the A half of a tile only and
+ * stages at most half a tile, so its tiles are 1.5x as long (6 positions per thread, 6080 records:
+ * the per-tile costs -- barriers, ring, scan, fetch set-up -- are paid two thirds as often) */
+__host__ __device__ constexpr int merge_ipt (int nt, int ops_class) { return (nt == 1024 && ops_class == 2) ? GT4_IPT_INTERSECT : MERGE_VT; }
+
 template <int NT, int IPT, int OPS>
 struct RankShared {
   static constexpr int CAP = NT * IPT;
@@ -393,7 +423,7 @@ struct RankShared {
   static constexpr int STAGE_DW = OPS == 2 ? ((3 * (CAP / 2 + 1) + 3) & ~3) : (OPS == 1 ? 3 * CAP : 4); /* 16-byte multiples */
   /* write-out lags this many tiles behind ranking; an intersection's staging slots are half the
    * size of a union's, so it can afford three within the LDS of two workgroups per CU */
-  static constexpr int STAGE_SLOTS = OPS == 2 ? 4 : 2;
+  static constexpr int STAGE_SLOTS = (OPS == 2 && IPT <= 4) ? 4 : 2;
   /* input view: the tile's packed records exactly as they lie in HBM (12-byte AoS), the A range
    * from dword 0, the B range from the next 16-byte boundary; OPS == 0: the output view (3 * CAP
    * dwords) starts here too */
@@ -442,7 +472,7 @@ __device__ __forceinline__ void scatter_stream (Shared &sh, u32 *dst32, const Pa
   }
 }
 
-/* Ranks of two keys, each in its own sorted run of packed records in LDS (lower bound: the number
+/* Ranks of G keys, each in its own sorted run of packed records in LDS (lower bound: the number
  * of records with a smaller key), as byte offsets 12 * rank into the run.  The runs' starts and
  * lengths are wave-uniform, which makes the whole search plan scalar: with P = 2^bitlen(n) > n,
  * the first probe is record n - P/2 and leaves a window of exactly P/2 - 1 records on either side,
@@ -450,17 +480,17 @@ __device__ __forceinline__ void scatter_stream (Shared &sh, u32 *dst32, const Pa
  * in all, every one of them inside the run -- no bounds test -- and for h <= 64 the probe's offset
  * from the running position fits the LDS instruction's offset field: compare, select, add per
  * step.  Steps a short run does not need add 0 (their probes read this workgroup's LDS beyond
- * the run, and the value is ignored).  The two searches are interleaved for two LDS reads in flight. */
-template <int CAP>
-__device__ __forceinline__ void rank_pair (const u32 *lds32, const u32 (&sbase)[2], const u32 (&sn)[2], const u64 (&ky)[2], u32 (&lo)[2])
+ * the run, and the value is ignored).  The G searches are interleaved: G LDS reads in flight per lane. */
+template <int CAP, int G>
+__device__ __forceinline__ void rank_group (const u32 *lds32, const u32 (&sbase)[G], const u32 (&sn)[G], const u64 (&ky)[G], u32 (&lo)[G])
 {
   auto key_at = [&] (u32 byte_off) -> u64 {
     const u32 *const q = reinterpret_cast<const u32 *> (reinterpret_cast<const char *> (lds32) + byte_off);
     return (u64) q[0] | ((u64) q[1] << 32);
   };
-  u32 q4[2], at[2];
+  u32 q4[G], at[G];
 #pragma unroll
-  for (int u = 0; u < 2; u++) {
+  for (int u = 0; u < G; u++) {
     const u32 n = sn[u];
     const u32 half = n ? 1u << (31 - __builtin_clz (n)) : 0u; /* P/2 = the largest power of two <= n */
     q4[u] = half >> 1;
@@ -469,28 +499,35 @@ __device__ __forceinline__ void rank_pair (const u32 *lds32, const u32 (&sbase)[
     const u64 pv = key_at (4u * sbase[u] + 12u * i0);
     at[u] = 4u * sbase[u] + (pv < ky[u] ? inc : 0u);
   }
+  constexpr u32 HTOP = (CAP & (CAP - 1)) ? (1u << (31 - __builtin_clz ((unsigned) CAP))) / 2 : CAP / 4; /* P/4 of the longest run */
 #pragma unroll
-  for (u32 h = CAP / 4; h > 64; h >>= 1) {
-    if (h > q4[0] && h > q4[1]) continue; /* wave-uniform */
-    u64 pv[2];
+  for (u32 h = HTOP; h > 64; h >>= 1) {
+    bool any = false; /* wave-uniform */
 #pragma unroll
-    for (int u = 0; u < 2; u++) pv[u] = key_at (at[u] + 12u * (h - 1u));
+    for (int u = 0; u < G; u++) any |= h <= q4[u];
+    if (!any) continue;
+    u64 pv[G];
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
+    for (int u = 0; u < G; u++) pv[u] = key_at (at[u] + 12u * (h - 1u));
+#pragma unroll
+    for (int u = 0; u < G; u++) {
       const u32 hs = h <= q4[u] ? 12u * h : 0u; /* scalar */
       u32 cand = at[u] + hs;                   /* independent of the probe: issued under its latency */
       asm volatile ("" : "+v"(cand));          /* keep add + select (the folded form needs a move of hs per step) */
       at[u] = pv[u] < ky[u] ? cand : at[u];
     }
   }
-  if (q4[0] >= 64 && q4[1] >= 64) { /* both runs hold >= 256 records (the usual tile): every remaining step is live */
+  bool all_long = true; /* every run holds >= 256 records (the usual tile): every remaining step is live */
+#pragma unroll
+  for (int u = 0; u < G; u++) all_long &= q4[u] >= 64;
+  if (all_long) {
 #pragma unroll
     for (u32 h = 64; h >= 1; h >>= 1) {
-      u64 pv[2];
+      u64 pv[G];
 #pragma unroll
-      for (int u = 0; u < 2; u++) pv[u] = key_at (at[u] + 12u * (h - 1u));
+      for (int u = 0; u < G; u++) pv[u] = key_at (at[u] + 12u * (h - 1u));
 #pragma unroll
-      for (int u = 0; u < 2; u++) {
+      for (int u = 0; u < G; u++) {
         u32 cand = at[u] + 12u * h;
         asm volatile ("" : "+v"(cand));
         at[u] = pv[u] < ky[u] ? cand : at[u];
@@ -499,11 +536,11 @@ __device__ __forceinline__ void rank_pair (const u32 *lds32, const u32 (&sbase)[
   } else {
 #pragma unroll
     for (u32 h = 64; h >= 1; h >>= 1) {
-      u64 pv[2];
+      u64 pv[G];
 #pragma unroll
-      for (int u = 0; u < 2; u++) pv[u] = key_at (at[u] + 12u * (h - 1u));
+      for (int u = 0; u < G; u++) pv[u] = key_at (at[u] + 12u * (h - 1u));
 #pragma unroll
-      for (int u = 0; u < 2; u++) {
+      for (int u = 0; u < G; u++) {
         const u32 hs = h <= q4[u] ? 12u * h : 0u;
         u32 cand = at[u] + hs;
         asm volatile ("" : "+v"(cand));
@@ -512,7 +549,7 @@ __device__ __forceinline__ void rank_pair (const u32 *lds32, const u32 (&sbase)[
     }
   }
 #pragma unroll
-  for (int u = 0; u < 2; u++) lo[u] = at[u] - 4u * sbase[u];
+  for (int u = 0; u < G; u++) lo[u] = at[u] - 4u * sbase[u];
 }
 
 /* Tile write-out: `tot` packed records from an LDS staging slot (16-byte aligned) to the output
@@ -558,7 +595,7 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
   constexpr int S0 = OPS == 2 ? 1 : 0;           /* the stream of a single-output kernel */
   constexpr bool STAGGER = NT >= 1024;           /* spread the fetch over the iteration (measured: helps 16-wave workgroups only) */
   static_assert (NW >= 4, "one wavefront per output stream in phase 2");
-  static_assert (NCH <= WAVE, "chunk scan is a single wavefront pass");
+  static_assert (NCH <= 2 * WAVE, "chunk scan is a single wavefront pass");
   /* count-only kernels stage nothing: no staging slots in their LDS */
   typedef RankShared<NT, IPT, (MODE == MODE_COUNT ? 0 : OPS)> Shared;
   __shared__ Shared sh;
@@ -778,25 +815,27 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
     u32 fa[IPT], fb[IPT], meta[IPT]; /* meta: rank | kind << 16 | is_a << 18 */
     {
       const StreamCoef c0 = make_coef<0> (p), c1 = make_coef<1> (p), c2 = make_coef<2> (p), c3 = make_coef<3> (p);
-      static_assert (IPT % 2 == 0, "chunks are searched in pairs");
+      constexpr int G = IPT % 3 == 0 ? 3 : 2; /* chunks searched together */
+      static_assert (IPT % G == 0, "chunks are searched in groups");
 #pragma unroll
-      for (int kk = 0; kk < IPT; kk += 2) {
-        if (STAGGER && kk == 2 && nxt < ntl) fetch_part (tn, 1); /* staggered fetch: see fetch_part */
-        bool live[2], valid[2];
-        u32 is_a[2], own[2], lim[2], lo[2]; /* is_a: wave-uniform (chunks never mix the lists); lim, lo: bytes (12 per record) */
-        u32 sbase[2], sn[2];                /* wave-uniform: dword base and length of the run this chunk is ranked in */
-        u64 ky[2];
+      for (int kk = 0; kk < IPT; kk += G) {
+        if (STAGGER && kk == G && nxt < ntl) fetch_part (tn, 1); /* staggered fetch: see fetch_part */
+        bool live[G], valid[G], any_live = false;
+        u32 is_a[G], own[G], lim[G], lo[G]; /* is_a: wave-uniform (chunks never mix the lists); lim, lo: bytes (12 per record) */
+        u32 sbase[G], sn[G];                /* wave-uniform: dword base and length of the run this chunk is ranked in */
+        u64 ky[G];
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
+        for (int u = 0; u < G; u++) {
           const u32 cbeg = ((u32) (kk + u) * NW + (u32) wid) * WAVE; /* wave-uniform */
           is_a[u] = cbeg < nbs ? 1u : 0u;
           live[u] = is_a[u] ? cbeg < na : (need_b && cbeg < npos);
+          any_live |= live[u];
         }
-        if (!live[0] && !live[1]) {
-          /* nothing in these two chunks can be kept (padding, or B records of a call that keeps none
+        if (!any_live) {
+          /* nothing in these chunks can be kept (padding, or B records of a call that keeps none
            * of them on their own: pairs are found from the A side): empty keep masks, no other work */
 #pragma unroll
-          for (int u = 0; u < 2; u++) {
+          for (int u = 0; u < G; u++) {
             const int k = kk + u;
             key[k] = 0;
             fa[k] = fb[k] = 0;
@@ -811,7 +850,7 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
           continue;
         }
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
+        for (int u = 0; u < G; u++) {
           const u32 e = (u32) (kk + u) * NT + (u32) tid;
           valid[u] = live[u] && (is_a[u] ? e < na : e < npos);
           const u32 at = valid[u] ? (is_a[u] ? 3 * e : OB + 3 * (e - nbs)) : 0u;
@@ -822,9 +861,9 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
           lim[u] = valid[u] ? 12 * sn[u] : 0u;
           lo[u] = 0;
         }
-        if (live[0] || live[1]) rank_pair<CAP> (lds32, sbase, sn, ky, lo);
+        rank_group<CAP, G> (lds32, sbase, sn, ky, lo);
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
+        for (int u = 0; u < G; u++) {
           const int k = kk + u;
           const u32 chunk = (u32) k * NW + (u32) wid;
           const u32 r = (lo[u] * 43691u) >> 19; /* lo / 12, exact for multiples of 12 below 2^16 */
@@ -893,13 +932,8 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
      * barrier between ranking and staging; wavefront 0 also publishes the tile total. */
     u32 my_total = 0;
     if (DEFER) {
-      const u32 v = lane < NCH ? (u32) __popcll (sh.kmask[S0][lane]) : 0u;
-      const u32 incl = dpp_inclusive_scan_u32 (v);
-      my_total = (u32) __builtin_amdgcn_readlane ((int) incl, WAVE - 1);
-      if (lane < NCH) sh.cpre[S0][lane] = incl - v;
+      my_total = chunk_scan<NCH> (sh.kmask[S0], sh.cpre[S0], lane);
       if (lane == 0) {
-        sh.cpre[S0][NCH] = my_total;
-        sh.kmask[S0][NCH] = 0;
         if (wid == S0) blk_cnt += my_total; /* the kernel-total reduction reads it from lane 0 of wave S0 */
         if (wid == 0 && MODE == MODE_LOOKBACK) publish_u32 (&agg[(u64) S0 * n_rows * WAVE + cur], AGG_READY | my_total);
       }
@@ -907,13 +941,8 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
     /* any-combination kernel: wavefront s owns stream s: chunk scan, tile total, publish */
     if (!DEFER && wid < 4 && ((ops >> wid) & 1u)) {
       const int s = wid;
-      const u32 v = lane < NCH ? (u32) __popcll (sh.kmask[s][lane]) : 0u;
-      const u32 incl = dpp_inclusive_scan_u32 (v);
-      const u32 total = (u32) __builtin_amdgcn_readlane ((int) incl, WAVE - 1);
-      if (lane < NCH) sh.cpre[s][lane] = incl - v;
+      const u32 total = chunk_scan<NCH> (sh.kmask[s], sh.cpre[s], lane);
       if (lane == 0) {
-        sh.cpre[s][NCH] = total;
-        sh.kmask[s][NCH] = 0;
         sh.tot[s] = total;
         blk_cnt += total;
         if (MODE == MODE_COUNT) {
@@ -1186,11 +1215,11 @@ static hipError_t launch_pair_merge_ops (hipStream_t s, int mode, int grid, cons
                                          unsigned long long *desc, PairControl *ctl)
 {
   if (mode == MODE_COUNT)
-    hipLaunchKernelGGL ((k_pair_merge<NT, MERGE_VT, MODE_COUNT, OPS>), dim3 (grid), dim3 (NT), 0, s, A, nA, B, nB, (u64 *) part, num_tiles, p, o, desc, ctl);
+    hipLaunchKernelGGL ((k_pair_merge<NT, merge_ipt (NT, OPS), MODE_COUNT, OPS>), dim3 (grid), dim3 (NT), 0, s, A, nA, B, nB, (u64 *) part, num_tiles, p, o, desc, ctl);
   else if (mode == MODE_LOOKBACK)
-    hipLaunchKernelGGL ((k_pair_merge<NT, MERGE_VT, MODE_LOOKBACK, OPS>), dim3 (grid), dim3 (NT), 0, s, A, nA, B, nB, (u64 *) part, num_tiles, p, o, desc, ctl);
+    hipLaunchKernelGGL ((k_pair_merge<NT, merge_ipt (NT, OPS), MODE_LOOKBACK, OPS>), dim3 (grid), dim3 (NT), 0, s, A, nA, B, nB, (u64 *) part, num_tiles, p, o, desc, ctl);
   else
-    hipLaunchKernelGGL ((k_pair_merge<NT, MERGE_VT, MODE_OFFSETS, OPS>), dim3 (grid), dim3 (NT), 0, s, A, nA, B, nB, (u64 *) part, num_tiles, p, o, desc, ctl);
+    hipLaunchKernelGGL ((k_pair_merge<NT, merge_ipt (NT, OPS), MODE_OFFSETS, OPS>), dim3 (grid), dim3 (NT), 0, s, A, nA, B, nB, (u64 *) part, num_tiles, p, o, desc, ctl);
   return hipGetLastError ();
 }
 
@@ -1199,9 +1228,9 @@ static int blocks_per_cu_ops (int mode)
 {
   int n = 0;
   hipError_t e;
-  if (mode == MODE_COUNT) e = hipOccupancyMaxActiveBlocksPerMultiprocessor (&n, k_pair_merge<NT, MERGE_VT, MODE_COUNT, OPS>, NT, 0);
-  else if (mode == MODE_LOOKBACK) e = hipOccupancyMaxActiveBlocksPerMultiprocessor (&n, k_pair_merge<NT, MERGE_VT, MODE_LOOKBACK, OPS>, NT, 0);
-  else e = hipOccupancyMaxActiveBlocksPerMultiprocessor (&n, k_pair_merge<NT, MERGE_VT, MODE_OFFSETS, OPS>, NT, 0);
+  if (mode == MODE_COUNT) e = hipOccupancyMaxActiveBlocksPerMultiprocessor (&n, k_pair_merge<NT, merge_ipt (NT, OPS), MODE_COUNT, OPS>, NT, 0);
+  else if (mode == MODE_LOOKBACK) e = hipOccupancyMaxActiveBlocksPerMultiprocessor (&n, k_pair_merge<NT, merge_ipt (NT, OPS), MODE_LOOKBACK, OPS>, NT, 0);
+  else e = hipOccupancyMaxActiveBlocksPerMultiprocessor (&n, k_pair_merge<NT, merge_ipt (NT, OPS), MODE_OFFSETS, OPS>, NT, 0);
   if (e != hipSuccess || n < 1) n = 1;
   /* never more than the register file admits for the declared launch bounds */
   const int by_regs = merge_waves_per_simd (NT, mode) * 4 / (NT / 64);
@@ -1209,7 +1238,11 @@ static int blocks_per_cu_ops (int mode)
   return n;
 }
 
-uint64_t merge_tile_records (int geom) { return (uint64_t) (geom ? 1024 : 512) * MERGE_VT - MERGE_TILE_SLACK; }
+uint64_t merge_tile_records (int geom, uint32_t ops)
+{
+  const int nt = geom ? 1024 : 512;
+  return (uint64_t) nt * merge_ipt (nt, ops == 1u ? 1 : (ops == 2u ? 2 : 0)) - MERGE_TILE_SLACK;
+}
 
 /* workgroups of the merge kernel that are resident per CU (the single-pass path needs every
  * worker resident: see k_pair_merge) */

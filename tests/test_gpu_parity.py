@@ -105,8 +105,10 @@ def test_tile_boundary_sizes(ctx):
     T = U.merge_tile()
     rng = np.random.default_rng(5)
     T2 = U.merge_tile(1)  # the large geometry's tile (1024 threads x 4 records - slack)
+    T3 = T2 + 2 * 1024    # ... and the intersection's (6 positions per thread)
     for n in (1, 2, T // 2 - 1, T // 2, T // 2 + 1, T - 1, T, T + 1, 2 * T, 3 * T + 1, 10 * T - 1,
-              T2 // 2, T2 // 2 + 1, T2 - 1, T2, T2 + 1, 3 * T2 + 1):
+              T2 // 2, T2 // 2 + 1, T2 - 1, T2, T2 + 1, 3 * T2 + 1,
+              T3 // 2, T3 // 2 + 1, T3 - 1, T3, T3 + 1, 3 * T3 + 1):
         keys = np.unique(rng.integers(0, 1 << 40, size=n, dtype=np.uint64))
         a = U.make_records(keys, rng.integers(1, 9, size=len(keys), dtype=np.uint32))
         b = U.make_records(keys, rng.integers(1, 9, size=len(keys), dtype=np.uint32))
