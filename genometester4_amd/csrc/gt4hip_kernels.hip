@@ -593,6 +593,7 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
   constexpr int NLOAD4 = (3 * IPT + 3) / 4;      /* 16-byte chunks each thread fetches per tile */
   constexpr bool DEFER = (OPS == 1 || OPS == 2) && MODE != MODE_COUNT;
   constexpr int S0 = OPS == 2 ? 1 : 0;           /* the stream of a single-output kernel */
+  constexpr int G = IPT % 3 == 0 ? 3 : 2; /* chunks searched together (four at a time is no faster for the union and spills the 85-register count kernels) */
   constexpr bool STAGGER = NT >= 1024;           /* spread the fetch over the iteration (measured: helps 16-wave workgroups only) */
   static_assert (NW >= 4, "one wavefront per output stream in phase 2");
   static_assert (NCH <= 2 * WAVE, "chunk scan is a single wavefront pass");
@@ -815,7 +816,6 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
     u32 fa[IPT], fb[IPT], meta[IPT]; /* meta: rank | kind << 16 | is_a << 18 */
     {
       const StreamCoef c0 = make_coef<0> (p), c1 = make_coef<1> (p), c2 = make_coef<2> (p), c3 = make_coef<3> (p);
-      constexpr int G = IPT % 3 == 0 ? 3 : 2; /* chunks searched together */
       static_assert (IPT % G == 0, "chunks are searched in groups");
 #pragma unroll
       for (int kk = 0; kk < IPT; kk += G) {
@@ -920,6 +920,7 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
 #pragma unroll
     for (int k = 0; k < IPT; k++) asm volatile ("" : "+v"(fa[k]), "+v"(fb[k]), "+v"(meta[k]));
     if (STAGGER && nxt < ntl) {
+      if (G == IPT) fetch_part (tn, 1); /* a single search group: no second group to issue it under */
 #pragma unroll
       for (int j = 2; j <= NLOAD4; j++) fetch_part (tn, j);
     }
