@@ -135,6 +135,23 @@ def test_empty_and_ragged(ctx):
     _check_pair(ctx, ev, od, 15)
 
 
+@pytest.mark.parametrize("ops", [1, 2, 4, 8, 15])
+def test_skewed_tiles(ctx, ops):
+    """Tiles that are nearly all A or nearly all B (every chunk slot of a wavefront holds one list),
+    runs shorter than 256 records inside a tile (the search's short-run path), and a dense cluster
+    of shared keys: each output alone (specialised kernels) and all four together."""
+    rng = np.random.default_rng(77)
+    big = np.unique(rng.integers(0, 1 << 44, size=150000, dtype=np.uint64))
+    few = np.sort(rng.choice(big, size=90, replace=False))               # all shared, sparse
+    own = np.unique(rng.integers(0, 1 << 44, size=70, dtype=np.uint64))   # mostly private, sparse
+    cluster = big[60000:60400]                                            # 400 consecutive shared keys
+    small_keys = np.unique(np.concatenate([few, own, cluster]))
+    a = U.make_records(big, rng.integers(1, 9, size=len(big), dtype=np.uint32))
+    b = U.make_records(small_keys, rng.integers(1, 9, size=len(small_keys), dtype=np.uint32))
+    _check_pair(ctx, a, b, ops, k=22, cutoff=2)
+    _check_pair(ctx, b, a, ops, k=22, cutoff=2)
+
+
 def test_k32_full_range_keys(ctx):
     a, b = U.random_pair(3, 30000, 0.6, 0.6, k=32)
     top = U.make_records([0xFFFFFFFFFFFFFFFE, 0xFFFFFFFFFFFFFFFF], [3, 4])
