@@ -131,6 +131,10 @@ def bench_union8(args, ctx, capi, rank, local_rank, world):
             dist.barrier()
         torch.cuda.synchronize()
 
+    def merge_only_step():
+        rc, n, total, _ = ctx.union_multi(lists, out=out)
+        assert rc == 0
+
     for _ in range(args.warmup):
         step()
     fence()
@@ -139,10 +143,16 @@ def bench_union8(args, ctx, capi, rank, local_rank, world):
         totals, g = step()
     fence()
     elapsed = time.perf_counter() - t0
+    # the same steps without the gather of the payload (what the shards alone sustain)
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        merge_only_step()
+    fence()
+    merge_only = time.perf_counter() - t1
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed, merge_only], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, merge_only = float(t[0].item()), float(t[1].item())
     if rank == 0:
         n_in = 8 * n_list * world
         n_out = sum(t[0] for t in totals)
@@ -152,7 +162,10 @@ def bench_union8(args, ctx, capi, rank, local_rank, world):
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u64 keys + u32 counts", "data": "synthetic",
             "config": {"workload": "8-way union, eight %d-entry k=%d lists, key-range sharded over %d GPU(s), RCCL gatherv" % (n_list * world, args.k, world),
-                       "entries_per_list": n_list * world, "output_records": n_out, "device": ctx.device_info()},
+                       "entries_per_list": n_list * world, "output_records": n_out, "device": ctx.device_info(),
+                       "merge_only_k_mers_per_s": n_in * args.steps / merge_only,
+                       "merge_only_ms_per_step": merge_only / args.steps * 1e3,
+                       "gathered_bytes_per_step": 12 * (n_out - totals[0][0]) if world > 1 else 0},
             "roofline": {"bound": "hbm", "kernel": "k_pair_merge (3-level pairwise tree)", "achieved": None, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": None, "traffic": None,
                          "note": "tree moves 12*(sum n_i)*~3 + 12*sum(level outputs) bytes; see DESIGN.md"},
