@@ -420,10 +420,13 @@ struct RankShared {
   static constexpr int CAP = NT * IPT;
   static constexpr int NCH = CAP / WAVE;
   /* deferred staging: an intersection keeps at most one record per pair, a union at most CAP */
-  static constexpr int STAGE_DW = OPS == 2 ? ((3 * (CAP / 2 + 1) + 3) & ~3) : (OPS == 1 ? 3 * CAP : 4); /* 16-byte multiples */
+  /* OPS == 3 (any combination of outputs): union + intersection + both complements of one tile are
+   * at most 2 x tile records (union = tile - pairs, intersection = pairs, complements = tile - 2 pairs);
+   * each stream's start is rounded up to 4 records (16-byte LDS reads in the write-out) */
+  static constexpr int STAGE_DW = OPS == 2 ? ((3 * (CAP / 2 + 1) + 3) & ~3) : (OPS == 1 ? 3 * CAP : (OPS == 3 ? 3 * (2 * CAP + 16) : 4)); /* 16-byte multiples */
   /* write-out lags this many tiles behind ranking; an intersection's staging slots are half the
    * size of a union's, so it can afford three within the LDS of two workgroups per CU */
-  static constexpr int STAGE_SLOTS = (OPS == 2 && IPT <= 4) ? 4 : 2;
+  static constexpr int STAGE_SLOTS = (OPS == 2 && IPT <= 4) ? 4 : (OPS == 3 ? 1 : 2);
   /* input view: the tile's packed records exactly as they lie in HBM (12-byte AoS), the A range
    * from dword 0, the B range from the next 16-byte boundary; OPS == 0: the output view (3 * CAP
    * dwords) starts here too */
@@ -593,12 +596,15 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
   constexpr int NLOAD4 = (3 * IPT + 3) / 4;      /* 16-byte chunks each thread fetches per tile */
   constexpr bool DEFER = (OPS == 1 || OPS == 2) && MODE != MODE_COUNT;
   constexpr int S0 = OPS == 2 ? 1 : 0;           /* the stream of a single-output kernel */
+  /* any-combination kernel: all requested streams of a tile are staged in one LDS area and written
+   * out during the NEXT tile (after its ranking), when their global offsets have long been published */
+  constexpr bool GDEFER = OPS == 0 && MODE != MODE_COUNT;
   constexpr int G = IPT % 3 == 0 ? 3 : 2; /* chunks searched together (four at a time is no faster for the union and spills the 85-register count kernels) */
   constexpr bool STAGGER = NT >= 1024;           /* spread the fetch over the iteration (measured: helps 16-wave workgroups only) */
   static_assert (NW >= 4, "one wavefront per output stream in phase 2");
   static_assert (NCH <= 2 * WAVE, "chunk scan is a single wavefront pass");
   /* count-only kernels stage nothing: no staging slots in their LDS */
-  typedef RankShared<NT, IPT, (MODE == MODE_COUNT ? 0 : OPS)> Shared;
+  typedef RankShared<NT, IPT, (MODE == MODE_COUNT ? 0 : (OPS ? OPS : 3))> Shared;
   __shared__ Shared sh;
   u32 *const lds32 = sh.raw;
 
@@ -728,6 +734,7 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
 #pragma unroll
   for (int q = 0; q < LAG; q++) pend_tot[q] = 0;
   auto tile_of_iter = [&] (int j) -> u32 { return wk + (u32) j * n_workers; };
+  u32 g_tot[4] = { 0, 0, 0, 0 }, g_off[4] = { 0, 0, 0, 0 }; /* GDEFER: the staged tile's records per stream and their staging offsets (records) */
   int it = 0;
 
   while (cur < ntl) {
@@ -802,6 +809,15 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
       const u64 prow = n_tile / WAVE;
       if ((u32) lane < n_tile % WAVE) xagg = peek_u32 (&agg[(u64) S0 * n_rows * WAVE + prow * WAVE + lane]);
       xcarry = peek_u64 (&carry[(u64) S0 * (n_rows + 1) + prow]);
+    }
+    if (GDEFER && MODE == MODE_LOOKBACK && it >= 1 && wid >= 4 && wid < 8 && ((ops >> (wid - 4)) & 1u)) {
+      /* wavefront 4 + s asks for the words stream s of the previous tile needs (published during
+       * the previous iteration) and resolves them behind its own ranking, before B1 */
+      const int s = wid - 4;
+      const u32 pt = tile_of_iter (it - 1);
+      const u64 prow = pt / WAVE;
+      if ((u32) lane < pt % WAVE) xagg = peek_u32 (&agg[(u64) s * n_rows * WAVE + prow * WAVE + lane]);
+      xcarry = peek_u64 (&carry[(u64) s * (n_rows + 1) + prow]);
     }
     /* in flight until the next iteration's phase 0; the large geometry staggers the parts */
     if (nxt < ntl) {
@@ -924,6 +940,14 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
 #pragma unroll
       for (int j = 2; j <= NLOAD4; j++) fetch_part (tn, j);
     }
+    if (GDEFER && it >= 1 && wid >= 4 && wid < 8 && ((ops >> (wid - 4)) & 1u)) {
+      const int s = wid - 4;
+      const u32 pt = tile_of_iter (it - 1);
+      u64 x;
+      if (MODE == MODE_LOOKBACK) x = resolve_offset (agg + (u64) s * n_rows * WAVE, carry + (u64) s * (n_rows + 1), pt, lane, xagg, xcarry, ctl);
+      else x = desc[4 * (u64) pt + s];
+      if (lane == 0) sh.excl[s] = x;
+    }
     PHASE_STAMP (3); /* phase 1 */
     __syncthreads (); /* B1: all input reads done */
     PHASE_STAMP (4); /* barrier B1 */
@@ -952,55 +976,54 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
           publish_u32 (&agg[(u64) s * n_rows * WAVE + cur], AGG_READY | total);
         }
       }
-      if (MODE != MODE_COUNT && !DEFER) {
-        /* the tile's own offset: rows before it from the scanner, its own row summed here
-         * (or the pre-scanned offsets of the two-pass path) */
-        u64 x;
-        if (MODE == MODE_LOOKBACK) x = resolve_offset (agg + (u64) s * n_rows * WAVE, carry + (u64) s * (n_rows + 1), cur, lane, 0, 0, ctl);
-        else x = desc[4 * (u64) cur + s];
-        if (lane == 0) sh.excl[s] = x;
-      }
     }
 
     PHASE_STAMP (5); /* phase 2 */
-    if (MODE != MODE_COUNT) {
-      if (!DEFER) __syncthreads (); /* B2 */
-      if (DEFER) {
-        /* stage this tile in the slot the write-out at the top of this iteration freed */
-        u32 *const slot = sh.stage[it % LAG];
-        const u32 my_tot = my_total;
-        if (S0 == 0) scatter_stream<0, NT, IPT, OPS> (sh, slot, p, nbs, lane, wid, key, fa, fb, meta);
-        else scatter_stream<1, NT, IPT, OPS> (sh, slot, p, nbs, lane, wid, key, fa, fb, meta);
+    if (GDEFER) {
+      /* write the previous tile's streams out of the staging area, then (B2) stage this tile's */
+      if (it >= 1) {
 #pragma unroll
-        for (int q = 0; q + 1 < LAG; q++) pend_tot[q] = pend_tot[q + 1];
-        pend_tot[LAG - 1] = my_tot;
-        if (n_have && wid == 4) {
-          /* global offset of the tile the next iteration writes out (this iteration's write-out,
-           * which read sh.excl, finished before B1) */
-          u64 x;
-          if (MODE == MODE_LOOKBACK) x = resolve_offset (agg + (u64) S0 * n_rows * WAVE, carry + (u64) S0 * (n_rows + 1), n_tile, lane, xagg, xcarry, ctl);
-          else x = desc[4 * (u64) n_tile + S0];
-          if (lane == 0) sh.excl[S0] = x;
-        }
-      } else {
+        for (int s = 0; s < 4; s++)
+          if ((ops >> s) & 1u) write_out_tile<NT> (outs.rec[s], uniform64 (sh.excl[s]), g_tot[s], sh.stage[0] + 3 * g_off[s], tid);
+      }
+      __syncthreads (); /* B2: staging area free, this tile's totals and prefix tables complete */
+      u32 run = 0;
 #pragma unroll
-        for (int s = 0; s < 4; s++) {
-          if (!((ops >> s) & 1u)) continue;
-          switch (s) {
-            case 0: scatter_stream<0, NT, IPT, OPS> (sh, lds32, p, nbs, lane, wid, key, fa, fb, meta); break;
-            case 1: scatter_stream<1, NT, IPT, OPS> (sh, lds32, p, nbs, lane, wid, key, fa, fb, meta); break;
-            case 2: scatter_stream<2, NT, IPT, OPS> (sh, lds32, p, nbs, lane, wid, key, fa, fb, meta); break;
-            default: scatter_stream<3, NT, IPT, OPS> (sh, lds32, p, nbs, lane, wid, key, fa, fb, meta); break;
-          }
-          __syncthreads ();
-          u32 *__restrict__ dst = outs.rec[s] + 3 * sh.excl[s];
-          const u32 nd = 3 * sh.tot[s];
-          for (u32 d = tid; d < nd; d += NT) dst[d] = lds32[d];
-          __syncthreads ();
+      for (int s = 0; s < 4; s++) {
+        g_off[s] = run;
+        g_tot[s] = ((ops >> s) & 1u) ? uniform32 (sh.tot[s]) : 0u;
+        run += (g_tot[s] + 3u) & ~3u;
+      }
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        if (!((ops >> s) & 1u)) continue;
+        u32 *const dst = sh.stage[0] + 3 * g_off[s];
+        switch (s) {
+          case 0: scatter_stream<0, NT, IPT, OPS> (sh, dst, p, nbs, lane, wid, key, fa, fb, meta); break;
+          case 1: scatter_stream<1, NT, IPT, OPS> (sh, dst, p, nbs, lane, wid, key, fa, fb, meta); break;
+          case 2: scatter_stream<2, NT, IPT, OPS> (sh, dst, p, nbs, lane, wid, key, fa, fb, meta); break;
+          default: scatter_stream<3, NT, IPT, OPS> (sh, dst, p, nbs, lane, wid, key, fa, fb, meta); break;
         }
       }
+    } else if (DEFER) {
+      /* stage this tile in the slot the write-out at the top of this iteration freed */
+      u32 *const slot = sh.stage[it % LAG];
+      const u32 my_tot = my_total;
+      if (S0 == 0) scatter_stream<0, NT, IPT, OPS> (sh, slot, p, nbs, lane, wid, key, fa, fb, meta);
+      else scatter_stream<1, NT, IPT, OPS> (sh, slot, p, nbs, lane, wid, key, fa, fb, meta);
+#pragma unroll
+      for (int q = 0; q + 1 < LAG; q++) pend_tot[q] = pend_tot[q + 1];
+      pend_tot[LAG - 1] = my_tot;
+      if (n_have && wid == 4) {
+        /* global offset of the tile the next iteration writes out (this iteration's write-out,
+         * which read sh.excl, finished before B1) */
+        u64 x;
+        if (MODE == MODE_LOOKBACK) x = resolve_offset (agg + (u64) S0 * n_rows * WAVE, carry + (u64) S0 * (n_rows + 1), n_tile, lane, xagg, xcarry, ctl);
+        else x = desc[4 * (u64) n_tile + S0];
+        if (lane == 0) sh.excl[S0] = x;
+      }
     }
-    PHASE_STAMP (6); /* B2, write-out, B3, scatter */
+    PHASE_STAMP (6); /* (any-combination kernel: previous tile's write-out, B2) staging scatter */
     if (tid == 0) {
       sh.tick[s_cur] = hk_ticket; /* becomes the "after next" ticket of the next iteration */
       if (hk_have_rng) {
@@ -1018,6 +1041,22 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
     for (int i = 0; i < 8; i++) atomicAdd (&ctl->phase_cycles[i], ph[i]);
 #endif
 
+  if (GDEFER && it >= 1) {
+    /* drain: the last tile's streams are still staged */
+    const u32 pt = tile_of_iter (it - 1);
+    __syncthreads ();
+    if (wid < 4 && ((ops >> wid) & 1u)) {
+      const int s = wid;
+      u64 x;
+      if (MODE == MODE_LOOKBACK) x = resolve_offset (agg + (u64) s * n_rows * WAVE, carry + (u64) s * (n_rows + 1), pt, lane, 0, 0, ctl);
+      else x = desc[4 * (u64) pt + s];
+      if (lane == 0) sh.excl[s] = x;
+    }
+    __syncthreads ();
+#pragma unroll
+    for (int s = 0; s < 4; s++)
+      if ((ops >> s) & 1u) write_out_tile<NT> (outs.rec[s], uniform64 (sh.excl[s]), g_tot[s], sh.stage[0] + 3 * g_off[s], tid);
+  }
   if (DEFER) {
     /* drain: the tiles still staged, oldest first */
 #pragma unroll

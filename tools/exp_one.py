@@ -14,7 +14,12 @@ for opt in ("geom0", "geom1", "grid", "two_pass"):
     if os.environ.get("GT4_" + opt.upper()):
         ctx.set_option(opt, int(os.environ["GT4_" + opt.upper()]))
 a, b = build_lists(ctx, capi, n, 25, 0)
-out = None if count_only else {ops: ctx.alloc(2 * n if ops == 1 else n, 25)}
+if count_only:
+    out = None
+elif ops in (1, 2, 4, 8):
+    out = {ops: ctx.alloc(2 * n if ops == 1 else n, 25)}
+else:
+    out = {bit: ctx.alloc(2 * n if bit == 1 else n, 25) for bit in (1, 2, 4, 8) if ops & bit}
 for _ in range(3):
-    st, _, t = ctx.compare(a, b, ops, out=out, count_only=count_only)
+    st, _, t = ctx.compare(a, b, ops, out=out, count_only=count_only, cutoff=int(os.environ.get("GT4_CUTOFF", "1")))
     print("merge %.3f ms  device %.3f ms  tiles %d" % (t["merge_kernel_ms"], t["device_ms"], t["merge_tiles"]), st, flush=True)
