@@ -32,7 +32,8 @@ class CompareResult(C.Structure):
 
 
 class MultiResult(C.Structure):
-    _fields_ = [("n_words", C.c_uint64), ("total_count", C.c_uint64), ("out", C.c_void_p), ("device_ms", C.c_double)]
+    _fields_ = [("n_words", C.c_uint64), ("total_count", C.c_uint64), ("out", C.c_void_p), ("device_ms", C.c_double),
+                ("records_read", C.c_uint64), ("records_written", C.c_uint64)]
 
 
 class CountTable(C.Structure):
@@ -269,6 +270,7 @@ class Context:
         else:
             result = DeviceList(self, C.c_void_p(res.out))
         self.last_multi_device_ms = res.device_ms
+        self.last_multi_records = (res.records_read, res.records_written)
         return 0, res.n_words, res.total_count, result
 
     def union_multi(self, lists, cutoff=1, rule=0, count_override=1, count_only=False, out=None):

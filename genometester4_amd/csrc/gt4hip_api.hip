@@ -652,6 +652,8 @@ static int nway_final (gt4hip_context *ctx, const gt4hip_list *a, const gt4hip_l
   res->total_count = run.total_count[stream_idx];
   res->out = count_only ? NULL : out[stream_idx];
   res->device_ms += run.device_ms;
+  res->records_read += a->n_words + b->n_words;
+  if (!count_only) res->records_written += run.n_words[stream_idx];
   return GT4HIP_OK;
 }
 
@@ -684,6 +686,7 @@ extern "C" int gt4hip_union_multi (gt4hip_context *ctx, const gt4hip_list *const
   }
   HIPCHK (ctx, hipSetDevice (ctx->device));
   res->device_ms = 0;
+  res->records_read = res->records_written = 0;
   std::vector<const gt4hip_list *> work;
   std::vector<gt4hip_list *> owned; /* intermediate levels, freed as soon as consumed */
   for (uint32_t j = 0; j < n_lists; j++)
@@ -707,6 +710,8 @@ extern "C" int gt4hip_union_multi (gt4hip_context *ctx, const gt4hip_list *const
       rc = pair_with_outputs (ctx, work[i], work[i + 1], raw, false, out, &run);
       if (!rc) {
         res->device_ms += run.device_ms;
+        res->records_read += work[i]->n_words + work[i + 1]->n_words;
+        res->records_written += run.n_words[0];
         next.push_back (out[0]);
         next_owned.push_back (out[0]);
       }
@@ -746,6 +751,7 @@ extern "C" int gt4hip_intersect_multi (gt4hip_context *ctx, const gt4hip_list *c
   }
   HIPCHK (ctx, hipSetDevice (ctx->device));
   res->device_ms = 0;
+  res->records_read = res->records_written = 0;
   const uint32_t wl = lists[0]->word_length;
   if (any_empty) return empty_result (ctx, wl, count_only != 0, res); /* :633-636 */
   /* Left-to-right chain R_k = R_{k-1} n L_k, exactly the reference's fold order over the lists
@@ -771,6 +777,8 @@ extern "C" int gt4hip_intersect_multi (gt4hip_context *ctx, const gt4hip_list *c
     acc_owned = NULL;
     if (!rc) {
       res->device_ms += run.device_ms;
+      res->records_read += acc->n_words + lists[k]->n_words;
+      res->records_written += run.n_words[1];
       acc = acc_owned = out[1];
     }
   }

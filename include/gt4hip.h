@@ -153,6 +153,8 @@ typedef struct {
   uint64_t total_count;
   gt4hip_list *out;        /* as gt4hip_compare_result.out: optional in, result out */
   double device_ms;
+  uint64_t records_read;    /* records the pairwise merges of this call read (all levels) ...      */
+  uint64_t records_written; /* ... and wrote: 12 bytes each, the HBM traffic the call really caused */
 } gt4hip_multi_result;
 
 /* union_multi, src/glistcompare.c:500-603: rule in {DEFAULT(=ADD), ADD, MAX, NUMBER}, cutoff
