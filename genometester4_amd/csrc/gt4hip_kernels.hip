@@ -467,7 +467,8 @@ __device__ __forceinline__ void scatter_stream (Shared &sh, u32 *dst32, const Pa
         slot += kept_before (sh.kmask[S], sh.cpre[S], z) - pna;
       }
       u32 f;
-      eval_stream<S> ((meta[k] >> 16) & 3u, fa[k], fb[k], c, f);
+      if (OPS == 1 || OPS == 2) f = fa[k]; /* single-output kernels carry the stream's count itself */
+      else eval_stream<S> ((meta[k] >> 16) & 3u, fa[k], fb[k], c, f);
       dst32[3 * slot] = (u32) key[k];
       dst32[3 * slot + 1] = (u32) (key[k] >> 32);
       dst32[3 * slot + 2] = f;
@@ -928,6 +929,7 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
             if (lane == 0) sh.kmask[3][chunk] = m;
             acc_sum3 += keep ? f : 0u;
           }
+          if (OPS == 1 || OPS == 2) fa[k] = f; /* the one stream's count: staging does not evaluate the rule again */
         }
       }
     }
