@@ -50,6 +50,7 @@ SYMBOLS = [
     "gt4hip_list_is_sorted", "gt4hip_list_lower_bound", "gt4hip_list_get_word", "gt4hip_compare",
     "gt4hip_union_multi", "gt4hip_intersect_multi", "gt4hip_union_table", "gt4hip_probe_table", "gt4hip_table_download",
     "gt4hip_table_free", "gt4hip_generate", "gt4hip_generate_ex", "gt4hip_synchronize", "gt4hip_set_option",
+    "gt4hip_get_counter",
 ]
 
 _lib = None
@@ -102,6 +103,7 @@ def lib():
             "gt4hip_generate_ex": (C.c_int, [vp, vp, u64, u64, u64, u32, u64, u64]),
             "gt4hip_synchronize": (C.c_int, [vp]),
             "gt4hip_set_option": (C.c_int, [vp, C.c_char_p, C.c_int64]),
+            "gt4hip_get_counter": (C.c_int, [vp, C.c_char_p, C.POINTER(u64)]),
         }
         for name, (res, args) in sig.items():
             f = getattr(L, name)
@@ -206,6 +208,11 @@ class Context:
 
     def set_option(self, name, value):
         self._chk(lib().gt4hip_set_option(self.h, name.encode(), value))
+
+    def get_counter(self, name) -> int:
+        v = C.c_uint64()
+        self._chk(lib().gt4hip_get_counter(self.h, name.encode(), C.byref(v)))
+        return v.value
 
     def synchronize(self):
         self._chk(lib().gt4hip_synchronize(self.h))

@@ -25,6 +25,7 @@ struct gt4hip_context {
   int n_cus;
   int two_pass;
   int64_t grid_override;
+  uint32_t spin_limit;       /* option "spin_limit": bound of the single-pass kernel's waits (0 = default) */
   int force_geom; /* options "geom1" / "geom0": force the large / small geometry for every call (experiments); 0 = automatic */
   uint64_t single_pass_fallbacks; /* calls that had to be rerun on the two-pass path */
   /* freed list storage kept for reuse: hipMalloc / hipFree of tens of GB cost far more than the
@@ -180,9 +181,18 @@ extern "C" int gt4hip_set_option (gt4hip_context *ctx, const char *name, int64_t
     }
   }
   else if (!strcmp (name, "grid")) ctx->grid_override = value;
+  else if (!strcmp (name, "spin_limit")) ctx->spin_limit = value > 0 ? (uint32_t) value : 0u;
   else if (!strcmp (name, "geom1")) ctx->force_geom = value != 0 ? 1 : 0;
   else if (!strcmp (name, "geom0")) ctx->force_geom = value != 0 ? -1 : 0;
   else return fail (ctx, GT4HIP_EINVAL, "unknown option %s", name);
+  return GT4HIP_OK;
+}
+
+extern "C" int gt4hip_get_counter (gt4hip_context *ctx, const char *name, uint64_t *value)
+{
+  if (!ctx || !name || !value) return GT4HIP_EINVAL;
+  if (!strcmp (name, "single_pass_fallbacks")) *value = ctx->single_pass_fallbacks;
+  else return fail (ctx, GT4HIP_EINVAL, "unknown counter %s", name);
   return GT4HIP_OK;
 }
 
@@ -456,8 +466,10 @@ struct PairRun {
 /* Runs the merge of (a, b) with fully resolved kernel parameters.  dst[s] (device record buffers)
  * must be non-null for every requested stream unless count_only. */
 static int run_pair (gt4hip_context *ctx, const uint32_t *A, uint64_t nA, const uint32_t *B, uint64_t nB,
-                     const PairParams &p, bool count_only, uint32_t *const dst[4], PairRun *run, bool force_two_pass = false)
+                     const PairParams &p_in, bool count_only, uint32_t *const dst[4], PairRun *run, bool force_two_pass = false)
 {
+  PairParams p = p_in;
+  p.spin_limit = ctx->spin_limit;
   memset (run, 0, sizeof *run);
   const uint64_t total = nA + nB;
   if (!total || !p.ops) return GT4HIP_OK;

@@ -26,6 +26,7 @@ struct PairParams {
   uint32_t subtract;       /* diff1 only                                                         */
   uint32_t count_override;
   uint32_t filter;
+  uint32_t spin_limit;     /* bound of every inter-workgroup wait (0: the default, ~seconds); tests set it low */
 };
 
 struct PairOutputs {

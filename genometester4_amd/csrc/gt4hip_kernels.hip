@@ -276,7 +276,7 @@ constexpr int SCAN_ROWS = 16;        /* rows of 64 tiles a scanner wavefront kee
 /* The scanner: one wavefront per stream.  Loads SCAN_ROWS x 64 tile counts at once (so that its
  * rate is set by L2 bandwidth, not by one round trip per row), waits for each row to be complete,
  * publishes the carry into the next row. */
-__device__ void scanner_wave (u32 *agg, u64 *carry_out, u64 num_tiles, PairControl *ctl, int lane)
+__device__ void scanner_wave (u32 *agg, u64 *carry_out, u64 num_tiles, PairControl *ctl, int lane, u32 spin_limit)
 {
   /* the scanner shares its SIMD with worker wavefronts and is the one serial resource of the
    * kernel: it must win the instruction arbitration */
@@ -326,7 +326,7 @@ __device__ void scanner_wave (u32 *agg, u64 *carry_out, u64 num_tiles, PairContr
       }
 #endif
       if (done >= n) break;
-      if (++spins > SPIN_LIMIT) {
+      if (++spins > spin_limit) {
         if (lane == 0) atomicOr (&ctl->error, 4u);
         return;
       }
@@ -345,7 +345,7 @@ __device__ void scanner_wave (u32 *agg, u64 *carry_out, u64 num_tiles, PairContr
 
 /* A tile's global output offset: carry of its row + counts of the tiles before it in the row.
  * `a` and `c` are the values of an earlier, speculative load of the same words (or 0). */
-__device__ __forceinline__ u64 resolve_offset (u32 *agg, u64 *carry, u64 tile, int lane, u32 a, u64 c, PairControl *ctl)
+__device__ __forceinline__ u64 resolve_offset (u32 *agg, u64 *carry, u64 tile, int lane, u32 a, u64 c, PairControl *ctl, u32 spin_limit)
 {
   const u64 row = tile / WAVE;
   const u32 pos = (u32) (tile % WAVE);
@@ -357,7 +357,7 @@ __device__ __forceinline__ u64 resolve_offset (u32 *agg, u64 *carry, u64 tile, i
   const bool agg_ok0 = __all (!mine || (a & AGG_READY) != 0), carry_ok0 = (c & CARRY_READY) != 0;
 #endif
   while (!__all (!mine || (a & AGG_READY) != 0) || !(c & CARRY_READY)) {
-    if (++spins > SPIN_LIMIT) {
+    if (++spins > spin_limit) {
       if (lane == 0) atomicOr (&ctl->error, 1u);
       break;
     }
@@ -618,6 +618,7 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
 
   /* single pass: agg u32[4][rows * 64] then carry u64[4][rows + 1] inside desc (zeroed by the host) */
   const u64 n_rows = (num_tiles + WAVE - 1) / WAVE;
+  const u32 spin_limit = p.spin_limit ? p.spin_limit : SPIN_LIMIT;
   u32 *const agg = reinterpret_cast<u32 *> (desc);
   u64 *const carry = desc + 2 * n_rows * WAVE; /* 4 * rows * 64 u32 */
 
@@ -629,7 +630,7 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
     role = sh.tick[0];
     __syncthreads ();
     if (role == 0) {
-      if (wid < 4 && ((ops >> wid) & 1u)) scanner_wave (agg + (u64) wid * n_rows * WAVE, carry + (u64) wid * (n_rows + 1), num_tiles, ctl, lane);
+      if (wid < 4 && ((ops >> wid) & 1u)) scanner_wave (agg + (u64) wid * n_rows * WAVE, carry + (u64) wid * (n_rows + 1), num_tiles, ctl, lane, spin_limit);
       return;
     }
   }
@@ -946,7 +947,7 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
       const int s = wid - 4;
       const u32 pt = tile_of_iter (it - 1);
       u64 x;
-      if (MODE == MODE_LOOKBACK) x = resolve_offset (agg + (u64) s * n_rows * WAVE, carry + (u64) s * (n_rows + 1), pt, lane, xagg, xcarry, ctl);
+      if (MODE == MODE_LOOKBACK) x = resolve_offset (agg + (u64) s * n_rows * WAVE, carry + (u64) s * (n_rows + 1), pt, lane, xagg, xcarry, ctl, spin_limit);
       else x = desc[4 * (u64) pt + s];
       if (lane == 0) sh.excl[s] = x;
     }
@@ -1020,7 +1021,7 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
         /* global offset of the tile the next iteration writes out (this iteration's write-out,
          * which read sh.excl, finished before B1) */
         u64 x;
-        if (MODE == MODE_LOOKBACK) x = resolve_offset (agg + (u64) S0 * n_rows * WAVE, carry + (u64) S0 * (n_rows + 1), n_tile, lane, xagg, xcarry, ctl);
+        if (MODE == MODE_LOOKBACK) x = resolve_offset (agg + (u64) S0 * n_rows * WAVE, carry + (u64) S0 * (n_rows + 1), n_tile, lane, xagg, xcarry, ctl, spin_limit);
         else x = desc[4 * (u64) n_tile + S0];
         if (lane == 0) sh.excl[S0] = x;
       }
@@ -1050,7 +1051,7 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
     if (wid < 4 && ((ops >> wid) & 1u)) {
       const int s = wid;
       u64 x;
-      if (MODE == MODE_LOOKBACK) x = resolve_offset (agg + (u64) s * n_rows * WAVE, carry + (u64) s * (n_rows + 1), pt, lane, 0, 0, ctl);
+      if (MODE == MODE_LOOKBACK) x = resolve_offset (agg + (u64) s * n_rows * WAVE, carry + (u64) s * (n_rows + 1), pt, lane, 0, 0, ctl, spin_limit);
       else x = desc[4 * (u64) pt + s];
       if (lane == 0) sh.excl[s] = x;
     }
@@ -1069,7 +1070,7 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
       __syncthreads ();
       if (wid == 0) {
         u64 x;
-        if (MODE == MODE_LOOKBACK) x = resolve_offset (agg + (u64) S0 * n_rows * WAVE, carry + (u64) S0 * (n_rows + 1), tile, lane, 0, 0, ctl);
+        if (MODE == MODE_LOOKBACK) x = resolve_offset (agg + (u64) S0 * n_rows * WAVE, carry + (u64) S0 * (n_rows + 1), tile, lane, 0, 0, ctl, spin_limit);
         else x = desc[4 * (u64) tile + S0];
         if (lane == 0) sh.excl[S0] = x;
       }

@@ -207,8 +207,15 @@ int gt4hip_generate_ex (gt4hip_context *ctx, gt4hip_list *list, uint64_t n, uint
 int gt4hip_synchronize (gt4hip_context *ctx);
 
 /* Tuning / debugging knobs (not part of the reference surface):
- *   "two_pass" = 1  count + scan + write instead of the single-pass look-back kernel. */
+ *   "two_pass" = 1     count + scan + write instead of the single-pass kernel
+ *   "pool" = 0         release freed list storage to the driver instead of pooling it
+ *   "grid" = n         workgroups of the merge kernel (0: one per resident slot)
+ *   "spin_limit" = n   bound of the single-pass kernel's inter-workgroup waits (0: default, ~seconds)
+ *   "geom0" / "geom1"  force the 512- / 1024-thread geometry (experiments). */
 int gt4hip_set_option (gt4hip_context *ctx, const char *name, int64_t value);
+/* Diagnostic counters of a context.  "single_pass_fallbacks": calls whose single-pass merge gave up a
+ * bounded wait (a worker not resident: shared device) and were rerun on the two-pass path. */
+int gt4hip_get_counter (gt4hip_context *ctx, const char *name, uint64_t *value);
 
 #ifdef __cplusplus
 }

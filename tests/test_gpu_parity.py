@@ -283,3 +283,26 @@ def test_offsets_beyond_2_pow_31_records(ctx):
     for j in (0, m // 2, m - 1):
         k, c = b.get_word(j)
         assert out[1].get_word(j + a.lower_bound(k)) == (k, c)
+
+
+def test_single_pass_gives_up_and_falls_back(ctx):
+    """Twice as many workgroups as the device holds, and waits bounded to a few polls: the workers
+    that are resident wait for tiles of workers that are not, give up, and the call is rerun on the
+    dependency-free two-pass path -- same bytes, and the context counts the fallback."""
+    a, b = U.random_pair(5, 3_000_000, 0.5, 0.5, k=22)
+    exp = O.compare(a, b, 15)
+    da, db = ctx.upload(a, 22), ctx.upload(b, 22)
+    before = ctx.get_counter("single_pass_fallbacks")
+    ctx.set_option("grid", 2048)
+    ctx.set_option("spin_limit", 3)
+    try:
+        for ops in (2, 1, 15):
+            st, out, _ = ctx.compare(da, db, ops)
+            for bit in (1, 2, 4, 8):
+                if ops & bit:
+                    assert st[bit] == exp[bit][:2]
+                    assert out[bit].download().tobytes() == exp[bit][2].tobytes()
+    finally:
+        ctx.set_option("grid", 0)
+        ctx.set_option("spin_limit", 0)
+    assert ctx.get_counter("single_pass_fallbacks") > before
