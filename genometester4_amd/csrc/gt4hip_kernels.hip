@@ -18,6 +18,9 @@
  */
 #include "gt4hip_internal.h"
 
+#ifndef GT4_IPT_UNION
+#define GT4_IPT_UNION 4 /* 6 (one staging slot written out late) measured 3 % slower than 4 with two slots */
+#endif
 #ifndef GT4_IPT_INTERSECT
 #define GT4_IPT_INTERSECT 6
 #endif
@@ -413,7 +416,10 @@ __host__ __device__ constexpr int merge_waves_per_simd (int nt, int mode) { retu
 /* records per thread: an intersection does per-record work on the A half of a tile only and
  * stages at most half a tile, so its tiles are 1.5x as long (6 positions per thread, 6080 records:
  * the per-tile costs -- barriers, ring, scan, fetch set-up -- are paid two thirds as often) */
-__host__ __device__ constexpr int merge_ipt (int nt, int ops_class) { return (nt == 1024 && ops_class == 2) ? GT4_IPT_INTERSECT : MERGE_VT; }
+__host__ __device__ constexpr int merge_ipt (int nt, int ops_class)
+{
+  return (nt == 1024 && ops_class == 2) ? GT4_IPT_INTERSECT : ((nt == 1024 && ops_class == 1) ? GT4_IPT_UNION : MERGE_VT);
+}
 
 template <int NT, int IPT, int OPS>
 struct RankShared {
@@ -423,10 +429,10 @@ struct RankShared {
   /* OPS == 3 (any combination of outputs): union + intersection + both complements of one tile are
    * at most 2 x tile records (union = tile - pairs, intersection = pairs, complements = tile - 2 pairs);
    * each stream's start is rounded up to 4 records (16-byte LDS reads in the write-out) */
-  static constexpr int STAGE_DW = OPS == 2 ? ((3 * (CAP / 2 + 1) + 3) & ~3) : (OPS == 1 ? 3 * CAP : (OPS == 3 ? 3 * (2 * CAP + 16) : 4)); /* 16-byte multiples */
+  static constexpr int STAGE_DW = OPS == 2 ? ((3 * (CAP / 2 + 1) + 3) & ~3) : (OPS == 1 ? 3 * CAP : (OPS == 3 ? 3 * (2 * CAP + 16) : (OPS == 4 ? 3 * (CAP + 16) : 4))); /* 16-byte multiples; 4: a union written out late from one slot */
   /* write-out lags this many tiles behind ranking; an intersection's staging slots are half the
    * size of a union's, so it can afford three within the LDS of two workgroups per CU */
-  static constexpr int STAGE_SLOTS = (OPS == 2 && IPT <= 4) ? 4 : (OPS == 3 ? 1 : 2);
+  static constexpr int STAGE_SLOTS = (OPS == 2 && IPT <= 4) ? 4 : ((OPS == 3 || OPS == 4) ? 1 : 2);
   /* input view: the tile's packed records exactly as they lie in HBM (12-byte AoS), the A range
    * from dword 0, the B range from the next 16-byte boundary; OPS == 0: the output view (3 * CAP
    * dwords) starts here too */
@@ -595,17 +601,18 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
   constexpr int NW = NT / WAVE;
   constexpr int NCH = CAP / WAVE;
   constexpr int NLOAD4 = (3 * IPT + 3) / 4;      /* 16-byte chunks each thread fetches per tile */
-  constexpr bool DEFER = (OPS == 1 || OPS == 2) && MODE != MODE_COUNT;
+  constexpr bool LATE1 = OPS == 1 && IPT > 4;    /* union on long tiles: one staging slot, written out late (as the any-combination kernel) */
+  constexpr bool DEFER = (OPS == 1 || OPS == 2) && !LATE1 && MODE != MODE_COUNT;
   constexpr int S0 = OPS == 2 ? 1 : 0;           /* the stream of a single-output kernel */
   /* any-combination kernel: all requested streams of a tile are staged in one LDS area and written
    * out during the NEXT tile (after its ranking), when their global offsets have long been published */
-  constexpr bool GDEFER = OPS == 0 && MODE != MODE_COUNT;
+  constexpr bool GDEFER = (OPS == 0 || LATE1) && MODE != MODE_COUNT;
   constexpr int G = IPT % 3 == 0 ? 3 : 2; /* chunks searched together (four at a time is no faster for the union and spills the 85-register count kernels) */
   constexpr bool STAGGER = NT >= 1024;           /* spread the fetch over the iteration (measured: helps 16-wave workgroups only) */
   static_assert (NW >= 4, "one wavefront per output stream in phase 2");
   static_assert (NCH <= 2 * WAVE, "chunk scan is a single wavefront pass");
   /* count-only kernels stage nothing: no staging slots in their LDS */
-  typedef RankShared<NT, IPT, (MODE == MODE_COUNT ? 0 : (OPS ? OPS : 3))> Shared;
+  typedef RankShared<NT, IPT, (MODE == MODE_COUNT ? 0 : (OPS == 0 ? 3 : ((OPS == 1 && IPT > 4) ? 4 : OPS)))> Shared;
   __shared__ Shared sh;
   u32 *const lds32 = sh.raw;
 
