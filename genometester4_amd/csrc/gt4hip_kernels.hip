@@ -950,6 +950,14 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
 #pragma unroll
       for (int j = 2; j <= NLOAD4; j++) fetch_part (tn, j);
     }
+    if (DEFER && MODE == MODE_LOOKBACK && n_have && wid == 4) {
+      /* second look, behind the ranking, at the words that were not yet published at the top of
+       * the iteration: they arrive during phase 2 and the staging, so the resolve below rarely
+       * has to wait for a round trip */
+      const u64 prow = n_tile / WAVE;
+      if ((u32) lane < n_tile % WAVE && !(xagg & AGG_READY)) xagg = peek_u32 (&agg[(u64) S0 * n_rows * WAVE + prow * WAVE + lane]);
+      if (!(xcarry & CARRY_READY)) xcarry = peek_u64 (&carry[(u64) S0 * (n_rows + 1) + prow]);
+    }
     if (GDEFER && it >= 1 && wid >= 4 && wid < 8 && ((ops >> (wid - 4)) & 1u)) {
       const int s = wid - 4;
       const u32 pt = tile_of_iter (it - 1);
