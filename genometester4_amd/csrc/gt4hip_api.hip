@@ -468,6 +468,20 @@ struct PairRun {
 static int run_pair (gt4hip_context *ctx, const uint32_t *A, uint64_t nA, const uint32_t *B, uint64_t nB,
                      const PairParams &p_in, bool count_only, uint32_t *const dst[4], PairRun *run, bool force_two_pass = false)
 {
+  if (p_in.ops == 8u) {
+    /* the second complement alone is the first complement of the swapped pair
+     * (include_in_complement (f2, f1, 0), glistcompare.c:862, :896): same specialised kernel */
+    PairParams q = p_in;
+    q.ops = 4u;
+    q.rule[2] = p_in.rule[3];
+    q.subtract = 0;
+    uint32_t *const d2[4] = { NULL, NULL, dst ? dst[3] : NULL, NULL };
+    const int rc = run_pair (ctx, B, nB, A, nA, q, count_only, d2, run, force_two_pass);
+    run->n_words[3] = run->n_words[2];
+    run->total_count[3] = run->total_count[2];
+    run->n_words[2] = run->total_count[2] = 0;
+    return rc;
+  }
   PairParams p = p_in;
   p.spin_limit = ctx->spin_limit;
   memset (run, 0, sizeof *run);

@@ -418,8 +418,11 @@ __host__ __device__ constexpr int merge_waves_per_simd (int nt, int mode) { retu
  * the per-tile costs -- barriers, ring, scan, fetch set-up -- are paid two thirds as often) */
 __host__ __device__ constexpr int merge_ipt (int nt, int ops_class)
 {
-  return (nt == 1024 && ops_class == 2) ? GT4_IPT_INTERSECT : ((nt == 1024 && ops_class == 1) ? GT4_IPT_UNION : MERGE_VT);
+  return (nt == 1024 && ops_class == 2) ? GT4_IPT_INTERSECT : ((nt == 1024 && ops_class == 1) ? GT4_IPT_UNION : MERGE_VT); /* 0 (any) and 4 (complement): MERGE_VT */
 }
+
+/* staging layout of a kernel's LDS (third parameter of RankShared) */
+enum : int { STAGE_NONE = 0, STAGE_UNION = 1, STAGE_INTRSEC = 2, STAGE_ANY = 3, STAGE_UNION_LATE = 4, STAGE_COMPLEMENT = 5 };
 
 template <int NT, int IPT, int OPS>
 struct RankShared {
@@ -429,10 +432,12 @@ struct RankShared {
   /* OPS == 3 (any combination of outputs): union + intersection + both complements of one tile are
    * at most 2 x tile records (union = tile - pairs, intersection = pairs, complements = tile - 2 pairs);
    * each stream's start is rounded up to 4 records (16-byte LDS reads in the write-out) */
-  static constexpr int STAGE_DW = OPS == 2 ? ((3 * (CAP / 2 + 1) + 3) & ~3) : (OPS == 1 ? 3 * CAP : (OPS == 3 ? 3 * (2 * CAP + 16) : (OPS == 4 ? 3 * (CAP + 16) : 4))); /* 16-byte multiples; 4: a union written out late from one slot */
+  static constexpr int STAGE_DW = OPS == STAGE_INTRSEC ? ((3 * (CAP / 2 + 1) + 3) & ~3)
+                                  : ((OPS == STAGE_UNION || OPS == STAGE_COMPLEMENT) ? 3 * CAP /* a complement may keep the whole tile */
+                                     : (OPS == STAGE_ANY ? 3 * (2 * CAP + 16) : (OPS == STAGE_UNION_LATE ? 3 * (CAP + 16) : 4))); /* 16-byte multiples */
   /* write-out lags this many tiles behind ranking; an intersection's staging slots are half the
    * size of a union's, so it can afford three within the LDS of two workgroups per CU */
-  static constexpr int STAGE_SLOTS = (OPS == 2 && IPT <= 4) ? 4 : ((OPS == 3 || OPS == 4) ? 1 : 2);
+  static constexpr int STAGE_SLOTS = (OPS == STAGE_INTRSEC && IPT <= 4) ? 4 : ((OPS == STAGE_ANY || OPS == STAGE_UNION_LATE) ? 1 : 2);
   /* input view: the tile's packed records exactly as they lie in HBM (12-byte AoS), the A range
    * from dword 0, the B range from the next 16-byte boundary; OPS == 0: the output view (3 * CAP
    * dwords) starts here too */
@@ -459,7 +464,8 @@ __device__ __forceinline__ void scatter_stream (Shared &sh, u32 *dst32, const Pa
 {
   constexpr int NW = NT / WAVE;
   const StreamCoef c = make_coef<S> (p);
-  const u32 pna = (OPS == 2 && S == 1) ? 0u : kept_before (sh.kmask[S], sh.cpre[S], nbs); /* nbs: tile position of the first B record */
+  constexpr bool A_ONLY = (OPS == 2 && S == 1) || (OPS == 4 && S == 2); /* intersection / first complement alone: only A records are kept */
+  const u32 pna = A_ONLY ? 0u : kept_before (sh.kmask[S], sh.cpre[S], nbs); /* nbs: tile position of the first B record */
 #pragma unroll
   for (int k = 0; k < IPT; k++) {
     const u32 chunk = (u32) k * NW + (u32) wid;
@@ -467,13 +473,13 @@ __device__ __forceinline__ void scatter_stream (Shared &sh, u32 *dst32, const Pa
     if ((m >> lane) & 1ull) {
       const u32 own = sh.cpre[S][chunk] + (u32) __popcll (m & ((1ull << lane) - 1ull));
       u32 slot = own;
-      if (!(OPS == 2 && S == 1)) { /* an intersection keeps A records only: nothing of the other list comes before */
+      if (!A_ONLY) { /* (A-only streams: nothing of the other list comes before) */
         const u32 r = meta[k] & 0xffffu;
         const u32 z = ((meta[k] >> 18) & 1u) ? nbs + r : r;
         slot += kept_before (sh.kmask[S], sh.cpre[S], z) - pna;
       }
       u32 f;
-      if (OPS == 1 || OPS == 2) f = fa[k]; /* single-output kernels carry the stream's count itself */
+      if (OPS != 0) f = fa[k]; /* single-output kernels carry the stream's count itself */
       else eval_stream<S> ((meta[k] >> 16) & 3u, fa[k], fb[k], c, f);
       dst32[3 * slot] = (u32) key[k];
       dst32[3 * slot + 1] = (u32) (key[k] >> 32);
@@ -602,8 +608,9 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
   constexpr int NCH = CAP / WAVE;
   constexpr int NLOAD4 = (3 * IPT + 3) / 4;      /* 16-byte chunks each thread fetches per tile */
   constexpr bool LATE1 = OPS == 1 && IPT > 4;    /* union on long tiles: one staging slot, written out late (as the any-combination kernel) */
-  constexpr bool DEFER = (OPS == 1 || OPS == 2) && !LATE1 && MODE != MODE_COUNT;
-  constexpr int S0 = OPS == 2 ? 1 : 0;           /* the stream of a single-output kernel */
+  constexpr bool DEFER = OPS != 0 && !LATE1 && MODE != MODE_COUNT;
+  constexpr int S0 = OPS == 2 ? 1 : (OPS == 4 ? 2 : 0); /* the stream of a single-output kernel (OPS = 1 union, 2 intersection, 4 first complement) */
+  static_assert (OPS == 0 || OPS == 1 || OPS == 2 || OPS == 4, "specialised kernels exist for one of these outputs alone");
   /* any-combination kernel: all requested streams of a tile are staged in one LDS area and written
    * out during the NEXT tile (after its ranking), when their global offsets have long been published */
   constexpr bool GDEFER = (OPS == 0 || LATE1) && MODE != MODE_COUNT;
@@ -612,7 +619,7 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
   static_assert (NW >= 4, "one wavefront per output stream in phase 2");
   static_assert (NCH <= 2 * WAVE, "chunk scan is a single wavefront pass");
   /* count-only kernels stage nothing: no staging slots in their LDS */
-  typedef RankShared<NT, IPT, (MODE == MODE_COUNT ? 0 : (OPS == 0 ? 3 : ((OPS == 1 && IPT > 4) ? 4 : OPS)))> Shared;
+  typedef RankShared<NT, IPT, (MODE == MODE_COUNT ? STAGE_NONE : (OPS == 0 ? STAGE_ANY : (OPS == 4 ? STAGE_COMPLEMENT : (OPS == 2 ? STAGE_INTRSEC : (IPT > 4 ? STAGE_UNION_LATE : STAGE_UNION)))))> Shared;
   __shared__ Shared sh;
   u32 *const lds32 = sh.raw;
 
@@ -937,7 +944,7 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
             if (lane == 0) sh.kmask[3][chunk] = m;
             acc_sum3 += keep ? f : 0u;
           }
-          if (OPS == 1 || OPS == 2) fa[k] = f; /* the one stream's count: staging does not evaluate the rule again */
+          if (OPS != 0) fa[k] = f; /* the one stream's count: staging does not evaluate the rule again */
         }
       }
     }
@@ -1027,8 +1034,7 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
       /* stage this tile in the slot the write-out at the top of this iteration freed */
       u32 *const slot = sh.stage[it % LAG];
       const u32 my_tot = my_total;
-      if (S0 == 0) scatter_stream<0, NT, IPT, OPS> (sh, slot, p, nbs, lane, wid, key, fa, fb, meta);
-      else scatter_stream<1, NT, IPT, OPS> (sh, slot, p, nbs, lane, wid, key, fa, fb, meta);
+      scatter_stream<S0, NT, IPT, OPS> (sh, slot, p, nbs, lane, wid, key, fa, fb, meta);
 #pragma unroll
       for (int q = 0; q + 1 < LAG; q++) pend_tot[q] = pend_tot[q + 1];
       pend_tot[LAG - 1] = my_tot;
@@ -1296,22 +1302,25 @@ static int blocks_per_cu_ops (int mode)
   return n;
 }
 
+/* the kernel specialisation of a set of outputs: one of {union, intersection, first complement} alone, else 0 */
+static int ops_class (uint32_t ops) { return (ops == 1u || ops == 2u || ops == 4u) ? (int) ops : 0; }
+
 uint64_t merge_tile_records (int geom, uint32_t ops)
 {
   const int nt = geom ? 1024 : 512;
-  return (uint64_t) nt * merge_ipt (nt, ops == 1u ? 1 : (ops == 2u ? 2 : 0)) - MERGE_TILE_SLACK;
+  return (uint64_t) nt * merge_ipt (nt, ops_class (ops)) - MERGE_TILE_SLACK;
 }
 
 /* workgroups of the merge kernel that are resident per CU (the single-pass path needs every
  * worker resident: see k_pair_merge) */
 int merge_blocks_per_cu (int geom, int mode, uint32_t ops)
 {
-  static int cache[2][3][3];
-  const int oi = ops == 1u ? 1 : (ops == 2u ? 2 : 0);
+  static int cache[2][3][5];
+  const int oi = ops_class (ops);
   int &c = cache[geom ? 1 : 0][mode][oi];
   if (!c) {
-    if (geom) c = oi == 1 ? blocks_per_cu_ops<1024, 1> (mode) : (oi == 2 ? blocks_per_cu_ops<1024, 2> (mode) : blocks_per_cu_ops<1024, 0> (mode));
-    else c = oi == 1 ? blocks_per_cu_ops<512, 1> (mode) : (oi == 2 ? blocks_per_cu_ops<512, 2> (mode) : blocks_per_cu_ops<512, 0> (mode));
+    if (geom) c = oi == 1 ? blocks_per_cu_ops<1024, 1> (mode) : (oi == 2 ? blocks_per_cu_ops<1024, 2> (mode) : (oi == 4 ? blocks_per_cu_ops<1024, 4> (mode) : blocks_per_cu_ops<1024, 0> (mode)));
+    else c = oi == 1 ? blocks_per_cu_ops<512, 1> (mode) : (oi == 2 ? blocks_per_cu_ops<512, 2> (mode) : (oi == 4 ? blocks_per_cu_ops<512, 4> (mode) : blocks_per_cu_ops<512, 0> (mode)));
   }
   return c;
 }
@@ -1325,10 +1334,12 @@ hipError_t launch_pair_merge (hipStream_t s, int geom, int mode, int grid, const
   if (geom) {
     if (p.ops == 1u) return launch_pair_merge_ops<1024, 1> (s, mode, grid, A, nA, B, nB, part, num_tiles, p, o, desc, ctl);
     if (p.ops == 2u) return launch_pair_merge_ops<1024, 2> (s, mode, grid, A, nA, B, nB, part, num_tiles, p, o, desc, ctl);
+    if (p.ops == 4u) return launch_pair_merge_ops<1024, 4> (s, mode, grid, A, nA, B, nB, part, num_tiles, p, o, desc, ctl);
     return launch_pair_merge_ops<1024, 0> (s, mode, grid, A, nA, B, nB, part, num_tiles, p, o, desc, ctl);
   }
   if (p.ops == 1u) return launch_pair_merge_ops<512, 1> (s, mode, grid, A, nA, B, nB, part, num_tiles, p, o, desc, ctl);
   if (p.ops == 2u) return launch_pair_merge_ops<512, 2> (s, mode, grid, A, nA, B, nB, part, num_tiles, p, o, desc, ctl);
+  if (p.ops == 4u) return launch_pair_merge_ops<512, 4> (s, mode, grid, A, nA, B, nB, part, num_tiles, p, o, desc, ctl);
   return launch_pair_merge_ops<512, 0> (s, mode, grid, A, nA, B, nB, part, num_tiles, p, o, desc, ctl);
 }
 

@@ -36,3 +36,6 @@ run("union lookback", 1, {1: out_u})
 run("union two_pass", 1, {1: out_u}, two_pass=1)
 run("union count_only", 1, count_only=True)
 run("all4 count_only", 15, count_only=True)
+run("diff1 lookback", 4, {4: out_i})
+run("diff2 lookback", 8, {8: out_i})
+run("union+intersect lookback", 3, {1: out_u, 2: out_i})
