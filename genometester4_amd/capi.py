@@ -44,7 +44,7 @@ class CountTable(C.Structure):
 # every symbol include/gt4hip.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
     "gt4hip_create", "gt4hip_destroy", "gt4hip_last_error", "gt4hip_strerror", "gt4hip_device_count",
-    "gt4hip_device_info", "gt4hip_list_upload", "gt4hip_list_wrap", "gt4hip_list_alloc", "gt4hip_list_slice",
+    "gt4hip_device_info", "gt4hip_list_upload", "gt4hip_list_upload_index", "gt4hip_list_wrap", "gt4hip_list_alloc", "gt4hip_list_slice",
     "gt4hip_list_download", "gt4hip_list_download_range", "gt4hip_list_free", "gt4hip_list_n_words",
     "gt4hip_list_word_length", "gt4hip_list_device_ptr", "gt4hip_list_set_n_words", "gt4hip_list_sum_counts",
     "gt4hip_list_is_sorted", "gt4hip_list_lower_bound", "gt4hip_list_get_word", "gt4hip_compare",
@@ -78,6 +78,7 @@ def lib():
             "gt4hip_device_count": (C.c_int, []),
             "gt4hip_device_info": (C.c_char_p, [vp]),
             "gt4hip_list_upload": (C.c_int, [vp, vp, u64, u32, C.POINTER(vp)]),
+            "gt4hip_list_upload_index": (C.c_int, [vp, vp, u64, u64, u32, C.POINTER(vp)]),
             "gt4hip_list_wrap": (C.c_int, [vp, vp, u64, u32, C.POINTER(vp)]),
             "gt4hip_list_alloc": (C.c_int, [vp, u64, u32, C.POINTER(vp)]),
             "gt4hip_list_slice": (C.c_int, [vp, vp, u64, u64, C.POINTER(vp)]),
@@ -216,6 +217,13 @@ class Context:
 
     def synchronize(self):
         self._chk(lib().gt4hip_synchronize(self.h))
+
+    def upload_index(self, kmers, num_locations, word_length) -> DeviceList:
+        """kmers: (n, 2) uint64 array of (word, first location) entries of a GT4I index."""
+        kmers = np.ascontiguousarray(kmers, dtype=np.uint64)
+        h = C.c_void_p()
+        self._chk(lib().gt4hip_list_upload_index(self.h, kmers.ctypes.data, len(kmers), num_locations, word_length, C.byref(h)))
+        return DeviceList(self, h)
 
     def upload(self, records, word_length) -> DeviceList:
         rec = np.ascontiguousarray(records, dtype=RECORD_DTYPE)

@@ -7,7 +7,8 @@
  * as the reference's main() (reference src/glistcompare.c:84-429, naming :814-834, :907-953).
  * Deliberate differences, all loud:
  *   - a file that cannot be opened is an error message + exit 1 (the reference dereferences NULL);
- *   - GT4I index inputs, -mm and --subset are outside the GPU path: error + exit 1;
+ *   - -mm and --subset are outside the GPU path: error + exit 1 (GT4I index inputs are read as
+ *     the sorted k-mer lists they contain, as in the reference);
  *   - --stream and --disable_scouts are accepted and ignored (the whole list is uploaded to HBM;
  *     results are identical for well-formed files);
  *   - without a usable GPU the program fails: there is no CPU fallback.
@@ -270,17 +271,14 @@ int main (int argc, const char *argv[])
       err = 1;
       continue;
     }
-    if (code == GT4_INDEX_CODE_VALUE) {
-      fprintf (stderr, "Error: File %s is a GT4I index; index inputs are not supported by the GPU path\n", fnames[f]);
-      err = 1;
-      continue;
-    }
-    if (code != GT4_LIST_CODE_VALUE) {
+    if (code != GT4_LIST_CODE_VALUE && code != GT4_INDEX_CODE_VALUE) {
       fprintf (stderr, "Error: File %s has unknown format\n", fnames[f]);
       err = 1;
       continue;
     }
-    if (gt4_listfile_open (fnames[f], GT4_VERSION_MAJOR, &files[f])) {
+    /* a GT4I index is read as the sorted (k-mer, number of locations) list it contains (:269-270) */
+    if (code == GT4_INDEX_CODE_VALUE ? gt4_indexfile_open (fnames[f], GT4_VERSION_MAJOR, &files[f])
+                                     : gt4_listfile_open (fnames[f], GT4_VERSION_MAJOR, &files[f])) {
       fprintf (stderr, "Error: File %s is invalid or corrupted\n", fnames[f]);
       err = 1;
       continue;
@@ -353,7 +351,8 @@ int main (int argc, const char *argv[])
   }
   static gt4hip_list *lists[MAX_FILES];
   for (unsigned int f = 0; f < nfiles; f++) {
-    if (gt4hip_list_upload (ctx, files[f].records, files[f].header.n_words, wlen, &lists[f])) {
+    if (files[f].index_kmers ? gt4hip_list_upload_index (ctx, files[f].index_kmers, files[f].header.n_words, files[f].index_locations, wlen, &lists[f])
+                             : gt4hip_list_upload (ctx, files[f].records, files[f].header.n_words, wlen, &lists[f])) {
       fprintf (stderr, "Error: uploading %s to the GPU failed: %s\n", fnames[f], gt4hip_last_error (ctx));
       exit (1);
     }

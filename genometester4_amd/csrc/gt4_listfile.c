@@ -107,6 +107,58 @@ int gt4_listfile_open (const char *path, unsigned int major_version, GT4ListFile
   return GT4_LISTFILE_OK;
 }
 
+int gt4_indexfile_open (const char *path, unsigned int major_version, GT4ListFile *out)
+{
+  memset (out, 0, sizeof *out);
+  int fd = open (path, O_RDONLY);
+  struct stat st;
+  if (fd < 0 || fstat (fd, &st) < 0) {
+    if (fd >= 0) close (fd);
+    fprintf (stderr, "gt4_index_map_new: could not mmap file %s\n", path);
+    return GT4_LISTFILE_EOPEN;
+  }
+  const uint64_t size = (uint64_t) st.st_size;
+  const unsigned char *map = NULL;
+  if (size) {
+    map = (const unsigned char *) mmap (NULL, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (map == MAP_FAILED) map = NULL;
+  }
+  close (fd);
+  if (!map || size < sizeof (GT4IndexHeader)) {
+    if (map) munmap ((void *) map, size);
+    fprintf (stderr, "gt4_index_map_new: could not mmap file %s\n", path);
+    return GT4_LISTFILE_EOPEN;
+  }
+  GT4IndexHeader h;
+  memcpy (&h, map, sizeof h);
+  if (h.code != GT4_INDEX_CODE_VALUE) {
+    fprintf (stderr, "gt4_index_map_new: invalid file tag (%x, should be %x)\n", h.code, GT4_INDEX_CODE_VALUE);
+    munmap ((void *) map, size);
+    return GT4_LISTFILE_EMAGIC;
+  }
+  if (h.version_major != major_version) {
+    fprintf (stderr, "gt4_index_map_new: incompatible major version %u (required %u)\n", h.version_major, major_version);
+    munmap ((void *) map, size);
+    return GT4_LISTFILE_EVERSION;
+  }
+  if (h.kmers_start > size || h.num_words > (size - h.kmers_start) / 16) {
+    fprintf (stderr, "gt4_index_map_new: file size too small (%llu) for %llu k-mers at %llu\n", (unsigned long long) size,
+             (unsigned long long) h.num_words, (unsigned long long) h.kmers_start);
+    munmap ((void *) map, size);
+    return GT4_LISTFILE_ESIZE;
+  }
+  out->filename = strdup (path);
+  out->file_map = map;
+  out->file_size = size;
+  gt4_list_header_init (&out->header, h.word_length);
+  out->header.n_words = h.num_words;
+  out->header.total_count = h.num_locations;
+  out->records = NULL;
+  out->index_kmers = map + h.kmers_start;
+  out->index_locations = h.num_locations;
+  return GT4_LISTFILE_OK;
+}
+
 void gt4_listfile_close (GT4ListFile *lf)
 {
   if (!lf) return;

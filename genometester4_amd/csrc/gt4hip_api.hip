@@ -280,6 +280,34 @@ extern "C" int gt4hip_list_upload (gt4hip_context *ctx, const void *host_records
   return GT4HIP_OK;
 }
 
+extern "C" int gt4hip_list_upload_index (gt4hip_context *ctx, const void *host_kmers, uint64_t n_words, uint64_t num_locations,
+                                          uint32_t word_length, gt4hip_list **out)
+{
+  if (!ctx || !out || (n_words && !host_kmers)) return GT4HIP_EINVAL;
+  HIPCHK (ctx, hipSetDevice (ctx->device));
+  gt4hip_list *l = NULL;
+  int rc = list_new (ctx, n_words, word_length, &l);
+  if (rc) return rc;
+  if (n_words) {
+    void *tmp = NULL;
+    hipError_t e = hipMalloc (&tmp, (size_t) n_words * 16);
+    if (e != hipSuccess) {
+      gt4hip_list_free (l);
+      return fail (ctx, GT4HIP_ENOMEM, "hipMalloc of %llu bytes for the index table failed", (unsigned long long) n_words * 16);
+    }
+    e = hipMemcpyAsync (tmp, host_kmers, (size_t) n_words * 16, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = launch_decode_index (ctx->stream, (const unsigned long long *) tmp, n_words, num_locations, (uint32_t *) l->dev);
+    if (e == hipSuccess) e = hipStreamSynchronize (ctx->stream);
+    hipFree (tmp);
+    if (e != hipSuccess) {
+      gt4hip_list_free (l);
+      return fail (ctx, GT4HIP_EHIP, "index upload failed: %s", hipGetErrorString (e));
+    }
+  }
+  *out = l;
+  return GT4HIP_OK;
+}
+
 extern "C" int gt4hip_list_wrap (gt4hip_context *ctx, void *device_records, uint64_t n_words, uint32_t word_length, gt4hip_list **out)
 {
   if (!ctx || !out || (n_words && !device_records)) return GT4HIP_EINVAL;

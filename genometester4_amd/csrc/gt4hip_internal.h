@@ -79,6 +79,7 @@ hipError_t launch_lower_bound (hipStream_t s, const uint32_t *rec, uint64_t n, u
 hipError_t launch_counts_table (hipStream_t s, const uint32_t *keys_rec, uint64_t n_keys, const uint32_t *list,
                                 uint64_t n_list, uint32_t *counts, uint32_t n_lists, uint32_t column);
 hipError_t launch_extract_keys (hipStream_t s, const uint32_t *rec, uint64_t n, unsigned long long *keys);
+hipError_t launch_decode_index (hipStream_t s, const unsigned long long *kmers, uint64_t n, uint64_t num_locations, uint32_t *rec);
 
 int merge_blocks_per_cu (int geom, int mode, uint32_t ops);
 

@@ -1244,6 +1244,21 @@ __global__ void k_extract_keys (const u32 *__restrict__ rec, u64 n, u64 *__restr
   for (u64 i = (u64) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) keys[i] = load_key (rec, i);
 }
 
+/* GT4I index k-mer table -> packed list records: entry i = (word, first location); its count is
+ * the distance to the next entry's first location, the last one's to num_locations, truncated to
+ * 32 bits (imap_get_word / imap_get_count, reference src/index-map.c:123-139). */
+__global__ void k_decode_index (const u64 *__restrict__ kmers, u64 n, u64 num_locations, u32 *__restrict__ rec)
+{
+  const u64 step = (u64) gridDim.x * blockDim.x;
+  for (u64 i = (u64) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
+    const u64 word = kmers[2 * i], loc = kmers[2 * i + 1];
+    const u64 next = i + 1 < n ? kmers[2 * i + 3] : num_locations;
+    rec[3 * i] = (u32) word;
+    rec[3 * i + 1] = (u32) (word >> 32);
+    rec[3 * i + 2] = (u32) (next - loc);
+  }
+}
+
 inline int grid_for (u64 n, int block, int cap)
 {
   u64 g = (n + block - 1) / block;
@@ -1389,6 +1404,12 @@ hipError_t launch_counts_table (hipStream_t s, const uint32_t *keys_rec, uint64_
 hipError_t launch_extract_keys (hipStream_t s, const uint32_t *rec, uint64_t n, unsigned long long *keys)
 {
   hipLaunchKernelGGL (k_extract_keys, dim3 (grid_for (n, 256, 4096)), dim3 (256), 0, s, rec, n, keys);
+  return hipGetLastError ();
+}
+
+hipError_t launch_decode_index (hipStream_t s, const unsigned long long *kmers, uint64_t n, uint64_t num_locations, uint32_t *rec)
+{
+  hipLaunchKernelGGL (k_decode_index, dim3 (grid_for (n, 256, 4096)), dim3 (256), 0, s, (const u64 *) kmers, n, num_locations, rec);
   return hipGetLastError ();
 }
 

@@ -47,8 +47,30 @@ typedef struct {
   const unsigned char *file_map; /* whole file, PROT_READ / MAP_PRIVATE (src/utils.c:54) */
   uint64_t file_size;
   GT4ListHeader header;          /* normalised as src/word-map.c:198-209 */
-  const unsigned char *records;  /* file_map + header.list_start */
+  const unsigned char *records;  /* file_map + header.list_start; NULL for a GT4I index file */
+  /* GT4I index files (gt4_indexfile_open): the k-mer table of 16-byte (word, first location) entries;
+   * the count of entry i is the distance to the next entry's first location, the last one's to
+   * index_locations (imap_get_count, src/index-map.c:129-139).  NULL / 0 for list files. */
+  const unsigned char *index_kmers;
+  uint64_t index_locations;
 } GT4ListFile;
+
+/* struct _GT4IndexHeader, src/index-map.h:69-83: 72 bytes, little-endian, no padding */
+typedef struct {
+  uint32_t code;
+  uint32_t version_major;
+  uint32_t version_minor;
+  uint32_t word_length;
+  uint64_t num_words;
+  uint64_t num_locations;
+  uint32_t n_file_bits;
+  uint32_t n_subseq_bits;
+  uint32_t n_pos_bits;
+  uint32_t filler0;
+  uint64_t files_start;
+  uint64_t kmers_start;
+  uint64_t locations_start;
+} GT4IndexHeader;
 
 enum {
   GT4_LISTFILE_OK = 0,
@@ -66,6 +88,13 @@ int gt4_listfile_sniff (const char *path, uint32_t *code);
  * ("gt4_word_map_new: ...") and returns a GT4_LISTFILE_E* code. */
 int gt4_listfile_open (const char *path, unsigned int major_version, GT4ListFile *out);
 void gt4_listfile_close (GT4ListFile *lf);
+
+/* Maps a GT4I index file (gt4_index_map_new, src/index-map.c:317-373) as a sorted k-mer list: fills
+ * header.word_length / n_words (= num_words) / total_count (= num_locations), index_kmers and
+ * index_locations; records stays NULL.  The reference checks tag and major version only
+ * ("gt4_index_map_new: ..." diagnostics, reproduced); a k-mer table that does not fit in the file
+ * is rejected here with GT4_LISTFILE_ESIZE instead of being read out of bounds. */
+int gt4_indexfile_open (const char *path, unsigned int major_version, GT4ListFile *out);
 
 /* Incremental writer: placeholder header, records, back-patched header (the reference's
  * fopen/fwrite/fseek sequence, src/glistcompare.c:816-834, :907-915, or write/pwrite, :538-595). */

@@ -87,6 +87,12 @@ const char *gt4hip_device_info (const gt4hip_context *ctx);
  * Replaces gt4_word_map_new's mmap (src/word-map.c:165-241) as the way a list becomes readable. */
 int gt4hip_list_upload (gt4hip_context *ctx, const void *host_records, uint64_t n_words,
                         uint32_t word_length, gt4hip_list **out);
+/* The same from the k-mer table of a GT4I index file (what gt4_index_map_new exposes through the
+ * sorted-list interface, reference src/index-map.c:123-175): n_words 16-byte (word, first location)
+ * entries; the count of entry i is entry i+1's first location minus its own, the last one's
+ * num_locations minus its own, truncated to 32 bits.  Decoded on the device. */
+int gt4hip_list_upload_index (gt4hip_context *ctx, const void *host_kmers, uint64_t n_words, uint64_t num_locations,
+                              uint32_t word_length, gt4hip_list **out);
 /* Wraps records already in device memory (16-byte aligned); not freed by gt4hip_list_free. */
 int gt4hip_list_wrap (gt4hip_context *ctx, void *device_records, uint64_t n_words,
                       uint32_t word_length, gt4hip_list **out);

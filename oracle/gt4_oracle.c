@@ -82,6 +82,40 @@ int gt4o_header_parse (const uint8_t *file, uint64_t file_size, gt4o_header *out
   return 0;
 }
 
+int gt4o_index_decode (const uint8_t *file, uint64_t file_size, uint32_t *word_length, uint64_t *num_words,
+                       uint64_t *num_locations, uint8_t *records)
+{
+  /* struct _GT4IndexHeader, src/index-map.h:69-83 (72 bytes, little-endian) */
+  uint32_t code, major, wlen;
+  uint64_t nw, nloc, kmers_start;
+  if (file_size < 72) return 3;
+  memcpy (&code, file, 4);
+  memcpy (&major, file + 4, 4);
+  memcpy (&wlen, file + 12, 4);
+  memcpy (&nw, file + 16, 8);
+  memcpy (&nloc, file + 24, 8);
+  memcpy (&kmers_start, file + 56, 8);
+  if (code != 0x47543449u) return 1;           /* src/index-map.c:339 */
+  if (major != 4) return 2;                    /* src/index-map.c:344 */
+  if (kmers_start > file_size || nw > (file_size - kmers_start) / 16) return 3;
+  *word_length = wlen;
+  *num_words = nw;
+  *num_locations = nloc;
+  if (!records) return 0;
+  const uint8_t *k = file + kmers_start;
+  for (uint64_t i = 0; i < nw; i++) {
+    uint64_t word, loc, next;
+    memcpy (&word, k + 16 * i, 8);             /* imap_get_word, :123-127 */
+    memcpy (&loc, k + 16 * i + 8, 8);
+    if (i + 1 == nw) next = nloc;              /* imap_get_count, :129-139 */
+    else memcpy (&next, k + 16 * (i + 1) + 8, 8);
+    const uint32_t count = (uint32_t) (next - loc);
+    memcpy (records + 12 * i, &word, 8);
+    memcpy (records + 12 * i + 8, &count, 4);
+  }
+  return 0;
+}
+
 uint32_t gt4o_calculate_freq (uint32_t f1, uint32_t f2, int rule, uint32_t count_override)
 {
   /* src/glistcompare.c:433-455 */

@@ -55,6 +55,21 @@ def lib():
     return _lib
 
 
+def index_decode(file_bytes):
+    """GT4I index file image -> (word_length, num_locations, records) via the C restatement."""
+    buf = np.frombuffer(bytes(file_bytes), dtype=np.uint8)
+    f = lib().gt4o_index_decode
+    f.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_void_p]
+    f.restype = C.c_int
+    wl, nw, nl = C.c_uint32(), C.c_uint64(), C.c_uint64()
+    rc = f(buf.ctypes.data, len(buf), C.byref(wl), C.byref(nw), C.byref(nl), None)
+    if rc:
+        raise ValueError("gt4o_index_decode: %d" % rc)
+    rec = np.zeros(nw.value, dtype=RECORD_DTYPE)
+    f(buf.ctypes.data, len(buf), C.byref(wl), C.byref(nw), C.byref(nl), rec.ctypes.data)
+    return wl.value, nl.value, rec
+
+
 def _ptr(a: np.ndarray):
     return C.c_void_p(a.ctypes.data)
 
