@@ -59,9 +59,13 @@ GT4HipWordList *gt4_hip_word_list_new (const char *listfilename, unsigned int ma
   gt4hip_context *ctx = gt4_hip_default_context ();
   if (!ctx) return NULL;
   GT4ListFile lf;
-  if (gt4_listfile_open (listfilename, major_version, &lf)) return NULL;
+  uint32_t code = 0;
+  /* a GT4I index is a sorted k-mer list too (gt4_index_map_new's GT4WordSList interface) */
+  const int is_index = !gt4_listfile_sniff (listfilename, &code) && code == GT4_INDEX_CODE_VALUE;
+  if (is_index ? gt4_indexfile_open (listfilename, major_version, &lf) : gt4_listfile_open (listfilename, major_version, &lf)) return NULL;
   gt4hip_list *dev = NULL;
-  int rc = gt4hip_list_upload (ctx, lf.records, lf.header.n_words, lf.header.word_length, &dev);
+  int rc = is_index ? gt4hip_list_upload_index (ctx, lf.index_kmers, lf.header.n_words, lf.index_locations, lf.header.word_length, &dev)
+                    : gt4hip_list_upload (ctx, lf.records, lf.header.n_words, lf.header.word_length, &dev);
   const uint64_t n = lf.header.n_words, total = lf.header.total_count;
   const unsigned int wl = lf.header.word_length;
   gt4_listfile_close (&lf);

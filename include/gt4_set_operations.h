@@ -27,8 +27,9 @@ typedef struct _GT4HipWordList GT4HipWordList;
  * device $GT4HIP_DEVICE, default 0).  NULL (and a message on stderr) when there is no GPU. */
 gt4hip_context *gt4_hip_default_context (void);
 
-/* gt4_word_map_new (src/word-map.c:165-241) for the GPU path: map, validate, upload.  NULL on
- * failure (diagnostic on stderr). */
+/* gt4_word_map_new (src/word-map.c:165-241) for the GPU path: map, validate, upload.  A GT4I index
+ * file is accepted as the sorted k-mer list it contains (gt4_index_map_new, src/index-map.c:317-373).
+ * NULL on failure (diagnostic on stderr). */
 GT4HipWordList *gt4_hip_word_list_new (const char *listfilename, unsigned int major_version);
 /* Wraps packed records already in host memory (copied to HBM). */
 GT4HipWordList *gt4_hip_word_list_new_from_records (const void *records, uint64_t n_words, unsigned int word_length);
