@@ -274,7 +274,10 @@ __device__ __forceinline__ u64 peek_u64 (u64 *p) { return __hip_atomic_load (p, 
 #endif
 
 constexpr u32 SPIN_LIMIT = 1u << 22; /* bounded: ~seconds; sets ctl->error instead of hanging */
-constexpr int SCAN_ROWS = 16;        /* rows of 64 tiles a scanner wavefront keeps in flight */
+#ifndef GT4_SCAN_ROWS
+#define GT4_SCAN_ROWS 16
+#endif
+constexpr int SCAN_ROWS = GT4_SCAN_ROWS;        /* rows of 64 tiles a scanner wavefront keeps in flight */
 
 /* The scanner: one wavefront per stream.  Loads SCAN_ROWS x 64 tile counts at once (so that its
  * rate is set by L2 bandwidth, not by one round trip per row), waits for each row to be complete,
