@@ -5,14 +5,17 @@
  * The hot path restates, per merged key, what the reference's single-threaded loop does
  * (compare_wordmaps, reference src/glistcompare.c:843-905; predicates :433-489):
  *
- *   K1 k_partition    merge-path co-ranking: tile t starts at (a_t, b_t) with a_t + b_t = t*TILE,
- *                     "A first on ties"; a matching A/B pair is never split between tiles.
- *   K2 k_pair_merge   persistent workgroups pull tiles by ticket; per tile: coalesced loads of the
- *                     two record ranges -> LDS (SoA: 8-byte-aligned keys + counts), one record per
- *                     lane: rank in the other list by LDS binary search, classification
- *                     {A only, B only, both}, up to four output predicates, wavefront ballots +
- *                     popcount prefix for output slots; a scanner wavefront chains the tile totals
- *                     into global output offsets; LDS-staged compaction, coalesced record stores.
+ *   K1 k_partition*   merge-path co-ranking (coarse, then fine inside the coarse bracket): tile t
+ *                     starts at (a_t, b_t) with a_t + b_t = t*TILE, "A first on ties"; a matching
+ *                     A/B pair is never split between tiles.
+ *   K2 k_pair_merge   persistent workgroups, tiles dealt statically; per tile: coalesced 16-byte
+ *                     loads of the two record ranges (one tile ahead, in registers) -> LDS as they
+ *                     lie in HBM (packed 12-byte records), one record per lane: rank in the other
+ *                     list by a scalar-planned LDS search, classification {A only, B only, both},
+ *                     up to four output predicates, wavefront ballots + popcount prefix for output
+ *                     slots; a scanner wavefront chains the tile totals into global output
+ *                     offsets; compaction into LDS staging, written out one or two tiles later
+ *                     with 16-byte stores.
  *   K3 k_scan_*       tile-count scan for the two-pass fallback.
  *   K0 k_generate     synthetic ascending lists written straight into HBM (bench only).
  */
@@ -385,29 +388,30 @@ __device__ __forceinline__ u64 resolve_offset (u32 *agg, u64 *carry, u64 tile, i
 /* ------------------------------------------------------------------ K2: tile merge by rank search */
 
 /*
- * Persistent workgroups; each processes one merge-path tile (<= CAP records of A and B together)
- * at a time, tiles handed out in index order by an atomic ticket:
+ * Persistent workgroups; each processes one merge-path tile (<= CAP - 64 records of A and B
+ * together) at a time; worker w takes tiles w, w + W, ... (static dealing):
  *
  *  phase 0  the tile's two packed record ranges, fetched one tile AHEAD into registers with
- *           coalesced dword loads, go to LDS as SoA (keys[] 8-byte aligned, counts[]); A records
- *           first, then B records.  The next tile's loads are issued right away and stay in
- *           flight during phases 1-3.
- *  phase 1  one record per lane (striped: consecutive lanes hold consecutive sorted keys, so the
- *           64 binary searches of a wavefront walk nearly the same LDS addresses -> broadcasts, few
- *           bank conflicts): rank r = number of records of the OTHER list with a smaller key,
- *           match test at r, classification {A only, B only, both}, per-stream keep predicate;
- *           the keep flags of each 64-record chunk go to LDS as one wavefront ballot.
- *  phase 2  one wavefront per stream: popcount-scan of the chunk ballots, tile total published
- *           for the scanner wavefront (chained scan, above).
+ *           16-byte buffer loads, are copied to LDS as they are (A from dword 0, B from the next
+ *           16-byte boundary).  The next tile's loads are issued during phases 1-2.
+ *  phase 1  position space: A records at [0, na), B records from the next multiple of 64, so a
+ *           64-position chunk (one wavefront pass) never mixes the lists.  One record per lane:
+ *           rank r = number of records of the OTHER list with a smaller key (rank_group), match
+ *           test at r, classification {A only, B only, both}, per-stream keep predicate; the keep
+ *           flags of each chunk go to LDS as one wavefront ballot.  Chunks that cannot keep a
+ *           record do no per-record work.
+ *  phase 2  popcount-scan of the chunk ballots (single-output kernels: by every wavefront; else
+ *           one wavefront per stream), tile total published for the scanner wavefront.
  *  phase 3  output slot of a kept record = (kept records before it in its own list)
  *           + (kept records of the other list before its rank) -- two ballot/prefix lookups, no
- *           sort; records are scattered into an LDS staging area in output order and leave with
- *           coalesced dword stores at the tile's global offset.
+ *           sort; records are scattered into an LDS staging slot in output order.
  *
- * Single-output kernels (OPS = union or intersection) DEFER the write-out of tile i until tile
- * i+1 has been ranked: by then the scanner has long published tile i's offset, so no wavefront
- * ever waits on the chain.  The any-combination kernel (OPS = 0) writes out in place (staging
- * aliases the dead input view) and waits for its offset right after publishing its totals.
+ * Write-out is DEFERRED.  Single-output kernels (OPS = union, intersection or first complement)
+ * keep LAG staging slots and write tile i at the top of iteration i + LAG, when the scanner has
+ * long published its offset.  The any-combination kernel (OPS = 0) stages all requested streams of
+ * a tile in one area (at most 2 x tile records) and writes them out during the next tile, after its
+ * ranking.  No wavefront waits on the chain unless the device is oversubscribed; then a bounded
+ * wait gives up and the host reruns the call on the two-pass path.
  *
  * Keys are unique inside a list (reference precondition), so "both" pairs are found by the match
  * test alone; the B record of a pair keeps nothing (its A partner carries both counts).
