@@ -51,15 +51,14 @@ enum MergeMode : int {
   MODE_OFFSETS = 2    /* pass 2 of the two-pass path: tile offsets already scanned                       */
 };
 
-/* Geometry of the merge kernel: 4 records per thread; workgroups of 512 threads
- * (2048-record tiles, geom 0: count-only calls) or 1024 threads (4096-record tiles, geom 1: calls
- * that materialise records).  A tile holds CAP - 64 records (the pair fix-up makes it +-1): in the
- * workgroup's position space the B records start at the next multiple of 64 after the A records,
- * so that no 64-position chunk mixes the two lists, and both record ranges fit in 16-byte chunks. */
+/* Geometry of the merge kernel: workgroups of 512 threads (geom 0: count-only
+ * calls) or 1024 threads (geom 1: calls that materialise records), MERGE_VT positions per thread --
+ * 6 for the single-output intersection (merge_ipt in gt4hip_kernels.hip).  A tile holds
+ * threads x positions - 64 records (the pair fix-up makes it +-1): in the workgroup's position
+ * space the B records start at the next multiple of 64 after the A records, so that no 64-position
+ * chunk mixes the two lists, and both record ranges fit in 16-byte chunks. */
 constexpr int MERGE_VT = 4;
 constexpr int MERGE_TILE_SLACK = 64;
-constexpr int MERGE_WAVES_PER_SIMD = 4;         /* 512-thread geometry, single-output kernels: <= 128 VGPRs */
-constexpr int MERGE_WAVES_PER_SIMD_GENERIC = 4; /* any-combination kernel                                     */
 
 uint64_t merge_tile_records (int geom, uint32_t ops);
 hipError_t launch_partition (hipStream_t s, const uint32_t *A, uint64_t nA, const uint32_t *B, uint64_t nB,

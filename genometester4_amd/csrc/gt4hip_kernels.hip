@@ -442,12 +442,11 @@ struct RankShared {
   static constexpr int STAGE_DW = OPS == STAGE_INTRSEC ? ((3 * (CAP / 2 + 1) + 3) & ~3)
                                   : ((OPS == STAGE_UNION || OPS == STAGE_COMPLEMENT) ? 3 * CAP /* a complement may keep the whole tile */
                                      : (OPS == STAGE_ANY ? 3 * (2 * CAP + 16) : (OPS == STAGE_UNION_LATE ? 3 * (CAP + 16) : 4))); /* 16-byte multiples */
-  /* write-out lags this many tiles behind ranking; an intersection's staging slots are half the
-   * size of a union's, so it can afford three within the LDS of two workgroups per CU */
+  /* write-out lags this many tiles behind ranking (LAG): two slots in general; an intersection on
+   * 4-position tiles has room for four half-size slots; the late-written layouts use one */
   static constexpr int STAGE_SLOTS = (OPS == STAGE_INTRSEC && IPT <= 4) ? 4 : ((OPS == STAGE_ANY || OPS == STAGE_UNION_LATE) ? 1 : 2);
   /* input view: the tile's packed records exactly as they lie in HBM (12-byte AoS), the A range
-   * from dword 0, the B range from the next 16-byte boundary; OPS == 0: the output view (3 * CAP
-   * dwords) starts here too */
+   * from dword 0, the B range from the next 16-byte boundary */
   alignas (16) u32 raw[3 * CAP];
   u32 stage[STAGE_SLOTS][STAGE_DW];
   u64 kmask[4][NCH + 1];  /* keep-flag ballot per 64-record chunk, per stream (+1: empty sentinel chunk) */
