@@ -604,7 +604,12 @@ __device__ __forceinline__ u64 uniform64 (u64 v)
 
 /* OPS != 0 fixes the set of output streams at compile time (the common single-output calls get a
  * kernel without the other streams' code and registers); OPS == 0 takes it from p.ops. */
-template <int NT, int IPT, int MODE, int OPS>
+/* FAST != 0 (single-output kernels, chosen by the launcher from the call's parameters): the count
+ * rule and keep test of the commonest calls as two or three instructions instead of the general
+ * coefficient form -- 1: the reference predicate with the operation's default rule (union: ADD,
+ * intersection: MIN, both with cutoff <= 1; first complement: SUBTRACT, cutoff 1, no -du);
+ * 2: ADD keeping every key (intermediate N-way union levels). */
+template <int NT, int IPT, int MODE, int OPS, int FAST = 0>
 __global__ __launch_bounds__ (NT, merge_waves_per_simd (NT, MODE)) void
 k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 nB, u64 *part, u64 num_tiles,
               PairParams p, PairOutputs outs, u64 *desc, PairControl *ctl)
@@ -926,25 +931,43 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
           fb[k] = xb;
           meta[k] = r | (kind << 16) | (is_a[u] << 18);
           u32 f;
-          if (ops & 1u) {
+          if (FAST && OPS == 1) {
+            f = xa + xb;                                         /* ADD (u32 wrap), :433-455 */
+            const bool keep = kind != KIND_SKIP && (FAST == 2 || f != 0u); /* cutoff <= 1: "either count >= cutoff" follows from f != 0 */
+            const u64 m = __ballot (keep);
+            if (lane == 0) sh.kmask[0][chunk] = m;
+            acc_sum0 += keep ? f : 0u;
+          } else if (FAST && OPS == 4) {
+            f = xa;                                              /* SUBTRACT with f2 == 0 */
+            const bool keep = (kind & KIND_A) != 0 && xb == 0u && xa != 0u; /* cutoff 1: f1 >= 1 && f2 < 1 */
+            const u64 m = __ballot (keep);
+            if (lane == 0) sh.kmask[2][chunk] = m;
+            acc_sum2 += keep ? f : 0u;
+          } else if (FAST && OPS == 2) {
+            f = xa < xb ? xa : xb;                               /* MIN */
+            const bool keep = kind == KIND_BOTH && f != 0u;      /* cutoff <= 1: "both counts >= cutoff" follows from min != 0 */
+            const u64 m = __ballot (keep);
+            if (lane == 0) sh.kmask[1][chunk] = m;
+            acc_sum1 += keep ? f : 0u;
+          } else if (ops & 1u) {
             const bool keep = eval_stream<0> (kind, xa, xb, c0, f);
             const u64 m = __ballot (keep);
             if (lane == 0) sh.kmask[0][chunk] = m;
             acc_sum0 += keep ? f : 0u;
           }
-          if (ops & 2u) {
+          if (!FAST && (ops & 2u)) {
             const bool keep = eval_stream<1> (kind, xa, xb, c1, f);
             const u64 m = __ballot (keep);
             if (lane == 0) sh.kmask[1][chunk] = m;
             acc_sum1 += keep ? f : 0u;
           }
-          if (ops & 4u) {
+          if (!FAST && (ops & 4u)) {
             const bool keep = eval_stream<2> (kind, xa, xb, c2, f);
             const u64 m = __ballot (keep);
             if (lane == 0) sh.kmask[2][chunk] = m;
             acc_sum2 += keep ? f : 0u;
           }
-          if (ops & 8u) {
+          if (!FAST && (ops & 8u)) {
             const bool keep = eval_stream<3> (kind, xa, xb, c3, f);
             const u64 m = __ballot (keep);
             if (lane == 0) sh.kmask[3][chunk] = m;
@@ -1299,12 +1322,29 @@ static hipError_t launch_pair_merge_ops (hipStream_t s, int mode, int grid, cons
                                          const uint64_t *part, uint64_t num_tiles, const PairParams &p, const PairOutputs &o,
                                          unsigned long long *desc, PairControl *ctl)
 {
-  if (mode == MODE_COUNT)
-    hipLaunchKernelGGL ((k_pair_merge<NT, merge_ipt (NT, OPS), MODE_COUNT, OPS>), dim3 (grid), dim3 (NT), 0, s, A, nA, B, nB, (u64 *) part, num_tiles, p, o, desc, ctl);
-  else if (mode == MODE_LOOKBACK)
-    hipLaunchKernelGGL ((k_pair_merge<NT, merge_ipt (NT, OPS), MODE_LOOKBACK, OPS>), dim3 (grid), dim3 (NT), 0, s, A, nA, B, nB, (u64 *) part, num_tiles, p, o, desc, ctl);
-  else
-    hipLaunchKernelGGL ((k_pair_merge<NT, merge_ipt (NT, OPS), MODE_OFFSETS, OPS>), dim3 (grid), dim3 (NT), 0, s, A, nA, B, nB, (u64 *) part, num_tiles, p, o, desc, ctl);
+  /* the commonest single-output calls take the variant with the rule folded in (see FAST) */
+  int fast = 0;
+  if (p.filter == FILTER_REFERENCE) {
+    if (OPS == 1 && p.rule[0] == 1u && p.cutoff <= 1u) fast = 1;
+    if (OPS == 2 && p.rule[1] == 3u && p.cutoff <= 1u) fast = 1;
+    if (OPS == 4 && p.rule[2] == 2u && p.cutoff == 1u && !p.subtract) fast = 1;
+  } else if (p.filter == FILTER_RAW && OPS == 1 && p.rule[0] == 1u) {
+    fast = 2;
+  }
+  constexpr int F1 = OPS ? 1 : 0, F2 = OPS == 1 ? 2 : 0;
+#define GT4_LAUNCH_MERGE(M, F) hipLaunchKernelGGL ((k_pair_merge<NT, merge_ipt (NT, OPS), M, OPS, F>), dim3 (grid), dim3 (NT), 0, s, A, nA, B, nB, (u64 *) part, num_tiles, p, o, desc, ctl)
+  if (mode == MODE_COUNT) {
+    if (fast == 1 && F1) GT4_LAUNCH_MERGE (MODE_COUNT, F1);
+    else if (fast == 2 && F2) GT4_LAUNCH_MERGE (MODE_COUNT, F2);
+    else GT4_LAUNCH_MERGE (MODE_COUNT, 0);
+  } else if (mode == MODE_LOOKBACK) {
+    if (fast == 1 && F1) GT4_LAUNCH_MERGE (MODE_LOOKBACK, F1);
+    else if (fast == 2 && F2) GT4_LAUNCH_MERGE (MODE_LOOKBACK, F2);
+    else GT4_LAUNCH_MERGE (MODE_LOOKBACK, 0);
+  } else {
+    GT4_LAUNCH_MERGE (MODE_OFFSETS, 0); /* second pass of the two-pass path: general form only */
+  }
+#undef GT4_LAUNCH_MERGE
   return hipGetLastError ();
 }
 
