@@ -929,47 +929,47 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
           key[k] = ky[u];
           fa[k] = xa;
           fb[k] = xb;
-          meta[k] = r | (kind << 16) | (is_a[u] << 18);
+          meta[k] = (OPS == 2 || OPS == 4) ? 0u : (r | (kind << 16) | (is_a[u] << 18)); /* A-only kernels place by the own prefix alone */
           u32 f;
           if (FAST && OPS == 1) {
             f = xa + xb;                                         /* ADD (u32 wrap), :433-455 */
             const bool keep = kind != KIND_SKIP && (FAST == 2 || f != 0u); /* cutoff <= 1: "either count >= cutoff" follows from f != 0 */
-            const u64 m = __ballot (keep);
+            const u64 m = __builtin_amdgcn_ballot_w64 (keep);
             if (lane == 0) sh.kmask[0][chunk] = m;
             acc_sum0 += keep ? f : 0u;
           } else if (FAST && OPS == 4) {
             f = xa;                                              /* SUBTRACT with f2 == 0 */
             const bool keep = (kind & KIND_A) != 0 && xb == 0u && xa != 0u; /* cutoff 1: f1 >= 1 && f2 < 1 */
-            const u64 m = __ballot (keep);
+            const u64 m = __builtin_amdgcn_ballot_w64 (keep);
             if (lane == 0) sh.kmask[2][chunk] = m;
             acc_sum2 += keep ? f : 0u;
           } else if (FAST && OPS == 2) {
             f = xa < xb ? xa : xb;                               /* MIN */
             const bool keep = kind == KIND_BOTH && f != 0u;      /* cutoff <= 1: "both counts >= cutoff" follows from min != 0 */
-            const u64 m = __ballot (keep);
+            const u64 m = __builtin_amdgcn_ballot_w64 (keep);
             if (lane == 0) sh.kmask[1][chunk] = m;
             acc_sum1 += keep ? f : 0u;
           } else if (ops & 1u) {
             const bool keep = eval_stream<0> (kind, xa, xb, c0, f);
-            const u64 m = __ballot (keep);
+            const u64 m = __builtin_amdgcn_ballot_w64 (keep);
             if (lane == 0) sh.kmask[0][chunk] = m;
             acc_sum0 += keep ? f : 0u;
           }
           if (!FAST && (ops & 2u)) {
             const bool keep = eval_stream<1> (kind, xa, xb, c1, f);
-            const u64 m = __ballot (keep);
+            const u64 m = __builtin_amdgcn_ballot_w64 (keep);
             if (lane == 0) sh.kmask[1][chunk] = m;
             acc_sum1 += keep ? f : 0u;
           }
           if (!FAST && (ops & 4u)) {
             const bool keep = eval_stream<2> (kind, xa, xb, c2, f);
-            const u64 m = __ballot (keep);
+            const u64 m = __builtin_amdgcn_ballot_w64 (keep);
             if (lane == 0) sh.kmask[2][chunk] = m;
             acc_sum2 += keep ? f : 0u;
           }
           if (!FAST && (ops & 8u)) {
             const bool keep = eval_stream<3> (kind, xa, xb, c3, f);
-            const u64 m = __ballot (keep);
+            const u64 m = __builtin_amdgcn_ballot_w64 (keep);
             if (lane == 0) sh.kmask[3][chunk] = m;
             acc_sum3 += keep ? f : 0u;
           }
@@ -980,7 +980,11 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
     /* cut the value-numbering link between phase 1 and phase 3: without it the compiler keeps every
      * stream's count of every record alive across phase 2 instead of recomputing it (2x the VGPRs) */
 #pragma unroll
-    for (int k = 0; k < IPT; k++) asm volatile ("" : "+v"(fa[k]), "+v"(fb[k]), "+v"(meta[k]));
+    for (int k = 0; k < IPT; k++) {
+      if (OPS == 0) asm volatile ("" : "+v"(fa[k]), "+v"(fb[k]), "+v"(meta[k]));
+      else if (OPS == 1) asm volatile ("" : "+v"(fa[k]), "+v"(meta[k]));
+      else asm volatile ("" : "+v"(fa[k]));
+    }
     if (STAGGER && nxt < ntl) {
       if (G == IPT) fetch_part (tn, 1); /* a single search group: no second group to issue it under */
 #pragma unroll
