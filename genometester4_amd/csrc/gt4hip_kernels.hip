@@ -915,6 +915,28 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
           const u64 okey = (u64) lds32[oat] | ((u64) lds32[oat + 1] << 32);
           const u32 ocnt = lds32[oat + 2];
           const bool matched = in & (okey == ky[u]);
+          if (FAST && (OPS == 2 || OPS == 4)) {
+            /* A-only kernels with the rule folded in: live chunks are A chunks (`in` implies a valid
+             * lane), and the kept records are decided by the match alone */
+            u32 f;
+            bool keep;
+            if (OPS == 2) {
+              f = own[u] < ocnt ? own[u] : ocnt;                  /* MIN */
+              keep = matched && f != 0u;                         /* cutoff <= 1: both counts >= cutoff <=> min != 0 */
+            } else {
+              f = own[u];                                        /* SUBTRACT with f2 == 0 */
+              keep = valid[u] && !(matched && ocnt != 0u) && f != 0u; /* cutoff 1: f1 >= 1 && f2 < 1 */
+            }
+            key[k] = ky[u];
+            fa[k] = f;
+            fb[k] = 0;
+            meta[k] = 0;
+            const u64 m = __builtin_amdgcn_ballot_w64 (keep);
+            if (lane == 0) sh.kmask[OPS == 2 ? 1 : 2][chunk] = m;
+            if (OPS == 2) acc_sum1 += keep ? f : 0u;
+            else acc_sum2 += keep ? f : 0u;
+            continue;
+          }
           u32 kind, xa, xb;
           if (is_a[u]) {
             kind = matched ? KIND_BOTH : KIND_A;
@@ -937,18 +959,6 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
             const u64 m = __builtin_amdgcn_ballot_w64 (keep);
             if (lane == 0) sh.kmask[0][chunk] = m;
             acc_sum0 += keep ? f : 0u;
-          } else if (FAST && OPS == 4) {
-            f = xa;                                              /* SUBTRACT with f2 == 0 */
-            const bool keep = (kind & KIND_A) != 0 && xb == 0u && xa != 0u; /* cutoff 1: f1 >= 1 && f2 < 1 */
-            const u64 m = __builtin_amdgcn_ballot_w64 (keep);
-            if (lane == 0) sh.kmask[2][chunk] = m;
-            acc_sum2 += keep ? f : 0u;
-          } else if (FAST && OPS == 2) {
-            f = xa < xb ? xa : xb;                               /* MIN */
-            const bool keep = kind == KIND_BOTH && f != 0u;      /* cutoff <= 1: "both counts >= cutoff" follows from min != 0 */
-            const u64 m = __builtin_amdgcn_ballot_w64 (keep);
-            if (lane == 0) sh.kmask[1][chunk] = m;
-            acc_sum1 += keep ? f : 0u;
           } else if (ops & 1u) {
             const bool keep = eval_stream<0> (kind, xa, xb, c0, f);
             const u64 m = __builtin_amdgcn_ballot_w64 (keep);
