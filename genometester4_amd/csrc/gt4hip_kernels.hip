@@ -937,6 +937,20 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
             else acc_sum2 += keep ? f : 0u;
             continue;
           }
+          if (FAST && OPS == 1) {
+            /* union with ADD folded in: an A record carries its partner's count, a B record with a
+             * partner keeps nothing; FAST == 2 (intermediate N-way level) keeps zero sums too */
+            const u32 f = is_a[u] ? own[u] + (matched ? ocnt : 0u) : own[u];
+            const bool keep = valid[u] && (is_a[u] || !matched) && (FAST == 2 || f != 0u);
+            key[k] = ky[u];
+            fa[k] = f;
+            fb[k] = 0;
+            meta[k] = r | (is_a[u] << 18);
+            const u64 m = __builtin_amdgcn_ballot_w64 (keep);
+            if (lane == 0) sh.kmask[0][chunk] = m;
+            acc_sum0 += keep ? f : 0u;
+            continue;
+          }
           u32 kind, xa, xb;
           if (is_a[u]) {
             kind = matched ? KIND_BOTH : KIND_A;
@@ -953,13 +967,7 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
           fb[k] = xb;
           meta[k] = (OPS == 2 || OPS == 4) ? 0u : (r | (kind << 16) | (is_a[u] << 18)); /* A-only kernels place by the own prefix alone */
           u32 f;
-          if (FAST && OPS == 1) {
-            f = xa + xb;                                         /* ADD (u32 wrap), :433-455 */
-            const bool keep = kind != KIND_SKIP && (FAST == 2 || f != 0u); /* cutoff <= 1: "either count >= cutoff" follows from f != 0 */
-            const u64 m = __builtin_amdgcn_ballot_w64 (keep);
-            if (lane == 0) sh.kmask[0][chunk] = m;
-            acc_sum0 += keep ? f : 0u;
-          } else if (ops & 1u) {
+          if (ops & 1u) {
             const bool keep = eval_stream<0> (kind, xa, xb, c0, f);
             const u64 m = __builtin_amdgcn_ballot_w64 (keep);
             if (lane == 0) sh.kmask[0][chunk] = m;
