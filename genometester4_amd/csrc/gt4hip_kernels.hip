@@ -475,9 +475,12 @@ __device__ __forceinline__ void scatter_stream (Shared &sh, u32 *dst32, const Pa
 #pragma unroll
   for (int k = 0; k < IPT; k++) {
     const u32 chunk = (u32) k * NW + (u32) wid;
-    const u64 m = sh.kmask[S][chunk];
-    if ((m >> lane) & 1ull) {
-      const u32 own = sh.cpre[S][chunk] + (u32) __popcll (m & ((1ull << lane) - 1ull));
+    /* the chunk's ballot is the same in every lane: as a scalar it IS the lane mask of the kept
+     * records (no per-lane bit test) and the count of kept lanes below is one mbcnt pair */
+    const u64 mv = sh.kmask[S][chunk];
+    const u32 m_lo = __builtin_amdgcn_readfirstlane ((u32) mv), m_hi = __builtin_amdgcn_readfirstlane ((u32) (mv >> 32));
+    if (__builtin_amdgcn_inverse_ballot_w64 (((u64) m_hi << 32) | m_lo)) {
+      const u32 own = sh.cpre[S][chunk] + __builtin_amdgcn_mbcnt_hi (m_hi, __builtin_amdgcn_mbcnt_lo (m_lo, 0u));
       u32 slot = own;
       if (!A_ONLY) { /* (A-only streams: nothing of the other list comes before) */
         const u32 r = meta[k] & 0xffffu;
