@@ -120,6 +120,25 @@ __device__ __forceinline__ bool eval_stream (u32 kind, u32 fa, u32 fb, const Str
   return keep;
 }
 
+/* The reference predicates with every stream's DEFAULT rule (union ADD, intersection MIN,
+ * complements SUBTRACT; no -du) and any cutoff, written out: what eval_stream computes through its
+ * coefficient form when glistcompare is run without -r (src/glistcompare.c:459-489). */
+template <int S>
+__device__ __forceinline__ bool eval_default (u32 kind, u32 fa, u32 fb, u32 cutoff, u32 &freq)
+{
+  if (S == 0) {
+    freq = fa + fb;
+    return kind != KIND_SKIP && (fa >= cutoff || fb >= cutoff) && freq != 0u;
+  }
+  if (S == 1) {
+    freq = fa < fb ? fa : fb;
+    return kind == KIND_BOTH && freq >= cutoff && freq != 0u; /* both >= cutoff <=> min >= cutoff */
+  }
+  const u32 f1 = S == 3 ? fb : fa, f2 = S == 3 ? fa : fb;
+  freq = f1 - f2; /* kept only when f1 >= cutoff > f2 */
+  return (kind & (S == 2 ? KIND_A : KIND_B)) != 0 && f1 >= cutoff && f2 < cutoff && freq != 0u;
+}
+
 /* ------------------------------------------------------------------ K1: partition */
 
 /* Number of A records among the first `diag` records of merge(A, B) with A first on ties,
@@ -464,7 +483,7 @@ __device__ __forceinline__ u32 kept_before (const u64 *km, const u32 *cp, u32 z)
   return cp[c] + (u32) __popcll (km[c] & ((1ull << (z & 63u)) - 1ull));
 }
 
-template <int S, int NT, int IPT, int OPS, class Shared>
+template <int S, int NT, int IPT, int OPS, int FAST, class Shared>
 __device__ __forceinline__ void scatter_stream (Shared &sh, u32 *dst32, const PairParams &p, u32 nbs, int lane, int wid,
                                                 const u64 (&key)[IPT], const u32 (&fa)[IPT], const u32 (&fb)[IPT], const u32 (&meta)[IPT])
 {
@@ -489,6 +508,7 @@ __device__ __forceinline__ void scatter_stream (Shared &sh, u32 *dst32, const Pa
       }
       u32 f;
       if (OPS != 0) f = fa[k]; /* single-output kernels carry the stream's count itself */
+      else if (FAST) eval_default<S> ((meta[k] >> 16) & 3u, fa[k], fb[k], p.cutoff, f);
       else eval_stream<S> ((meta[k] >> 16) & 3u, fa[k], fb[k], c, f);
       dst32[3 * slot] = (u32) key[k];
       dst32[3 * slot + 1] = (u32) (key[k] >> 32);
@@ -971,25 +991,25 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
           meta[k] = (OPS == 2 || OPS == 4) ? 0u : (r | (kind << 16) | (is_a[u] << 18)); /* A-only kernels place by the own prefix alone */
           u32 f;
           if (ops & 1u) {
-            const bool keep = eval_stream<0> (kind, xa, xb, c0, f);
+            const bool keep = (FAST && OPS == 0) ? eval_default<0> (kind, xa, xb, p.cutoff, f) : eval_stream<0> (kind, xa, xb, c0, f);
             const u64 m = __builtin_amdgcn_ballot_w64 (keep);
             if (lane == 0) sh.kmask[0][chunk] = m;
             acc_sum0 += keep ? f : 0u;
           }
-          if (!FAST && (ops & 2u)) {
-            const bool keep = eval_stream<1> (kind, xa, xb, c1, f);
+          if ((!FAST || OPS == 0) && (ops & 2u)) {
+            const bool keep = (FAST && OPS == 0) ? eval_default<1> (kind, xa, xb, p.cutoff, f) : eval_stream<1> (kind, xa, xb, c1, f);
             const u64 m = __builtin_amdgcn_ballot_w64 (keep);
             if (lane == 0) sh.kmask[1][chunk] = m;
             acc_sum1 += keep ? f : 0u;
           }
-          if (!FAST && (ops & 4u)) {
-            const bool keep = eval_stream<2> (kind, xa, xb, c2, f);
+          if ((!FAST || OPS == 0) && (ops & 4u)) {
+            const bool keep = (FAST && OPS == 0) ? eval_default<2> (kind, xa, xb, p.cutoff, f) : eval_stream<2> (kind, xa, xb, c2, f);
             const u64 m = __builtin_amdgcn_ballot_w64 (keep);
             if (lane == 0) sh.kmask[2][chunk] = m;
             acc_sum2 += keep ? f : 0u;
           }
-          if (!FAST && (ops & 8u)) {
-            const bool keep = eval_stream<3> (kind, xa, xb, c3, f);
+          if ((!FAST || OPS == 0) && (ops & 8u)) {
+            const bool keep = (FAST && OPS == 0) ? eval_default<3> (kind, xa, xb, p.cutoff, f) : eval_stream<3> (kind, xa, xb, c3, f);
             const u64 m = __builtin_amdgcn_ballot_w64 (keep);
             if (lane == 0) sh.kmask[3][chunk] = m;
             acc_sum3 += keep ? f : 0u;
@@ -1078,17 +1098,17 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
         if (!((ops >> s) & 1u)) continue;
         u32 *const dst = sh.stage[0] + 3 * g_off[s];
         switch (s) {
-          case 0: scatter_stream<0, NT, IPT, OPS> (sh, dst, p, nbs, lane, wid, key, fa, fb, meta); break;
-          case 1: scatter_stream<1, NT, IPT, OPS> (sh, dst, p, nbs, lane, wid, key, fa, fb, meta); break;
-          case 2: scatter_stream<2, NT, IPT, OPS> (sh, dst, p, nbs, lane, wid, key, fa, fb, meta); break;
-          default: scatter_stream<3, NT, IPT, OPS> (sh, dst, p, nbs, lane, wid, key, fa, fb, meta); break;
+          case 0: scatter_stream<0, NT, IPT, OPS, FAST> (sh, dst, p, nbs, lane, wid, key, fa, fb, meta); break;
+          case 1: scatter_stream<1, NT, IPT, OPS, FAST> (sh, dst, p, nbs, lane, wid, key, fa, fb, meta); break;
+          case 2: scatter_stream<2, NT, IPT, OPS, FAST> (sh, dst, p, nbs, lane, wid, key, fa, fb, meta); break;
+          default: scatter_stream<3, NT, IPT, OPS, FAST> (sh, dst, p, nbs, lane, wid, key, fa, fb, meta); break;
         }
       }
     } else if (DEFER) {
       /* stage this tile in the slot the write-out at the top of this iteration freed */
       u32 *const slot = sh.stage[it % LAG];
       const u32 my_tot = my_total;
-      scatter_stream<S0, NT, IPT, OPS> (sh, slot, p, nbs, lane, wid, key, fa, fb, meta);
+      scatter_stream<S0, NT, IPT, OPS, FAST> (sh, slot, p, nbs, lane, wid, key, fa, fb, meta);
 #pragma unroll
       for (int q = 0; q + 1 < LAG; q++) pend_tot[q] = pend_tot[q + 1];
       pend_tot[LAG - 1] = my_tot;
@@ -1356,7 +1376,11 @@ static hipError_t launch_pair_merge_ops (hipStream_t s, int mode, int grid, cons
   } else if (p.filter == FILTER_RAW && OPS == 1 && p.rule[0] == 1u) {
     fast = 2;
   }
-  constexpr int F1 = OPS ? 1 : 0, F2 = OPS == 1 ? 2 : 0;
+  /* any combination of outputs with every requested stream on its default rule, any cutoff, no -du */
+  if (OPS == 0 && p.filter == FILTER_REFERENCE && !p.subtract && (!(p.ops & 1u) || p.rule[0] == 1u) && (!(p.ops & 2u) || p.rule[1] == 3u) &&
+      (!(p.ops & 4u) || p.rule[2] == 2u) && (!(p.ops & 8u) || p.rule[3] == 2u))
+    fast = 1;
+  constexpr int F1 = 1, F2 = OPS == 1 ? 2 : 0;
 #define GT4_LAUNCH_MERGE(M, F) hipLaunchKernelGGL ((k_pair_merge<NT, merge_ipt (NT, OPS), M, OPS, F>), dim3 (grid), dim3 (NT), 0, s, A, nA, B, nB, (u64 *) part, num_tiles, p, o, desc, ctl)
   if (mode == MODE_COUNT) {
     if (fast == 1 && F1) GT4_LAUNCH_MERGE (MODE_COUNT, F1);
