@@ -630,8 +630,9 @@ __device__ __forceinline__ u64 uniform64 (u64 v)
 /* FAST != 0 (single-output kernels, chosen by the launcher from the call's parameters): the count
  * rule and keep test of the commonest calls as two or three instructions instead of the general
  * coefficient form -- 1: the reference predicate with the operation's default rule (union: ADD,
- * intersection: MIN, both with cutoff <= 1; first complement: SUBTRACT, cutoff 1, no -du);
- * 2: ADD keeping every key (intermediate N-way union levels). */
+ * intersection: MIN, first complement: SUBTRACT without -du; any-combination kernel: every
+ * requested stream on its default rule), any cutoff; 2: ADD keeping every key (intermediate
+ * N-way union levels). */
 template <int NT, int IPT, int MODE, int OPS, int FAST = 0>
 __global__ __launch_bounds__ (NT, merge_waves_per_simd (NT, MODE)) void
 k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 nB, u64 *part, u64 num_tiles,
@@ -945,10 +946,11 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
             bool keep;
             if (OPS == 2) {
               f = own[u] < ocnt ? own[u] : ocnt;                  /* MIN */
-              keep = matched && f != 0u;                         /* cutoff <= 1: both counts >= cutoff <=> min != 0 */
+              keep = matched && f >= (p.cutoff ? p.cutoff : 1u); /* both counts >= cutoff <=> min >= cutoff; and min != 0 */
             } else {
-              f = own[u];                                        /* SUBTRACT with f2 == 0 */
-              keep = valid[u] && !(matched && ocnt != 0u) && f != 0u; /* cutoff 1: f1 >= 1 && f2 < 1 */
+              const u32 xb = matched ? ocnt : 0u;
+              f = own[u] - xb;                                   /* SUBTRACT: kept only when f1 >= cutoff > f2 */
+              keep = valid[u] && own[u] >= p.cutoff && xb < p.cutoff && f != 0u;
             }
             key[k] = ky[u];
             fa[k] = f;
@@ -963,8 +965,9 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
           if (FAST && OPS == 1) {
             /* union with ADD folded in: an A record carries its partner's count, a B record with a
              * partner keeps nothing; FAST == 2 (intermediate N-way level) keeps zero sums too */
-            const u32 f = is_a[u] ? own[u] + (matched ? ocnt : 0u) : own[u];
-            const bool keep = valid[u] && (is_a[u] || !matched) && (FAST == 2 || f != 0u);
+            const u32 xo = (is_a[u] && matched) ? ocnt : 0u; /* the partner's count travels with the A record */
+            const u32 f = own[u] + xo;
+            const bool keep = valid[u] && (is_a[u] || !matched) && (FAST == 2 || ((own[u] >= p.cutoff || xo >= p.cutoff) && f != 0u));
             key[k] = ky[u];
             fa[k] = f;
             fb[k] = 0;
@@ -1370,9 +1373,9 @@ static hipError_t launch_pair_merge_ops (hipStream_t s, int mode, int grid, cons
   /* the commonest single-output calls take the variant with the rule folded in (see FAST) */
   int fast = 0;
   if (p.filter == FILTER_REFERENCE) {
-    if (OPS == 1 && p.rule[0] == 1u && p.cutoff <= 1u) fast = 1;
-    if (OPS == 2 && p.rule[1] == 3u && p.cutoff <= 1u) fast = 1;
-    if (OPS == 4 && p.rule[2] == 2u && p.cutoff == 1u && !p.subtract) fast = 1;
+    if (OPS == 1 && p.rule[0] == 1u) fast = 1;
+    if (OPS == 2 && p.rule[1] == 3u) fast = 1;
+    if (OPS == 4 && p.rule[2] == 2u && !p.subtract) fast = 1;
   } else if (p.filter == FILTER_RAW && OPS == 1 && p.rule[0] == 1u) {
     fast = 2;
   }
