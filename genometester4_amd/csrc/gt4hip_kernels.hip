@@ -631,8 +631,8 @@ __device__ __forceinline__ u64 uniform64 (u64 v)
  * rule and keep test of the commonest calls as two or three instructions instead of the general
  * coefficient form -- 1: the reference predicate with the operation's default rule (union: ADD,
  * intersection: MIN, first complement: SUBTRACT without -du; any-combination kernel: every
- * requested stream on its default rule), any cutoff; 2: ADD keeping every key (intermediate
- * N-way union levels). */
+ * requested stream on its default rule), any cutoff; 2 / 3: ADD keeping every key / every sum
+ * >= cutoff (intermediate and final N-way union levels). */
 template <int NT, int IPT, int MODE, int OPS, int FAST = 0>
 __global__ __launch_bounds__ (NT, merge_waves_per_simd (NT, MODE)) void
 k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 nB, u64 *part, u64 num_tiles,
@@ -967,7 +967,8 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
              * partner keeps nothing; FAST == 2 (intermediate N-way level) keeps zero sums too */
             const u32 xo = (is_a[u] && matched) ? ocnt : 0u; /* the partner's count travels with the A record */
             const u32 f = own[u] + xo;
-            const bool keep = valid[u] && (is_a[u] || !matched) && (FAST == 2 || ((own[u] >= p.cutoff || xo >= p.cutoff) && f != 0u));
+            const bool keep = valid[u] && (is_a[u] || !matched) &&
+                              (FAST == 2 || (FAST == 3 ? f >= p.cutoff : ((own[u] >= p.cutoff || xo >= p.cutoff) && f != 0u)));
             key[k] = ky[u];
             fa[k] = f;
             fb[k] = 0;
@@ -1376,22 +1377,24 @@ static hipError_t launch_pair_merge_ops (hipStream_t s, int mode, int grid, cons
     if (OPS == 1 && p.rule[0] == 1u) fast = 1;
     if (OPS == 2 && p.rule[1] == 3u) fast = 1;
     if (OPS == 4 && p.rule[2] == 2u && !p.subtract) fast = 1;
-  } else if (p.filter == FILTER_RAW && OPS == 1 && p.rule[0] == 1u) {
-    fast = 2;
+  } else if (OPS == 1 && p.rule[0] == 1u) {
+    fast = p.filter == FILTER_RAW ? 2 : 3; /* N-way union levels: keep every key / keep sums >= cutoff (union_multi, :574) */
   }
   /* any combination of outputs with every requested stream on its default rule, any cutoff, no -du */
   if (OPS == 0 && p.filter == FILTER_REFERENCE && !p.subtract && (!(p.ops & 1u) || p.rule[0] == 1u) && (!(p.ops & 2u) || p.rule[1] == 3u) &&
       (!(p.ops & 4u) || p.rule[2] == 2u) && (!(p.ops & 8u) || p.rule[3] == 2u))
     fast = 1;
-  constexpr int F1 = 1, F2 = OPS == 1 ? 2 : 0;
+  constexpr int F1 = 1, F2 = OPS == 1 ? 2 : 0, F3 = OPS == 1 ? 3 : 0;
 #define GT4_LAUNCH_MERGE(M, F) hipLaunchKernelGGL ((k_pair_merge<NT, merge_ipt (NT, OPS), M, OPS, F>), dim3 (grid), dim3 (NT), 0, s, A, nA, B, nB, (u64 *) part, num_tiles, p, o, desc, ctl)
   if (mode == MODE_COUNT) {
     if (fast == 1 && F1) GT4_LAUNCH_MERGE (MODE_COUNT, F1);
     else if (fast == 2 && F2) GT4_LAUNCH_MERGE (MODE_COUNT, F2);
+    else if (fast == 3 && F3) GT4_LAUNCH_MERGE (MODE_COUNT, F3);
     else GT4_LAUNCH_MERGE (MODE_COUNT, 0);
   } else if (mode == MODE_LOOKBACK) {
     if (fast == 1 && F1) GT4_LAUNCH_MERGE (MODE_LOOKBACK, F1);
     else if (fast == 2 && F2) GT4_LAUNCH_MERGE (MODE_LOOKBACK, F2);
+    else if (fast == 3 && F3) GT4_LAUNCH_MERGE (MODE_LOOKBACK, F3);
     else GT4_LAUNCH_MERGE (MODE_LOOKBACK, 0);
   } else {
     GT4_LAUNCH_MERGE (MODE_OFFSETS, 0); /* second pass of the two-pass path: general form only */
