@@ -472,7 +472,7 @@ struct RankShared {
   u32 cpre[4][NCH + 1];   /* exclusive prefix of popcount(kmask) over chunks, per stream               */
   u64 excl[4];            /* global exclusive output offset of the tile being written out              */
   u32 tot[4];             /* records the current tile keeps, per stream                                */
-  u32 tick[3];            /* ticket ring: the tile in flight, the next one, the one after               */
+  u32 tick[3];            /* [0]: role election scratch (tile ids themselves are arithmetic: static dealing)      */
   u64 rng[3][4];          /* their record ranges {a0, b0, a1, b1} (part[] entries), fetched ahead        */
 };
 
@@ -699,22 +699,21 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
    * is processed, the records of tile i+1 are in flight and the range of tile i+2 is being read. */
   const u32 n_workers = MODE == MODE_LOOKBACK ? gridDim.x - 1 : gridDim.x;
   const u32 wk = MODE == MODE_LOOKBACK ? role - 1 : blockIdx.x;
-  u32 n_claimed = 0; /* thread 0 */
   const u32 ntl = (u32) num_tiles; /* the host refuses calls with 2^32 - 1 tiles or more */
-  auto claim = [&] () -> u32 {
-    const u64 t = (u64) wk + (u64) (n_claimed++) * n_workers;
+  /* static dealing: the tile of iteration j is known without asking anybody (0xffffffff: none) */
+  auto tile_at = [&] (int j) -> u32 {
+    const u64 t = (u64) wk + (u64) j * n_workers;
     return t < num_tiles ? (u32) t : 0xffffffffu;
   };
   if (tid == 0) {
-    for (int q = 0; q < 3; q++) {
-      const u32 t = claim ();
-      sh.tick[q] = t;
-      if (q < 2 && t < ntl)
+    for (int q = 0; q < 2; q++) {
+      const u32 t = tile_at (q);
+      if (t < ntl)
         for (int i = 0; i < 4; i++) sh.rng[q][i] = part[2 * (u64) t + i];
     }
   }
   __syncthreads ();
-  u32 cur = uniform32 (sh.tick[0]);
+  u32 cur = tile_at (0);
   TileRange tr = { 0, 0, 0, 0 };
   if (cur < ntl) {
     tr.a0 = uniform64 (sh.rng[0][0]);
@@ -815,8 +814,8 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
     PHASE_STAMP (0); /* phase 0: wait for the prefetched records, LDS writes */
     __syncthreads (); /* B0 */
     PHASE_STAMP (1); /* barrier B0 */
-    const int s_nxt = (it + 1) % 3, s_nn = (it + 2) % 3, s_cur = it % 3;
-    const u32 nxt = uniform32 (sh.tick[s_nxt]);
+    const int s_nxt = (it + 1) % 3, s_nn = (it + 2) % 3;
+    const u32 nxt = tile_at (it + 1);
     TileRange tn = { 0, 0, 0, 0 };
     if (nxt < ntl) {
       tn.a0 = uniform64 (sh.rng[s_nxt][0]);
@@ -825,12 +824,10 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
       tn.nb = uniform32 ((u32) (sh.rng[s_nxt][3] - sh.rng[s_nxt][1]));
     }
     /* housekeeping by thread 0, results consumed at the end of this iteration */
-    u32 hk_ticket = 0;
     u64 hk_rng[4] = { 0, 0, 0, 0 };
     bool hk_have_rng = false;
     if (tid == 0) {
-      hk_ticket = claim ();
-      const u32 tnn = sh.tick[s_nn];
+      const u32 tnn = tile_at (it + 2);
       if (tnn < ntl) {
         hk_have_rng = true;
 #pragma unroll
@@ -1127,7 +1124,6 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
     }
     PHASE_STAMP (6); /* (any-combination kernel: previous tile's write-out, B2) staging scatter */
     if (tid == 0) {
-      sh.tick[s_cur] = hk_ticket; /* becomes the "after next" ticket of the next iteration */
       if (hk_have_rng) {
 #pragma unroll
         for (int i = 0; i < 4; i++) sh.rng[s_nn][i] = hk_rng[i];
