@@ -510,6 +510,15 @@ static int run_pair (gt4hip_context *ctx, const uint32_t *A, uint64_t nA, const 
     run->n_words[2] = run->total_count[2] = 0;
     return rc;
   }
+  if (p_in.ops == 2u && nA > nB && p_in.rule[1] != 2u && p_in.rule[1] != RULE_MINZ) {
+    /* an intersection searches with the records of its first list: let that be the shorter one.
+     * Keep test and every rule but SUBTRACT / the N-way running MIN are symmetric in (f1, f2);
+     * FIRST and SECOND trade places. */
+    PairParams q = p_in;
+    if (q.rule[1] == 5u) q.rule[1] = 6u;
+    else if (q.rule[1] == 6u) q.rule[1] = 5u;
+    return run_pair (ctx, B, nB, A, nA, q, count_only, dst, run, force_two_pass);
+  }
   PairParams p = p_in;
   p.spin_limit = ctx->spin_limit;
   memset (run, 0, sizeof *run);
