@@ -735,13 +735,8 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
    * up in front of the CU's one address unit. */
   auto fetch_part = [&] (const TileRange &t, int j) {
     const u32 da = 3 * t.na, db = 3 * t.nb, cA = (da + 3) >> 2;
-#ifdef GT4_EXP_SAME_TILE /* timing experiment: every fetch hits the same (cached) addresses; results are wrong */
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc ((void *) (A + 3 * (t.a0 & 0xfffff)), 0, (int) (4 * da), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc ((void *) (B + 3 * (t.b0 & 0xfffff)), 0, (int) (4 * db), 0x00020000);
-#else
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc ((void *) (A + 3 * t.a0), 0, (int) (4 * da), 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc ((void *) (B + 3 * t.b0), 0, (int) (4 * db), 0x00020000);
-#endif
 #pragma unroll
     for (int jj = 0; jj < NLOAD4; jj++) {
       if (jj != j) continue;
@@ -845,9 +840,7 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
     const bool n_have = LAG > 1 && it >= LAG - 1;        /* written out next iteration */
     const u32 n_tile = tile_of_iter (it - (LAG - 1));
     if (DEFER && w_have) {
-#ifndef GT4_EXP_NO_WRITEOUT
       write_out_tile<NT> (outs.rec[S0], uniform64 (sh.excl[S0]), w_tot, sh.stage[it % LAG], tid);
-#endif
     }
     /* wave 4 asks now for the words the next write-out needs (row counts and row carry of the
      * tile in the next slot, published LAG - 1 iterations ago) and resolves them in phase 2 */
