@@ -1386,7 +1386,10 @@ static hipError_t launch_pair_merge_ops (hipStream_t s, int mode, int grid, cons
     else if (fast == 3 && F3) GT4_LAUNCH_MERGE (MODE_LOOKBACK, F3);
     else GT4_LAUNCH_MERGE (MODE_LOOKBACK, 0);
   } else {
-    GT4_LAUNCH_MERGE (MODE_OFFSETS, 0); /* second pass of the two-pass path: general form only */
+    if (fast == 1 && F1) GT4_LAUNCH_MERGE (MODE_OFFSETS, F1);
+    else if (fast == 2 && F2) GT4_LAUNCH_MERGE (MODE_OFFSETS, F2);
+    else if (fast == 3 && F3) GT4_LAUNCH_MERGE (MODE_OFFSETS, F3);
+    else GT4_LAUNCH_MERGE (MODE_OFFSETS, 0);
   }
 #undef GT4_LAUNCH_MERGE
   return hipGetLastError ();
