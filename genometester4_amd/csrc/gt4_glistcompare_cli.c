@@ -11,6 +11,7 @@
  *     the sorted k-mer lists they contain, as in the reference);
  *   - --stream and --disable_scouts are accepted and ignored (the whole list is uploaded to HBM;
  *     results are identical for well-formed files);
+ *   - GT4HIP_CHECK_SORTED=1 rejects an input that is not strictly ascending (the reference trusts it);
  *   - without a usable GPU the program fails: there is no CPU fallback.
  */
 #define _GNU_SOURCE
@@ -355,6 +356,15 @@ int main (int argc, const char *argv[])
                              : gt4hip_list_upload (ctx, files[f].records, files[f].header.n_words, wlen, &lists[f])) {
       fprintf (stderr, "Error: uploading %s to the GPU failed: %s\n", fnames[f], gt4hip_last_error (ctx));
       exit (1);
+    }
+    /* the reference trusts its inputs to be strictly ascending (results are undefined otherwise);
+     * GT4HIP_CHECK_SORTED=1 verifies that on the device before merging */
+    if (getenv ("GT4HIP_CHECK_SORTED") && atoi (getenv ("GT4HIP_CHECK_SORTED"))) {
+      int sorted = 0;
+      if (gt4hip_list_is_sorted (ctx, lists[f], &sorted) || !sorted) {
+        fprintf (stderr, "Error: File %s is not sorted by k-mer (strictly ascending, unique)\n", fnames[f]);
+        exit (1);
+      }
     }
   }
 

@@ -98,3 +98,18 @@ def test_set_operations_entry_points_match_reference(case, workdir):
     """gt4_write_union / gt4_union / gt4_is_union (include/gt4_set_operations.h) through
     examples/setops_driver.c vs the reference's set-operations.c through oracle/ref_setops_driver.c."""
     _check(case, SETOPS, workdir)
+
+
+@pytest.mark.gpu
+def test_cli_can_check_that_inputs_are_sorted(workdir):
+    import numpy as np
+    rec, k, _ = INPUTS["A8"]
+    bad = rec.copy()
+    bad[[3, 4]] = bad[[4, 3]]
+    write_list(os.path.join(workdir, "unsorted.list"), bad, k)
+    env = dict(os.environ, GT4HIP_CHECK_SORTED="1")
+    p = subprocess.run([CLI, "A8.list", "unsorted.list", "-u", "--count_only"], cwd=workdir, capture_output=True, env=env)
+    assert p.returncode == 1 and b"unsorted.list is not sorted" in p.stderr
+    p = subprocess.run([CLI, "A8.list", "B8.list", "-u", "--count_only"], cwd=workdir, capture_output=True, env=env)
+    assert p.returncode == 0
+    os.remove(os.path.join(workdir, "unsorted.list"))
