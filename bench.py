@@ -14,7 +14,13 @@ all-gathered over RCCL; scaling is weak.
 Prints ONE JSON line on rank 0.  `roofline` is computed from the merge kernel's own HIP-event time
 (recorded by the library on the stream it launches on); `cpu_baseline` times the REFERENCE binary
 (oracle/_ref/glistcompare, `kind: reference`) or, when that is absent, the C oracle (`kind: port`)
-on a bounded prefix sample of the same lists.
+on a bounded prefix sample of the same lists -- `--count_only` (the pure merge loop) and, on a
+smaller prefix, the file-writing variant (BASELINE.md protocol).  `verified`: after the timed loop
+the GPU runs the same operation on exactly the CPU sample and its (n_words, total_count) must equal
+what the reference binary printed.
+
+`--workload c2` is BASELINE configs[2]: union + first complement with cutoff 3 on the same pair
+(the any-combination kernel, two simultaneous output streams).
 """
 import argparse
 import json
@@ -57,18 +63,43 @@ def build_lists(ctx, capi, n, k, seed_base):
     return a, b
 
 
-def cpu_baseline(ctx, a, b, k, sample_records):
-    """Times the reference CPU path on a prefix sample covering the same key range of both lists."""
-    import numpy as np
+def _ref_flags(ops, cutoff):
+    f = []
+    if ops & 1:
+        f.append("-u")
+    if ops & 2:
+        f.append("-i")
+    if ops & 4:
+        f.append("-d")
+    if cutoff != 1:
+        f += ["-c", str(cutoff)]
+    return f
+
+
+def _parse_count_only(stdout):
+    """`NUnique\t<n>\nNTotal\t<t>\n` per requested op, in the order union, intrsec, diff1 (reference
+    src/glistcompare.c:916-952) -> [(n, t), ...]"""
+    vals = [int(line.split("\t")[1]) for line in stdout.strip().split("\n") if "\t" in line]
+    return list(zip(vals[0::2], vals[1::2]))
+
+
+def cpu_baseline(ctx, capi, a, b, k, sample_records, ops, cutoff):
+    """Times the reference CPU path on a prefix sample covering the same key range of both lists,
+    then runs the GPU on exactly that sample and compares the totals (`verified`)."""
     from genometester4_amd.listio import write_list
     m_a = min(sample_records, a.n_words)
     last_key, _ = a.get_word(m_a - 1)
     m_b = b.lower_bound(last_key + 1) if last_key < 0xFFFFFFFFFFFFFFFF else b.n_words
     ha, hb = a.download_range(0, m_a), b.download_range(0, m_b)
+    flags = _ref_flags(ops, cutoff)
+    # the GPU on the very same sample (device slices of the resident lists)
+    st, _, _ = ctx.compare(a.slice(0, m_a), b.slice(0, m_b), ops, cutoff=cutoff, count_only=True)
+    gpu_totals = [st[bit] for bit in (1, 2, 4) if ops & bit]
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "glistcompare")
-    sample = "first %d + %d records of the same two lists (equal key range), -i --count_only, warm page cache" % (m_a, m_b)
+    sample = "first %d + %d records of the same two lists (equal key range), %s --count_only, warm page cache" % (m_a, m_b, " ".join(flags))
+    nproc = os.cpu_count()
     if os.path.exists(ref_bin) and os.access(ref_bin, os.X_OK):
-        shm = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 13 * (m_a + m_b) else None
+        shm = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 40 * (m_a + m_b) else None
         d = tempfile.mkdtemp(prefix="gt4bench_", dir=shm)
         try:
             write_list(os.path.join(d, "a.list"), ha, k)
@@ -76,14 +107,29 @@ def cpu_baseline(ctx, a, b, k, sample_records):
             times = []
             for _ in range(3):
                 t0 = time.perf_counter()
-                r = subprocess.run([ref_bin, "a.list", "b.list", "-i", "--count_only"], cwd=d, capture_output=True)
+                r = subprocess.run([ref_bin, "a.list", "b.list"] + flags + ["--count_only"], cwd=d, capture_output=True)
                 times.append(time.perf_counter() - t0)
                 if r.returncode != 0:
                     raise RuntimeError("reference glistcompare failed: %s" % r.stderr.decode())
             t = statistics.median(times)
-            return dict(value=(m_a + m_b) / t, unit="k-mers/s", cores=3, kind="reference",
-                        sample=sample + "; reference glistcompare 4.2.16: 1 merge thread + 2 scout threads; median of 3 runs",
-                        stdout=r.stdout.decode().strip().replace("\n", " ").replace("\t", "="))
+            ref_totals = _parse_count_only(r.stdout.decode())
+            # the file-writing variant (output fwrite/write syscalls dominate the reference):
+            # a 10x smaller prefix, files in the same directory, one run
+            w_a, w_b = max(1, m_a // 10), max(1, m_b // 10)
+            write_list(os.path.join(d, "wa.list"), ha[:w_a], k)
+            write_list(os.path.join(d, "wb.list"), hb[:w_b], k)
+            t0 = time.perf_counter()
+            rw = subprocess.run([ref_bin, "wa.list", "wb.list"] + flags + ["-o", "w"], cwd=d, capture_output=True)
+            t_w = time.perf_counter() - t0
+            out_bytes = sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d) if f.startswith("w_"))
+            res = dict(value=(m_a + m_b) / t, unit="k-mers/s", cores=3, host_nproc=nproc, kind="reference",
+                       sample=sample + "; reference glistcompare 4.2.16: 1 merge thread + 2 scout threads (all it can use of the "
+                                       "host's %d logical CPUs); median of 3 runs" % nproc,
+                       stdout=r.stdout.decode().strip().replace("\n", " ").replace("\t", "="),
+                       file_writing=dict(value=(w_a + w_b) / t_w if rw.returncode == 0 else None, unit="k-mers/s",
+                                         sample="first %d + %d records, %s writing %d output bytes to %s, one run"
+                                                % (w_a, w_b, " ".join(flags), out_bytes, "tmpfs" if shm else "the temp dir")))
+            return res, ref_totals == gpu_totals, dict(reference=ref_totals, gpu=gpu_totals)
         finally:
             shutil.rmtree(d, ignore_errors=True)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -91,10 +137,29 @@ def cpu_baseline(ctx, a, b, k, sample_records):
     times = []
     for _ in range(3):
         t0 = time.perf_counter()
-        O.compare(ha, hb, O.OP_INTRSEC, count_only=True)
+        exp = O.compare(ha, hb, ops, cutoff=cutoff, count_only=True)
         times.append(time.perf_counter() - t0)
-    return dict(value=(m_a + m_b) / statistics.median(times), unit="k-mers/s", cores=1, kind="port",
-                sample=sample + "; oracle/gt4_oracle.c scalar restatement, median of 3 runs")
+    ora_totals = [exp[bit][:2] for bit in (1, 2, 4) if ops & bit]
+    res = dict(value=(m_a + m_b) / statistics.median(times), unit="k-mers/s", cores=1, host_nproc=nproc, kind="port",
+               sample=sample + "; oracle/gt4_oracle.c scalar restatement, median of 3 runs")
+    return res, ora_totals == gpu_totals, dict(oracle=ora_totals, gpu=gpu_totals)
+
+
+def load_traffic(workload, n):
+    """HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/
+    (tools/collect_profiles.sh: FETCH_SIZE and WRITE_SIZE cannot be collected inside this run)."""
+    tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % workload)
+    if not os.path.exists(tpath) and workload == "intersect":
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    try:
+        tj = json.load(open(tpath))
+        if tj.get("n_per_list") == n:
+            return tj.get("hbm_bytes_per_launch"), {"file": os.path.relpath(tpath, ROOT), "commit": tj.get("commit"),
+                                                     "kernel": tj.get("kernel"),
+                                                     "note": "replayed from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE), not measured in this run"}
+    except Exception:
+        pass
+    return None, None
 
 
 def union8_roofline(ctx, n_list, n_out_local, device_ms):
@@ -200,9 +265,10 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=200_000_000, help="records per list timed on the CPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--two-pass", action="store_true", help="count+scan+write instead of the single-pass kernel")
-    ap.add_argument("--workload", choices=["intersect", "union8"], default="intersect",
-                    help="intersect: BASELINE configs[1] (default, the headline metric); union8: configs[3], 8-way union "
-                         "sharded by key range over the ranks with an RCCL gatherv to rank 0 (strong scaling)")
+    ap.add_argument("--workload", choices=["intersect", "c2", "union8"], default="intersect",
+                    help="intersect: BASELINE configs[1] (default, the headline metric); c2: configs[2], union + first complement "
+                         "with cutoff 3 on the same pair; union8: configs[3], 8-way union sharded by key range over the ranks "
+                         "with an RCCL gatherv to rank 0 (strong scaling)")
     ap.add_argument("--n8", type=int, default=500_000_000, help="union8: entries per list (whole job)")
     args = ap.parse_args()
 
@@ -222,10 +288,13 @@ def main():
     if args.workload == "union8":
         return bench_union8(args, ctx, capi, rank, local_rank, world)
     n = args.n
+    ops = capi.OP_INTRSEC if args.workload == "intersect" else (capi.OP_UNION | capi.OP_DIFF1)
+    cutoff = 1 if args.workload == "intersect" else 3
+    op_bits = [bit for bit in (1, 2, 4) if ops & bit]
     while True:
         try:
             a, b = build_lists(ctx, capi, n, args.k, 1000 * rank)
-            out = ctx.alloc(n, args.k)
+            outs = {bit: ctx.alloc({1: 2 * n, 2: n, 4: n}[bit], args.k) for bit in op_bits}
             break
         except capi.Gt4HipError as e:
             if e.code != capi.ENOMEM or n < 1_000_000:
@@ -241,8 +310,8 @@ def main():
     n_a, n_b = a.n_words, b.n_words
 
     def step():
-        st, _, timing = ctx.compare(a, b, capi.OP_INTRSEC, out={capi.OP_INTRSEC: out})
-        return st[capi.OP_INTRSEC], timing
+        st, _, timing = ctx.compare(a, b, ops, cutoff=cutoff, out=outs)
+        return st, timing
 
     def fence():
         ctx.synchronize()
@@ -263,7 +332,7 @@ def main():
         device_ms.append(timing["device_ms"])
     fence()
     elapsed = time.perf_counter() - t0
-    totals = [stat[0], stat[1]]
+    totals = [sum(stat[bit][0] for bit in op_bits), sum(stat[bit][1] for bit in op_bits) & 0x7FFFFFFFFFFFFFFF]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -274,21 +343,22 @@ def main():
         totals = [int(sum(x[0].item() for x in g)), int(sum(x[1].item() for x in g))]
 
     if rank == 0:
-        n_out = stat[0]
+        n_out = sum(stat[bit][0] for bit in op_bits)
         k_ms = statistics.mean(kernel_ms)
         alg_bytes = 12 * (n_a + n_b) + 12 * n_out
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                if tj.get("n_per_list") == n:
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                pass
+        traffic, traffic_source = load_traffic(args.workload, n)
+        names = {1: "union", 2: "intrsec", 4: "diff1"}
+        if args.workload == "intersect":
+            metric = "k-mers merged/sec, 2-list k=%d intersection (glistcompare -i), lists resident in HBM" % args.k
+            wl = "single-GPU intersection, two %d-entry k=%d lists (%.1f GB each) per GPU, |A n B| = n/2" % (n, args.k, 12 * n / 1e9)
+            kernel = "k_pair_merge<1024, 6, MODE_LOOKBACK, intersection, folded MIN>"
+        else:
+            metric = "k-mers merged/sec, 2-list k=%d union + first complement, cutoff %d (glistcompare -u -d -c %d), lists resident in HBM" % (args.k, cutoff, cutoff)
+            wl = "single-GPU union + difference_first with --cutoff %d, two %d-entry k=%d lists (%.1f GB each) per GPU, |A n B| = n/2" % (cutoff, n, args.k, 12 * n / 1e9)
+            kernel = "k_pair_merge<1024, 4, MODE_LOOKBACK, any combination of outputs, default rules>"
         res = {
-            "metric": "k-mers merged/sec, 2-list k=%d intersection (glistcompare -i), lists resident in HBM" % args.k,
+            "metric": metric,
             "value": world * (n_a + n_b) * args.steps / elapsed,
             "unit": "k-mers/s",
             "n_gpus": world,
@@ -301,19 +371,18 @@ def main():
             "dtype": "u64 keys + u32 counts",
             "data": "synthetic",
             "config": {
-                "workload": "single-GPU intersection, two %d-entry k=%d lists (%.1f GB each) per GPU, |A n B| = n/2, bit-exact vs CPU"
-                            % (n, args.k, 12 * n / 1e9),
+                "workload": wl,
                 "entries_per_list_per_gpu": n,
                 "word_length": args.k,
-                "output_records": totals[0],
-                "output_total_count": totals[1],
+                "output_records": {names[bit]: stat[bit][0] for bit in op_bits} if world == 1 else totals[0],
+                "output_total_count": {names[bit]: stat[bit][1] for bit in op_bits} if world == 1 else totals[1],
                 "sharding": "one key-range shard per GPU, no data-path collective" if world > 1 else "none",
                 "path": "two_pass" if args.two_pass else "single_pass_lookback",
                 "device": ctx.device_info(),
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_pair_merge",
+                "kernel": kernel,
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -323,13 +392,17 @@ def main():
                 "kernel_ms_avg": k_ms,
                 "device_ms_avg": statistics.mean(device_ms),
                 "traffic": traffic,
+                "traffic_source": traffic_source,
             },
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
-                res["cpu_baseline"] = cpu_baseline(ctx, a, b, args.k, args.cpu_sample)
+                res["cpu_baseline"], res["verified"], res["verified_totals"] = cpu_baseline(ctx, capi, a, b, args.k, args.cpu_sample, ops, cutoff)
             except Exception as e:  # the GPU number stands on its own; say why the CPU leg is missing
                 res["cpu_baseline"] = {"value": None, "unit": "k-mers/s", "cores": 0, "kind": "reference", "sample": "failed: %s" % e}
+                res["verified"] = False
+            if res["verified"] is False and res["cpu_baseline"].get("value") is not None:
+                log("VERIFICATION FAILED: %s" % res.get("verified_totals"))
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

@@ -32,6 +32,8 @@ struct gt4hip_context {
    * merges themselves (an 8-way union tree allocates seven outputs per call) */
   std::vector<std::pair<void *, size_t>> *pool;
   int pool_enabled;
+  size_t pool_bytes;         /* bytes the pool holds right now */
+  size_t pool_cap;           /* most it may hold (option "pool_cap_mb"; default: half of the device memory) */
   /* workspace, grown on demand */
   uint64_t *part;
   size_t part_bytes;
@@ -58,6 +60,8 @@ struct gt4hip_list {
 };
 
 static char g_create_err[512] = "";
+
+static void pool_flush (gt4hip_context *ctx);
 
 static int fail (gt4hip_context *ctx, int code, const char *fmt, ...)
 {
@@ -122,12 +126,15 @@ extern "C" int gt4hip_create (int device, gt4hip_context **out)
   ctx->pool_enabled = ctx->pool != NULL;
   hipDeviceProp_t prop;
   if ((e = hipGetDeviceProperties (&prop, device)) != hipSuccess) {
+    delete ctx->pool;
     delete ctx;
     return fail (NULL, GT4HIP_ENODEVICE, "gt4hip_create: hipGetDeviceProperties: %s", hipGetErrorString (e));
   }
   ctx->n_cus = prop.multiProcessorCount;
+  ctx->pool_cap = prop.totalGlobalMem / 2;
   snprintf (ctx->info, sizeof ctx->info, "%s|%s|%d|%zu", prop.name, prop.gcnArchName, prop.multiProcessorCount, prop.totalGlobalMem);
   if ((e = hipStreamCreateWithFlags (&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
+    delete ctx->pool;
     delete ctx;
     return fail (NULL, GT4HIP_ENODEVICE, "gt4hip_create: hipStreamCreate: %s", hipGetErrorString (e));
   }
@@ -149,7 +156,7 @@ extern "C" void gt4hip_destroy (gt4hip_context *ctx)
   hipSetDevice (ctx->device);
   if (ctx->stream) hipStreamSynchronize (ctx->stream);
   if (ctx->pool) {
-    for (auto &b : *ctx->pool) hipFree (b.first);
+    pool_flush (ctx);
     delete ctx->pool;
   }
   if (ctx->part) hipFree (ctx->part);
@@ -175,10 +182,11 @@ extern "C" int gt4hip_set_option (gt4hip_context *ctx, const char *name, int64_t
   if (!strcmp (name, "two_pass")) ctx->two_pass = value != 0;
   else if (!strcmp (name, "pool")) {
     ctx->pool_enabled = value != 0 && ctx->pool;
-    if (!ctx->pool_enabled && ctx->pool) {
-      for (auto &b : *ctx->pool) hipFree (b.first);
-      ctx->pool->clear ();
-    }
+    if (!ctx->pool_enabled) pool_flush (ctx);
+  }
+  else if (!strcmp (name, "pool_cap_mb")) {
+    ctx->pool_cap = value > 0 ? (size_t) value << 20 : 0;
+    if (ctx->pool_bytes > ctx->pool_cap) pool_flush (ctx);
   }
   else if (!strcmp (name, "grid")) ctx->grid_override = value;
   else if (!strcmp (name, "spin_limit")) ctx->spin_limit = value > 0 ? (uint32_t) value : 0u;
@@ -201,6 +209,30 @@ extern "C" int gt4hip_synchronize (gt4hip_context *ctx)
   if (!ctx) return GT4HIP_EINVAL;
   HIPCHK (ctx, hipStreamSynchronize (ctx->stream));
   return GT4HIP_OK;
+}
+
+/* ------------------------------------------------------------------ device memory */
+
+static void pool_flush (gt4hip_context *ctx)
+{
+  if (!ctx->pool) return;
+  for (auto &b : *ctx->pool) hipFree (b.first);
+  ctx->pool->clear ();
+  ctx->pool_bytes = 0;
+}
+
+/* Every device allocation of the library goes through here: when the driver is out of memory the
+ * pooled blocks (freed list storage kept for reuse) are given back and the allocation is retried. */
+static hipError_t dev_alloc (gt4hip_context *ctx, void **p, size_t bytes)
+{
+  hipError_t e = hipMalloc (p, bytes);
+  if (e != hipSuccess && ctx->pool && !ctx->pool->empty ()) {
+    (void) hipGetLastError ();
+    pool_flush (ctx);
+    e = hipMalloc (p, bytes);
+  }
+  if (e != hipSuccess) (void) hipGetLastError ();
+  return e;
 }
 
 /* ------------------------------------------------------------------ lists */
@@ -230,20 +262,13 @@ static int list_new (gt4hip_context *ctx, uint64_t capacity, uint32_t word_lengt
     if (best != (size_t) -1) {
       l->dev = (*ctx->pool)[best_i].first;
       l->bytes = best;
+      ctx->pool_bytes -= best;
       ctx->pool->erase (ctx->pool->begin () + (long) best_i);
     }
   }
   if (!l->dev) {
-    hipError_t e = hipMalloc (&l->dev, bytes);
-    if (e != hipSuccess && ctx->pool && !ctx->pool->empty ()) {
-      /* give the pooled blocks back and try again */
-      (void) hipGetLastError ();
-      for (auto &b : *ctx->pool) hipFree (b.first);
-      ctx->pool->clear ();
-      e = hipMalloc (&l->dev, bytes);
-    }
+    const hipError_t e = dev_alloc (ctx, &l->dev, bytes);
     if (e != hipSuccess) {
-      (void) hipGetLastError ();
       delete l;
       return fail (ctx, GT4HIP_ENOMEM, "hipMalloc of %zu bytes failed: %s", bytes, hipGetErrorString (e));
     }
@@ -290,7 +315,7 @@ extern "C" int gt4hip_list_upload_index (gt4hip_context *ctx, const void *host_k
   if (rc) return rc;
   if (n_words) {
     void *tmp = NULL;
-    hipError_t e = hipMalloc (&tmp, (size_t) n_words * 16);
+    hipError_t e = dev_alloc (ctx, &tmp, (size_t) n_words * 16);
     if (e != hipSuccess) {
       gt4hip_list_free (l);
       return fail (ctx, GT4HIP_ENOMEM, "hipMalloc of %llu bytes for the index table failed", (unsigned long long) n_words * 16);
@@ -351,8 +376,17 @@ extern "C" void gt4hip_list_free (gt4hip_list *l)
 {
   if (!l) return;
   if (l->owns && l->dev) {
-    if (l->ctx->pool_enabled) {
-      l->ctx->pool->push_back (std::make_pair (l->dev, l->bytes));
+    gt4hip_context *const ctx = l->ctx;
+    if (ctx->pool_enabled && l->bytes <= ctx->pool_cap) {
+      /* the pool never holds more than its cap: the oldest blocks go back to the driver first */
+      while (ctx->pool_bytes + l->bytes > ctx->pool_cap && !ctx->pool->empty ()) {
+        hipSetDevice (ctx->device);
+        hipFree (ctx->pool->front ().first);
+        ctx->pool_bytes -= ctx->pool->front ().second;
+        ctx->pool->erase (ctx->pool->begin ());
+      }
+      ctx->pool->push_back (std::make_pair (l->dev, l->bytes));
+      ctx->pool_bytes += l->bytes;
     } else {
       hipSetDevice (l->ctx->device);
       hipFree (l->dev);
@@ -465,7 +499,7 @@ static int grow (gt4hip_context *ctx, void **p, size_t *have, size_t need)
     *have = 0;
   }
   need += need / 8; /* slack so that slightly larger follow-up calls do not reallocate */
-  hipError_t e = hipMalloc (p, need);
+  hipError_t e = dev_alloc (ctx, p, need);
   if (e != hipSuccess) return fail (ctx, GT4HIP_ENOMEM, "workspace hipMalloc of %zu bytes failed: %s", need, hipGetErrorString (e));
   *have = need;
   return GT4HIP_OK;
@@ -872,8 +906,8 @@ extern "C" int gt4hip_union_table (gt4hip_context *ctx, const gt4hip_list *const
     gt4hip_list_free (u.out);
     return GT4HIP_OK;
   }
-  hipError_t e = hipMalloc (&table->device_keys, (size_t) n * 8);
-  if (e == hipSuccess) e = hipMalloc (&table->device_counts, (size_t) n * n_lists * 4);
+  hipError_t e = dev_alloc (ctx, &table->device_keys, (size_t) n * 8);
+  if (e == hipSuccess) e = dev_alloc (ctx, &table->device_counts, (size_t) n * n_lists * 4);
   if (e != hipSuccess) {
     gt4hip_list_free (u.out);
     gt4hip_table_free (table);
@@ -902,8 +936,8 @@ extern "C" int gt4hip_probe_table (gt4hip_context *ctx, const gt4hip_list *const
   table->n_keys = n;
   if (!n) return GT4HIP_OK;
   HIPCHK (ctx, hipSetDevice (ctx->device));
-  hipError_t e = hipMalloc (&table->device_keys, (size_t) n * 8);
-  if (e == hipSuccess) e = hipMalloc (&table->device_counts, (size_t) n * n_lists * 4);
+  hipError_t e = dev_alloc (ctx, &table->device_keys, (size_t) n * 8);
+  if (e == hipSuccess) e = dev_alloc (ctx, &table->device_counts, (size_t) n * n_lists * 4);
   if (e != hipSuccess) {
     gt4hip_table_free (table);
     return fail (ctx, GT4HIP_ENOMEM, "count table allocation failed: %s", hipGetErrorString (e));

@@ -37,7 +37,7 @@ struct PairOutputs {
 struct PairControl {
   unsigned long long n_words[4];
   unsigned long long total_count[4];
-  unsigned int ticket;     /* tile-group counter of the single-pass kernel */
+  unsigned int pad0;
   unsigned int error;      /* non-zero: a bounded spin gave up / consistency check tripped */
   unsigned int role;       /* first workgroup to arrive becomes the scanner */
   unsigned int pad;

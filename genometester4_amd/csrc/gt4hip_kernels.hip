@@ -354,6 +354,8 @@ __device__ void scanner_wave (u32 *agg, u64 *carry_out, u64 num_tiles, PairContr
       }
 #endif
       if (done >= n) break;
+      /* somebody else gave up (the host reruns the call on the two-pass path): give up at this look too */
+      if ((spins & 63u) == 63u && peek_u32 (&ctl->error)) spins = spin_limit;
       if (++spins > spin_limit) {
         if (lane == 0) atomicOr (&ctl->error, 4u);
         return;
@@ -389,6 +391,11 @@ __device__ __forceinline__ u64 resolve_offset (u32 *agg, u64 *carry, u64 tile, i
       if (lane == 0) atomicOr (&ctl->error, 1u);
       break;
     }
+    /* once any wait of the launch has given up (the scanner stops publishing then) every other wait
+     * ends at its next look instead of spinning to its own bound, so the rest of the launch runs at
+     * its normal pace: the offset returned is not above the true one (stores stay inside the output)
+     * and is not used -- the host discards the outputs and reruns the call on the two-pass path */
+    if ((spins & 15u) == 0 && peek_u32 (&ctl->error)) break;
     if (spins > 1) __builtin_amdgcn_s_sleep (1);
     if (mine && !(a & AGG_READY)) a = peek_u32 (wa);
     if (!(c & CARRY_READY)) c = peek_u64 (wc);

@@ -2,7 +2,7 @@
  * gt4hip.h -- C ABI of the MI355X (gfx950) sorted k-mer list set-operation engine.
  *
  * This is the drop-in boundary between a C host -- the glistcompare CLI in
- * genometester4_amd/csrc/glistcompare.c, or GenomeTester4's own glistcompare.c / glistmaker.c /
+ * genometester4_amd/csrc/gt4_glistcompare_cli.c, or GenomeTester4's own glistcompare.c / glistmaker.c /
  * glistquery.c with the binding shown in INTEGRATION.md -- and the hand-written HIP kernels.
  * Plain C types only; nothing here throws, exits or prints.  Every function returns
  * GT4HIP_OK (0) or a GT4HIP_E* code; gt4hip_last_error() gives the message.
@@ -93,7 +93,8 @@ int gt4hip_list_upload (gt4hip_context *ctx, const void *host_records, uint64_t 
  * num_locations minus its own, truncated to 32 bits.  Decoded on the device. */
 int gt4hip_list_upload_index (gt4hip_context *ctx, const void *host_kmers, uint64_t n_words, uint64_t num_locations,
                               uint32_t word_length, gt4hip_list **out);
-/* Wraps records already in device memory (16-byte aligned); not freed by gt4hip_list_free. */
+/* Wraps records already in device memory (4-byte aligned, as the body of a .list file and every
+ * gt4hip_list_slice are); the storage is not freed by gt4hip_list_free. */
 int gt4hip_list_wrap (gt4hip_context *ctx, void *device_records, uint64_t n_words,
                       uint32_t word_length, gt4hip_list **out);
 /* Uninitialised list with room for `capacity` records (n_words = capacity until set). */
@@ -106,6 +107,8 @@ int gt4hip_list_download (gt4hip_context *ctx, const gt4hip_list *list, void *ho
 /* Copies records [first, first+count) back to host memory. */
 int gt4hip_list_download_range (gt4hip_context *ctx, const gt4hip_list *list, uint64_t first,
                                 uint64_t count, void *host_records);
+/* Lists return their storage to their context's pool: free every list BEFORE gt4hip_destroy of the
+ * context it came from (a list must not outlive its context). */
 void gt4hip_list_free (gt4hip_list *list);
 
 uint64_t gt4hip_list_n_words (const gt4hip_list *list);      /* GT4WordSListInstance.num_words   */
@@ -138,7 +141,8 @@ typedef struct {
   uint64_t n_words[4];     /* records per output (header n_words), 0 for outputs not requested */
   uint64_t total_count[4]; /* sum of counts per output (header total_count)                    */
   /* In: NULL, or a caller-provided list (gt4hip_list_alloc) with enough capacity to receive the
-   * output.  Out: the output records (a new list when NULL was passed; NULL for count_only and
+   * output -- ZERO the struct before the call (memset) unless outputs are provided: a garbage
+   * pointer here is taken for a caller's list.  Out: the output records (a new list when NULL was passed; NULL for count_only and
    * for outputs not requested).  Worst-case capacities: union na+nb, intrsec min(na,nb),
    * diff1 na, diff2 nb. */
   gt4hip_list *out[4];
@@ -215,6 +219,8 @@ int gt4hip_synchronize (gt4hip_context *ctx);
 /* Tuning / debugging knobs (not part of the reference surface):
  *   "two_pass" = 1     count + scan + write instead of the single-pass kernel
  *   "pool" = 0         release freed list storage to the driver instead of pooling it
+ *   "pool_cap_mb" = n  most the pool may hold (default: half of the device memory); every device
+ *                      allocation that fails gives the pooled blocks back and retries
  *   "grid" = n         workgroups of the merge kernel (0: one per resident slot)
  *   "spin_limit" = n   bound of the single-pass kernel's inter-workgroup waits (0: default, ~seconds)
  *   "geom0" / "geom1"  force the 512- / 1024-thread geometry (experiments). */

@@ -1,0 +1,138 @@
+"""Full-size parity (BASELINE.json configs 1, 2 and 4 at their real sizes) on one MI355X.
+
+No CPU oracle finishes 4e9 records in test time, but every set operation is KEY-LOCAL: the result
+for key x depends only on the records with key x.  So besides size-independent identities the GPU
+outputs are checked against the CPU oracle on key WINDOWS: a window [lo, hi) is cut out of both
+inputs by `lower_bound`, the oracle runs on the two slices, and its output must equal, byte for
+byte, the slice of the GPU output between the same two keys.  Windows are placed at the start, around
+record index 2^31 (and 2^32 where a list reaches it), in the middle and at the very end.
+
+Reference: compare_wordmaps hot loop, src/glistcompare.c:843-905; predicates :459-489."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+WINDOW = 400_000  # records of A per window (the oracle takes ~10 ms per 10^6 records)
+
+
+@pytest.fixture()
+def ctx():
+    from genometester4_amd import capi
+    c = capi.Context(0)
+    yield c
+    c.close()  # returns every list and the pool to the driver before the next full-size case
+
+
+def build_pair(ctx, n, k, seed_base=0):
+    """|A| = |B| = n, |A n B| = n // 2 exactly, from three disjoint residue classes (as bench.py)."""
+    from genometester4_amd import capi
+    n_s, n_p = n // 2, n - n // 2
+    s, p = ctx.alloc(n_s, k), ctx.alloc(n_p, k)
+    ctx.generate_ex(s, n_s, seed_base + 11, seed_base + 21, 8, 3, 0)
+    ctx.generate_ex(p, n_p, seed_base + 12, seed_base + 23, 8, 3, 1)
+    a = ctx.compare(s, p, capi.OP_UNION)[1][capi.OP_UNION]
+    ctx.generate_ex(s, n_s, seed_base + 11, seed_base + 22, 8, 3, 0)
+    ctx.generate_ex(p, n_p, seed_base + 13, seed_base + 24, 8, 3, 2)
+    b = ctx.compare(s, p, capi.OP_UNION)[1][capi.OP_UNION]
+    s.free()
+    p.free()
+    assert a.n_words == n and b.n_words == n
+    return a, b
+
+
+def window_starts(n):
+    """Record indices of A at which windows start: both ends, the middle, and the 32-bit edges."""
+    pts = [0, n // 2, max(0, n - WINDOW)]
+    for edge in (1 << 31, 1 << 32):
+        if edge + WINDOW < n:
+            pts.append(edge - WINDOW // 2)
+    return sorted(set(pts))
+
+
+def check_windows(a, b, outs, stats, ops, rule=0, cutoff=1, subtract=0, ovr=1):
+    n = a.n_words
+    checked = 0
+    for i0 in window_starts(n):
+        i1 = min(n, i0 + WINDOW)
+        lo = a.get_word(i0)[0] if i0 else 0
+        to_end = i1 == n
+        hi = None if to_end else a.get_word(i1)[0]
+
+        def cut(lst):
+            first = lst.lower_bound(lo) if lo else 0
+            last = lst.n_words if to_end else lst.lower_bound(hi)
+            return first, last
+
+        fa, la = cut(a)
+        fb, lb = cut(b)
+        assert (fa, la) == (i0, i1)
+        ha, hb = a.download_range(fa, la - fa), b.download_range(fb, lb - fb)
+        exp = O.compare(ha, hb, ops, rule, cutoff, subtract, ovr)
+        for bit, (n_exp, _, recs) in exp.items():
+            fo, lo_ = cut(outs[bit])
+            assert lo_ - fo == n_exp, "op %d window at %d: %d records, oracle %d" % (bit, i0, lo_ - fo, n_exp)
+            got = outs[bit].download_range(fo, lo_ - fo)
+            assert got.tobytes() == recs.tobytes(), "op %d window at %d differs from the oracle" % (bit, i0)
+            checked += n_exp
+    assert checked > 0
+    # header totals against a device-side recount of what was written
+    for bit, (n_words, total) in stats.items():
+        assert outs[bit].n_words == n_words
+        assert outs[bit].sum_counts() == total
+        assert outs[bit].is_sorted()
+
+
+def test_config1_intersection_alone_beyond_2_pow_31(ctx):
+    """The benchmarked specialisation (ops = intersection alone, default rule: the folded 6-position
+    kernel, single pass) with input record indices beyond 2^31: 2 x 2.2e9 k=25 records."""
+    n = 2_200_000_000
+    a, b = build_pair(ctx, n, 25)
+    assert a.is_sorted() and b.is_sorted()
+    st, out, _ = ctx.compare(a, b, 2)
+    assert st[2][0] == n // 2
+    check_windows(a, b, out, st, 2)
+    # the same call on the dependency-free two-pass path gives the same totals
+    ctx.set_option("two_pass", 1)
+    st2, out2, _ = ctx.compare(a, b, 2)
+    ctx.set_option("two_pass", 0)
+    assert st2 == st
+    mid = st[2][0] // 2
+    assert out2[2].download_range(mid, 100000).tobytes() == out[2].download_range(mid, 100000).tobytes()
+
+
+def test_config2_union_and_first_complement_with_cutoff(ctx):
+    """BASELINE config 2 exactly: `-u -d -c 3` on the 2 x 2e9 k=25 pair (any-combination kernel, two
+    simultaneous output streams, cutoff-driven compaction; the union is 3e9 records > 2^31)."""
+    n = 2_000_000_000
+    a, b = build_pair(ctx, n, 25)
+    st, out, _ = ctx.compare(a, b, 1 | 4, cutoff=3)
+    assert st[1][0] > (1 << 31)
+    check_windows(a, b, out, st, 1 | 4, cutoff=3)
+    stc, _, _ = ctx.compare(a, b, 1 | 4, cutoff=3, count_only=True)
+    assert stc == st
+
+
+def test_config4_shape_k32_full_key_range(ctx):
+    """BASELINE config 4's shape on one GPU: k=32 keys over the whole 64-bit range (values >= 2^63),
+    2 x 4e9 records, intersection; every key shared so the output is 4e9 records too (record
+    indices, tile ranges and output offsets beyond 2^31 and merged positions beyond 2^32)."""
+    n = 4_000_000_000
+    a, b = ctx.alloc(n, 32), ctx.alloc(n, 32)
+    ctx.generate_ex(a, n, 7, 50, 8, 1, 0)
+    ctx.generate_ex(b, n, 7, 51, 8, 1, 0)
+    assert a.get_word(n - 1)[0] >= (1 << 63)
+    st, out, _ = ctx.compare(a, b, 2)
+    assert st[2][0] == n
+    check_windows(a, b, out, st, 2)
+    del out
+    # a disjoint partner: nothing in common, the union interleaves both lists
+    m = 1_000_000_000
+    c = ctx.alloc(m, 32)
+    ctx.generate_ex(c, m, 9, 52, 8, 2, 1)   # odd keys only ...
+    ctx.generate_ex(b, n, 7, 51, 8, 2, 0)   # ... against even keys only
+    st, out, _ = ctx.compare(b, c, 1 | 2)
+    assert st[2][0] == 0 and st[1][0] == n + m
+    check_windows(b, c, out, st, 1 | 2)

@@ -306,3 +306,61 @@ def test_single_pass_gives_up_and_falls_back(ctx):
         ctx.set_option("grid", 0)
         ctx.set_option("spin_limit", 0)
     assert ctx.get_counter("single_pass_fallbacks") > before
+
+
+def test_fallback_with_default_spin_limit_is_fast(ctx):
+    """An oversubscribed grid with the DEFAULT wait bound: the first wait that gives up raises the
+    launch's error flag, every other wait then ends at its next look (the kernel peeks at the flag
+    inside its spin loops), so the launch finishes at its normal pace and the two-pass rerun
+    happens within seconds -- not after one full bound per remaining tile."""
+    import time
+    a, b = U.random_pair(15, 6_000_000, 0.5, 0.5, k=24)
+    exp = O.compare(a, b, 3)
+    da, db = ctx.upload(a, 24), ctx.upload(b, 24)
+    before = ctx.get_counter("single_pass_fallbacks")
+    ctx.set_option("grid", 1024)
+    try:
+        t0 = time.perf_counter()
+        st, out, _ = ctx.compare(da, db, 3)
+        elapsed = time.perf_counter() - t0
+    finally:
+        ctx.set_option("grid", 0)
+    assert ctx.get_counter("single_pass_fallbacks") > before
+    assert elapsed < 60.0, "fallback took %.1f s" % elapsed
+    for bit in (1, 2):
+        assert st[bit] == exp[bit][:2]
+        assert out[bit].download().tobytes() == exp[bit][2].tobytes()
+
+
+@pytest.mark.parametrize("rule", range(8))
+@pytest.mark.parametrize("cutoff", [0, 1, 3])
+def test_intersection_alone_long_and_short_first_list(ctx, rule, cutoff):
+    """ops = 2 alone swaps its inputs when the first list is the longer one (FIRST and SECOND trade
+    places, SUBTRACT must not swap): every rule, both orders, against the oracle."""
+    rng = np.random.default_rng(900 + rule * 5 + cutoff)
+    big = np.unique(rng.integers(0, 1 << 36, size=120000, dtype=np.uint64))
+    small = np.sort(rng.choice(big, size=7000, replace=False))
+    extra = np.unique(rng.integers(0, 1 << 36, size=2000, dtype=np.uint64))
+    small = np.unique(np.concatenate([small, extra]))
+    a = U.make_records(big, rng.integers(0, 9, size=len(big), dtype=np.uint32))
+    b = U.make_records(small, rng.integers(0, 9, size=len(small), dtype=np.uint32))
+    _check_pair(ctx, a, b, 2, rule, cutoff, 0, ovr=5, k=18)
+    _check_pair(ctx, b, a, 2, rule, cutoff, 0, ovr=5, k=18)
+
+
+@pytest.mark.parametrize("rule", [0, 1, 3, 4, 7])
+def test_intersect_multi_long_first_list(ctx, rule):
+    """intersect_multi with a long first list and short later ones (the chain's pair calls swap)."""
+    rng = np.random.default_rng(40 + rule)
+    big = np.unique(rng.integers(0, 1 << 34, size=90000, dtype=np.uint64))
+    lists = [U.make_records(big, rng.integers(0, 7, size=len(big), dtype=np.uint32))]
+    for frac in (0.3, 0.05, 0.5):
+        m = rng.random(len(big)) < frac
+        lists.append(U.make_records(big[m], rng.integers(0, 7, size=int(m.sum()), dtype=np.uint32)))
+    dev = [ctx.upload(x, 17) for x in lists]
+    for cutoff in (0, 1, 3):
+        rc_o, n_o, t_o, r_o = O.intersect_multi(lists, cutoff, rule, 4)
+        rc_g, n_g, t_g, out = ctx.intersect_multi(dev, cutoff, rule, 4)
+        assert rc_g == rc_o == 0
+        assert (n_g, t_g) == (n_o, t_o)
+        assert out.download().tobytes() == r_o.tobytes()

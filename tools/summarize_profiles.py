@@ -1,14 +1,17 @@
 """Summarises a tools/collect_profiles.sh output directory into small CSV/JSON files.
 
-    python3 tools/summarize_profiles.py gpurun_out/prof_<tag> <tag>
+    python3 tools/summarize_profiles.py gpurun_out/prof_<tag>/<workload> <tag> [workload]
 
 Writes next to the raw data (directory `summary/`): <tag>_bench.json, <tag>_kernel_stats.csv,
-<tag>_pmc_fetch_size.csv, <tag>_pmc_write_size.csv and traffic_latest.json.  FETCH_SIZE / WRITE_SIZE
+<tag>_pmc_fetch_size.csv, <tag>_pmc_write_size.csv and traffic_<workload>.json (what bench.py replays
+as `roofline.traffic`, with the commit the passes ran on: GT4_COMMIT).  FETCH_SIZE / WRITE_SIZE
 are in KiB; FETCH_SIZE is doubled on gfx950 as /opt/skills/guides/MI355X_MICROARCH.md (HBM section)
 prescribes."""
 import csv, glob, json, os, sys
 
 src, tag = sys.argv[1], sys.argv[2]
+workload = sys.argv[3] if len(sys.argv) > 3 else "intersect"
+ROUND = os.environ.get("GT4_ROUND", "round2")
 dst = os.path.join(src, "summary")
 os.makedirs(dst, exist_ok=True)
 
@@ -61,15 +64,23 @@ def pmc(sub, counter):
 fetch, fpath = pmc("fetch", "FETCH_SIZE")
 write, wpath = pmc("write", "WRITE_SIZE")
 if fetch and write:
-    # dominant kernel = the k_pair_merge instantiation with the most fetched bytes in total
-    cand = [k for k in fetch if k.startswith("k_pair_merge")]
+    # dominant kernel = the merge kernel instantiation with the most fetched bytes in total
+    cand = [k for k in fetch if k.startswith("k_pair_merge") or k.startswith("k_kway")]
     dom = max(cand, key=lambda k: sum(fetch[k].values()))
     fv = list(fetch[dom].values())
     wv = list(write.get(dom, {}).values())
     fb = 2.0 * 1024.0 * sum(fv) / len(fv)
     wb = 1024.0 * sum(wv) / len(wv) if wv else 0.0
+    # every merge kernel launch of one bench step together (the N-way union is several launches per step)
+    steps = 3  # --steps 2 --warmup 1
+    all_f = 2.0 * 1024.0 * sum(sum(fetch[k].values()) for k in cand)
+    all_w = 1024.0 * sum(sum(write.get(k, {}).values()) for k in cand)
+    cfg = (bench or {}).get("config", {})
     tj = {
-        "n_per_list": (bench or {}).get("config", {}).get("entries_per_list_per_gpu"),
+        "workload": workload,
+        "commit": os.environ.get("GT4_COMMIT"),
+        "n_per_list": cfg.get("entries_per_list_per_gpu", cfg.get("entries_per_list")),
+        "merge_kernels_hbm_bytes_per_step_incl_list_generation": (all_f + all_w) / steps,
         "kernel": dom,
         "hbm_bytes_per_launch": fb + wb,
         "fetch_bytes_corrected": fb,
@@ -78,8 +89,8 @@ if fetch and write:
         "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python3 bench.py "
                   "--steps 2 --warmup 1 --no-cpu-baseline`; KiB units; FETCH_SIZE doubled per the gfx950 "
                   "correction of MI355X_MICROARCH.md (HBM section); WRITE_SIZE as is",
-        "source": ["profiles/round1/" + os.path.basename(fpath), "profiles/round1/" + os.path.basename(wpath)],
+        "source": ["profiles/%s/" % ROUND + os.path.basename(fpath), "profiles/%s/" % ROUND + os.path.basename(wpath)],
     }
-    with open(os.path.join(dst, "traffic_latest.json"), "w") as f:
+    with open(os.path.join(dst, "traffic_%s.json" % workload), "w") as f:
         json.dump(tj, f, indent=1)
     print(json.dumps(tj))
