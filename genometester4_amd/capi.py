@@ -50,7 +50,9 @@ SYMBOLS = [
     "gt4hip_list_is_sorted", "gt4hip_list_lower_bound", "gt4hip_list_get_word", "gt4hip_compare",
     "gt4hip_union_multi", "gt4hip_intersect_multi", "gt4hip_union_table", "gt4hip_probe_table", "gt4hip_table_download",
     "gt4hip_table_free", "gt4hip_generate", "gt4hip_generate_ex", "gt4hip_synchronize", "gt4hip_set_option",
-    "gt4hip_get_counter",
+    "gt4hip_get_counter", "gt4hip_device_memory", "gt4hip_list_upload_fd", "gt4hip_list_load_fd", "gt4hip_list_load",
+    "gt4hip_list_write_fd", "gt4hip_shard_first_key", "gt4hip_comm_unique_id", "gt4hip_comm_create", "gt4hip_comm_destroy",
+    "gt4hip_comm_rank", "gt4hip_comm_size", "gt4hip_comm_last_error", "gt4hip_comm_gatherv",
 ]
 
 _lib = None
@@ -105,6 +107,19 @@ def lib():
             "gt4hip_synchronize": (C.c_int, [vp]),
             "gt4hip_set_option": (C.c_int, [vp, C.c_char_p, C.c_int64]),
             "gt4hip_get_counter": (C.c_int, [vp, C.c_char_p, C.POINTER(u64)]),
+            "gt4hip_device_memory": (C.c_int, [vp, C.POINTER(u64), C.POINTER(u64)]),
+            "gt4hip_list_upload_fd": (C.c_int, [vp, C.c_int, u64, u64, u32, C.POINTER(vp)]),
+            "gt4hip_list_load_fd": (C.c_int, [vp, vp, C.c_int, u64, u64]),
+            "gt4hip_list_load": (C.c_int, [vp, vp, vp, u64]),
+            "gt4hip_list_write_fd": (C.c_int, [vp, vp, u64, u64, C.c_int, u64]),
+            "gt4hip_shard_first_key": (u64, [u32, u32, u32]),
+            "gt4hip_comm_unique_id": (C.c_int, [vp]),
+            "gt4hip_comm_create": (C.c_int, [vp, vp, C.c_int, C.c_int, C.POINTER(vp)]),
+            "gt4hip_comm_destroy": (None, [vp]),
+            "gt4hip_comm_rank": (C.c_int, [vp]),
+            "gt4hip_comm_size": (C.c_int, [vp]),
+            "gt4hip_comm_last_error": (C.c_char_p, []),
+            "gt4hip_comm_gatherv": (C.c_int, [vp, vp, C.POINTER(u64), C.c_int, vp]),
         }
         for name, (res, args) in sig.items():
             f = getattr(L, name)
@@ -112,6 +127,18 @@ def lib():
             f.argtypes = args
         _lib = L
     return _lib
+
+
+def comm_unique_id() -> bytes:
+    buf = C.create_string_buffer(128)
+    rc = lib().gt4hip_comm_unique_id(buf)
+    if rc:
+        raise Gt4HipError(rc, lib().gt4hip_comm_last_error().decode())
+    return buf.raw
+
+
+def comm_destroy(comm):
+    lib().gt4hip_comm_destroy(comm)
 
 
 class DeviceList:
@@ -217,6 +244,31 @@ class Context:
 
     def synchronize(self):
         self._chk(lib().gt4hip_synchronize(self.h))
+
+    def device_memory(self):
+        f, t = C.c_uint64(), C.c_uint64()
+        self._chk(lib().gt4hip_device_memory(self.h, C.byref(f), C.byref(t)))
+        return f.value, t.value
+
+    def upload_fd(self, fd, file_offset, n_words, word_length) -> "DeviceList":
+        h = C.c_void_p()
+        self._chk(lib().gt4hip_list_upload_fd(self.h, fd, file_offset, n_words, word_length, C.byref(h)))
+        return DeviceList(self, h)
+
+    def write_fd(self, lst, first, count, fd, file_offset):
+        self._chk(lib().gt4hip_list_write_fd(self.h, lst.h, first, count, fd, file_offset))
+
+    def comm_create(self, comm_id: bytes, n_ranks: int, rank: int):
+        """RCCL communicator of this context's GPU (id from `comm_unique_id()` of ONE rank)."""
+        h = C.c_void_p()
+        buf = C.create_string_buffer(bytes(comm_id), 128)
+        self._chk(lib().gt4hip_comm_create(self.h, buf, n_ranks, rank, C.byref(h)))
+        return h
+
+    def comm_gatherv(self, comm, local, counts, root=0, gathered=None):
+        arr = (C.c_uint64 * len(counts))(*counts)
+        self._chk(lib().gt4hip_comm_gatherv(comm, local.h if local is not None else None, arr, root,
+                                             gathered.h if gathered is not None else None))
 
     def upload_index(self, kmers, num_locations, word_length) -> DeviceList:
         """kmers: (n, 2) uint64 array of (word, first location) entries of a GT4I index."""

@@ -12,6 +12,11 @@
  *   - --stream and --disable_scouts are accepted and ignored (the whole list is uploaded to HBM;
  *     results are identical for well-formed files);
  *   - GT4HIP_CHECK_SORTED=1 rejects an input that is not strictly ascending (the reference trusts it);
+ *   - --gpus N / GT4HIP_GPUS=N shards the job by key range over N GPUs (one worker process each, forked
+ *     before any HIP call; every worker writes its own extents of the output files, or with
+ *     GT4HIP_GATHER=rccl the shards are gathered on worker 0 over RCCL); GT4HIP_HBM_LIMIT=<bytes>, or
+ *     inputs that do not fit the device memory, stream the job through the GPU in key-range chunks
+ *     (gt4_shard.c).  Outputs are byte-identical to the single-pass run;
  *   - without a usable GPU the program fails: there is no CPU fallback.
  */
 #define _GNU_SOURCE
@@ -24,12 +29,13 @@
 #include <unistd.h>
 
 #include "gt4_listfile.h"
+#include "gt4_shard.h"
 #include "gt4hip.h"
 
 #define MAX_FILES 1024
 
 enum { OPT_PLAIN, OPT_VERSION, OPT_HELP, OPT_OUT, OPT_CUTOFF, OPT_MM, OPT_UNION, OPT_INTRSEC, OPT_DIFF, OPT_DDIFF, OPT_DU,
-       OPT_COUNT_ONLY, OPT_RULE, OPT_SUBSET, OPT_SEED, OPT_PRINT_OP, OPT_NOSCOUTS, OPT_STREAM, OPT_DEBUG };
+       OPT_COUNT_ONLY, OPT_RULE, OPT_SUBSET, OPT_SEED, OPT_PRINT_OP, OPT_NOSCOUTS, OPT_STREAM, OPT_DEBUG, OPT_GPUS };
 
 static const struct {
   const char *name;
@@ -38,6 +44,7 @@ static const struct {
   { "-v", OPT_VERSION }, { "--version", OPT_VERSION }, { "-h", OPT_HELP }, { "--help", OPT_HELP }, { "-?", OPT_HELP },
   { "-o", OPT_OUT }, { "--outputname", OPT_OUT }, { "-c", OPT_CUTOFF }, { "--cutoff", OPT_CUTOFF },
   { "--count_cutoff", OPT_CUTOFF }, /* alias used by the benchmark description; not in the reference */
+  { "--gpus", OPT_GPUS },           /* not in the reference: key-range shards over several GPUs */
   { "-mm", OPT_MM }, { "--mismatch", OPT_MM }, { "-u", OPT_UNION }, { "--union", OPT_UNION },
   { "-i", OPT_INTRSEC }, { "--intersection", OPT_INTRSEC }, { "-d", OPT_DIFF }, { "--difference", OPT_DIFF },
   { "-dd", OPT_DDIFF }, { "--double_difference", OPT_DDIFF }, { "-du", OPT_DU }, { "--diff_union", OPT_DU },
@@ -139,6 +146,19 @@ static int write_list_file (gt4hip_context *ctx, const gt4hip_list *list, unsign
   return 0;
 }
 
+
+/* "<n>[K|M|G]" -> bytes */
+static uint64_t parse_bytes (const char *s)
+{
+  if (!s || !*s) return 0;
+  char *end;
+  double v = strtod (s, &end);
+  if (*end == 'K' || *end == 'k') v *= 1024.0;
+  else if (*end == 'M' || *end == 'm') v *= 1024.0 * 1024.0;
+  else if (*end == 'G' || *end == 'g') v *= 1024.0 * 1024.0 * 1024.0;
+  return v > 0 ? (uint64_t) v : 0;
+}
+
 int main (int argc, const char *argv[])
 {
   const char *fnames[MAX_FILES];
@@ -147,6 +167,7 @@ int main (int argc, const char *argv[])
   unsigned int cutoff = 1, nmm = 0, count_override = 1;
   int find_union = 0, find_intrsec = 0, find_diff = 0, find_ddiff = 0, subtraction = 0, countonly = 0, print_operation = 0;
   int find_subset = 0, stream = 0, debug = 0;
+  int n_gpus = getenv ("GT4HIP_GPUS") ? atoi (getenv ("GT4HIP_GPUS")) : 0;
   const char *outputname = "out";
   char *end;
 
@@ -249,6 +270,15 @@ int main (int argc, const char *argv[])
       case OPT_NOSCOUTS: break;
       case OPT_STREAM: stream = 1; break;
       case OPT_DEBUG: debug += 1; break;
+      case OPT_GPUS:
+        i += 1;
+        if (i >= argc) print_help (1);
+        n_gpus = atoi (argv[i]);
+        if (n_gpus < 1) {
+          fprintf (stderr, "Error: Invalid number of GPUs: %s!\n", argv[i]);
+          print_help (1);
+        }
+        break;
       default:
         fprintf (stderr, "Unknown argument: %s!\n", arg);
         print_help (1);
@@ -340,16 +370,109 @@ int main (int argc, const char *argv[])
     exit (1);
   }
 
-  /* ---- the device */
+
+  /* ---- key-range shards: several GPUs and / or chunks streamed through the device memory */
+  static const char *const SUFFIX[4] = { "union", "intrsec", "0_diff1", "0_diff2" };
+  uint64_t hbm_limit = parse_bytes (getenv ("GT4HIP_HBM_LIMIT"));
+  int use_shards = n_gpus >= 1 || hbm_limit != 0;
   gt4hip_context *ctx = NULL;
-  {
+  if (!use_shards) {
     const char *dev = getenv ("GT4HIP_DEVICE");
     if (gt4hip_create (dev ? atoi (dev) : 0, &ctx)) {
       fprintf (stderr, "Error: %s\n", gt4hip_last_error (NULL));
       exit (1);
     }
     if (debug) fprintf (stderr, "Device: %s\n", gt4hip_device_info (ctx));
+    /* inputs + worst-case outputs (+ the N-way tree's intermediates) must fit, else stream in chunks */
+    uint64_t free_b = 0, total_b = 0, need = 0, in_records = 0;
+    gt4hip_device_memory (ctx, &free_b, &total_b);
+    for (unsigned int f = 0; f < nfiles; f++) in_records += files[f].header.n_words;
+    if (nfiles == 2) need = 12 * in_records * (1 + (uint64_t) (find_union + find_intrsec + find_diff + find_ddiff));
+    else need = 12 * in_records * 4;
+    if (free_b && need > free_b / 100 * 85) {
+      if (debug) fprintf (stderr, "Inputs and outputs need %llu bytes, %llu are free: streaming in key-range chunks\n", (unsigned long long) need, (unsigned long long) free_b);
+      gt4hip_destroy (ctx);
+      ctx = NULL;
+      use_shards = 1;
+    }
   }
+  if (use_shards) {
+    GT4ShardJob job;
+    memset (&job, 0, sizeof job);
+    job.n_files = nfiles;
+    job.files = files;
+    job.word_length = wlen;
+    job.n_ranks = n_gpus >= 1 ? n_gpus : 1;
+    job.hbm_limit = hbm_limit;
+    job.gather_rccl = getenv ("GT4HIP_GATHER") && !strcmp (getenv ("GT4HIP_GATHER"), "rccl");
+    job.debug = debug;
+    job.prm.rule = rule;
+    job.prm.cutoff = cutoff;
+    job.prm.subtract = subtraction;
+    job.prm.count_override = count_override;
+    job.prm.count_only = countonly;
+    char names[4][2048];
+    int v = 0;
+    if (nfiles == 2) {
+      if (debug) {
+        fprintf (stderr, "compare_wordmaps: methods %u/%u/%u/%u\n", find_union, find_intrsec, find_diff, find_ddiff);
+        fprintf (stderr, "compare_wordmaps: List 1: %llu entries\n", (unsigned long long) files[0].header.n_words);
+        fprintf (stderr, "compare_wordmaps; List 2: %llu entries\n", (unsigned long long) files[1].header.n_words);
+      }
+      job.mode = GT4_SHARD_PAIR;
+      job.prm.ops = (find_union ? GT4HIP_OP_UNION : 0) | (find_intrsec ? GT4HIP_OP_INTRSEC : 0) | (find_diff ? GT4HIP_OP_DIFF1 : 0) |
+                    (find_ddiff ? GT4HIP_OP_DIFF2 : 0);
+      job.out_mode = 0666;
+      for (int s = 0; s < 4; s++) {
+        if (!((job.prm.ops >> s) & 1u) || countonly) continue;
+        snprintf (names[s], sizeof names[s], "%s_%d_%s.list", outputname, wlen, SUFFIX[s]);
+        job.out_name[s] = names[s];
+      }
+      GT4ShardResult res;
+      if (job.prm.ops) {
+        if (gt4_shard_run (&job, &res)) exit (1);
+        if (debug) fprintf (stderr, "Sharded run: %u chunks over %d GPU(s)\n", res.n_chunks, job.n_ranks);
+        for (int s = 0; s < 4; s++) {
+          if (!((job.prm.ops >> s) & 1u)) continue;
+          if (countonly) fprintf (stdout, "NUnique\t%llu\nNTotal\t%llu\n", (unsigned long long) res.n_words[s], (unsigned long long) res.total_count[s]);
+          else if (debug && s >= 2) fprintf (stderr, "Renaming %s.tmp to %s\n", names[s], names[s]);
+        }
+      }
+    } else {
+      for (int pass = 0; pass < 2; pass++) {
+        const int is_union = pass == 0;
+        if (is_union ? !find_union : !find_intrsec) continue;
+        job.mode = is_union ? GT4_SHARD_UNION_MULTI : GT4_SHARD_INTERSECT_MULTI;
+        job.out_mode = 0644;
+        job.out_name[0] = NULL;
+        if (!countonly) {
+          snprintf (names[0], sizeof names[0], "%s_%d_%s.list", outputname, wlen, is_union ? "union" : "intrsec");
+          job.out_name[0] = names[0];
+        }
+        GT4ShardResult res;
+        const double t_s = now_seconds ();
+        const int rc = gt4_shard_run (&job, &res);
+        const double t_e = now_seconds ();
+        if (rc && res.rule_rejected) {
+          fprintf (stderr, "%s\n", res.message);
+          v = 1;
+          continue;
+        }
+        if (rc) exit (1);
+        v = 0;
+        if (debug) {
+          unsigned long long total = 0;
+          for (unsigned int f = 0; f < nfiles; f++) total += files[f].header.n_words;
+          fprintf (stderr, "Combined %u maps: input %llu (%.3f Mwords/s) output %llu (%.3f Mwords/s)\n", nfiles, is_union ? total : 0ull,
+                   (is_union ? total : 0ull) / (1000000 * (t_e - t_s)), (unsigned long long) res.n_words[0], res.n_words[0] / (1000000 * (t_e - t_s)));
+        }
+        if (countonly || debug) fprintf (stdout, "NUnique\t%llu\nNTotal\t%llu\n", (unsigned long long) res.n_words[0], (unsigned long long) res.total_count[0]);
+      }
+    }
+    for (unsigned int f = 0; f < nfiles; f++) gt4_listfile_close (&files[f]);
+    return v ? 1 : 0;
+  }
+
   static gt4hip_list *lists[MAX_FILES];
   for (unsigned int f = 0; f < nfiles; f++) {
     if (files[f].index_kmers ? gt4hip_list_upload_index (ctx, files[f].index_kmers, files[f].header.n_words, files[f].index_locations, wlen, &lists[f])
@@ -371,7 +494,6 @@ int main (int argc, const char *argv[])
   int v = 0;
   if (nfiles == 2) {
     /* ---- compare_wordmaps (reference :789-955) */
-    static const char *const SUFFIX[4] = { "union", "intrsec", "0_diff1", "0_diff2" };
     if (debug) {
       fprintf (stderr, "compare_wordmaps: methods %u/%u/%u/%u\n", find_union, find_intrsec, find_diff, find_ddiff);
       fprintf (stderr, "compare_wordmaps: List 1: %llu entries\n", (unsigned long long) files[0].header.n_words);

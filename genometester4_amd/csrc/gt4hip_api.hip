@@ -4,8 +4,7 @@
  * Host-side orchestration only: contexts, HBM-resident lists, workspace, kernel sequencing and
  * timing.  All per-record work happens in gt4hip_kernels.hip.  Nothing here falls back to the CPU.
  */
-#include "../../include/gt4hip.h"
-#include "gt4hip_internal.h"
+#include "gt4hip_host.h"
 
 #include <stdarg.h>
 #include <stdio.h>
@@ -18,52 +17,11 @@
 
 using namespace gt4;
 
-struct gt4hip_context {
-  int device;
-  hipStream_t stream;
-  hipEvent_t ev[4];
-  int n_cus;
-  int two_pass;
-  int64_t grid_override;
-  uint32_t spin_limit;       /* option "spin_limit": bound of the single-pass kernel's waits (0 = default) */
-  int force_geom; /* options "geom1" / "geom0": force the large / small geometry for every call (experiments); 0 = automatic */
-  uint64_t single_pass_fallbacks; /* calls that had to be rerun on the two-pass path */
-  /* freed list storage kept for reuse: hipMalloc / hipFree of tens of GB cost far more than the
-   * merges themselves (an 8-way union tree allocates seven outputs per call) */
-  std::vector<std::pair<void *, size_t>> *pool;
-  int pool_enabled;
-  size_t pool_bytes;         /* bytes the pool holds right now */
-  size_t pool_cap;           /* most it may hold (option "pool_cap_mb"; default: half of the device memory) */
-  /* workspace, grown on demand */
-  uint64_t *part;
-  size_t part_bytes;
-  unsigned long long *desc;
-  size_t desc_bytes;
-  unsigned long long *block_sums;
-  size_t block_sums_bytes;
-  PairControl *ctl;          /* device */
-  PairControl *ctl_host;     /* pinned */
-  unsigned long long *scratch;      /* device, 4 x u64 */
-  unsigned long long *scratch_host; /* pinned */
-  char err[512];
-  char info[256];
-};
-
-struct gt4hip_list {
-  gt4hip_context *ctx;
-  void *dev;
-  size_t bytes; /* size of the allocation behind dev when owned */
-  uint64_t n_words;
-  uint64_t capacity;
-  uint32_t word_length;
-  int owns;
-};
-
 static char g_create_err[512] = "";
 
 static void pool_flush (gt4hip_context *ctx);
 
-static int fail (gt4hip_context *ctx, int code, const char *fmt, ...)
+int gt4hip_fail (gt4hip_context *ctx, int code, const char *fmt, ...)
 {
   va_list ap;
   va_start (ap, fmt);
@@ -71,13 +29,6 @@ static int fail (gt4hip_context *ctx, int code, const char *fmt, ...)
   va_end (ap);
   return code;
 }
-
-#define HIPCHK(ctx, call)                                                                               \
-  do {                                                                                                  \
-    hipError_t e_ = (call);                                                                             \
-    if (e_ != hipSuccess) return fail ((ctx), e_ == hipErrorOutOfMemory ? GT4HIP_ENOMEM : GT4HIP_EHIP, \
-                                       "%s failed: %s", #call, hipGetErrorString (e_));                 \
-  } while (0)
 
 extern "C" const char *gt4hip_strerror (int code)
 {
@@ -91,6 +42,8 @@ extern "C" const char *gt4hip_strerror (int code)
     case GT4HIP_EWORDLEN: return "lists have different word lengths";
     case GT4HIP_EINTERNAL: return "internal consistency check failed";
     case GT4HIP_ECALLBACK: return "stopped by callback";
+    case GT4HIP_EIO: return "file I/O failed";
+    case GT4HIP_ECOMM: return "RCCL communication failed";
     default: return "unknown error";
   }
 }
@@ -109,17 +62,17 @@ extern "C" int gt4hip_device_count (void)
 
 extern "C" int gt4hip_create (int device, gt4hip_context **out)
 {
-  if (!out || device < 0) return fail (NULL, GT4HIP_EINVAL, "gt4hip_create: bad arguments");
+  if (!out || device < 0) return gt4hip_fail (NULL, GT4HIP_EINVAL, "gt4hip_create: bad arguments");
   *out = NULL;
   int n = 0;
   hipError_t e = hipGetDeviceCount (&n);
   if (e != hipSuccess || n <= 0)
-    return fail (NULL, GT4HIP_ENODEVICE, "gt4hip_create: no HIP device (%s)", e != hipSuccess ? hipGetErrorString (e) : "count 0");
-  if (device >= n) return fail (NULL, GT4HIP_ENODEVICE, "gt4hip_create: device %d not present (%d visible)", device, n);
+    return gt4hip_fail (NULL, GT4HIP_ENODEVICE, "gt4hip_create: no HIP device (%s)", e != hipSuccess ? hipGetErrorString (e) : "count 0");
+  if (device >= n) return gt4hip_fail (NULL, GT4HIP_ENODEVICE, "gt4hip_create: device %d not present (%d visible)", device, n);
   if ((e = hipSetDevice (device)) != hipSuccess)
-    return fail (NULL, GT4HIP_ENODEVICE, "gt4hip_create: hipSetDevice(%d): %s", device, hipGetErrorString (e));
+    return gt4hip_fail (NULL, GT4HIP_ENODEVICE, "gt4hip_create: hipSetDevice(%d): %s", device, hipGetErrorString (e));
   gt4hip_context *ctx = new (std::nothrow) gt4hip_context ();
-  if (!ctx) return fail (NULL, GT4HIP_ENOMEM, "gt4hip_create: host allocation failed");
+  if (!ctx) return gt4hip_fail (NULL, GT4HIP_ENOMEM, "gt4hip_create: host allocation failed");
   memset (ctx, 0, sizeof *ctx);
   ctx->device = device;
   ctx->pool = new (std::nothrow) std::vector<std::pair<void *, size_t>> ();
@@ -128,7 +81,7 @@ extern "C" int gt4hip_create (int device, gt4hip_context **out)
   if ((e = hipGetDeviceProperties (&prop, device)) != hipSuccess) {
     delete ctx->pool;
     delete ctx;
-    return fail (NULL, GT4HIP_ENODEVICE, "gt4hip_create: hipGetDeviceProperties: %s", hipGetErrorString (e));
+    return gt4hip_fail (NULL, GT4HIP_ENODEVICE, "gt4hip_create: hipGetDeviceProperties: %s", hipGetErrorString (e));
   }
   ctx->n_cus = prop.multiProcessorCount;
   ctx->pool_cap = prop.totalGlobalMem / 2;
@@ -136,7 +89,7 @@ extern "C" int gt4hip_create (int device, gt4hip_context **out)
   if ((e = hipStreamCreateWithFlags (&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
     delete ctx->pool;
     delete ctx;
-    return fail (NULL, GT4HIP_ENODEVICE, "gt4hip_create: hipStreamCreate: %s", hipGetErrorString (e));
+    return gt4hip_fail (NULL, GT4HIP_ENODEVICE, "gt4hip_create: hipStreamCreate: %s", hipGetErrorString (e));
   }
   for (int i = 0; i < 4; i++) hipEventCreate (&ctx->ev[i]);
   if (hipMalloc ((void **) &ctx->ctl, sizeof (PairControl)) != hipSuccess ||
@@ -144,7 +97,7 @@ extern "C" int gt4hip_create (int device, gt4hip_context **out)
       hipMalloc ((void **) &ctx->scratch, 64) != hipSuccess ||
       hipHostMalloc ((void **) &ctx->scratch_host, 64, hipHostMallocDefault) != hipSuccess) {
     gt4hip_destroy (ctx);
-    return fail (NULL, GT4HIP_ENOMEM, "gt4hip_create: control block allocation failed");
+    return gt4hip_fail (NULL, GT4HIP_ENOMEM, "gt4hip_create: control block allocation failed");
   }
   *out = ctx;
   return GT4HIP_OK;
@@ -155,6 +108,7 @@ extern "C" void gt4hip_destroy (gt4hip_context *ctx)
   if (!ctx) return;
   hipSetDevice (ctx->device);
   if (ctx->stream) hipStreamSynchronize (ctx->stream);
+  gt4hip_io_destroy (ctx);
   if (ctx->pool) {
     pool_flush (ctx);
     delete ctx->pool;
@@ -176,6 +130,18 @@ extern "C" const char *gt4hip_device_info (const gt4hip_context *ctx)
   return ctx ? ctx->info : "";
 }
 
+extern "C" int gt4hip_device_memory (gt4hip_context *ctx, uint64_t *free_bytes, uint64_t *total_bytes)
+{
+  if (!ctx) return GT4HIP_EINVAL;
+  HIPCHK (ctx, hipSetDevice (ctx->device));
+  size_t f = 0, t = 0;
+  HIPCHK (ctx, hipMemGetInfo (&f, &t));
+  /* what the context's pool holds can be had back at once */
+  if (free_bytes) *free_bytes = (uint64_t) f + ctx->pool_bytes;
+  if (total_bytes) *total_bytes = (uint64_t) t;
+  return GT4HIP_OK;
+}
+
 extern "C" int gt4hip_set_option (gt4hip_context *ctx, const char *name, int64_t value)
 {
   if (!ctx || !name) return GT4HIP_EINVAL;
@@ -192,7 +158,7 @@ extern "C" int gt4hip_set_option (gt4hip_context *ctx, const char *name, int64_t
   else if (!strcmp (name, "spin_limit")) ctx->spin_limit = value > 0 ? (uint32_t) value : 0u;
   else if (!strcmp (name, "geom1")) ctx->force_geom = value != 0 ? 1 : 0;
   else if (!strcmp (name, "geom0")) ctx->force_geom = value != 0 ? -1 : 0;
-  else return fail (ctx, GT4HIP_EINVAL, "unknown option %s", name);
+  else return gt4hip_fail (ctx, GT4HIP_EINVAL, "unknown option %s", name);
   return GT4HIP_OK;
 }
 
@@ -200,7 +166,7 @@ extern "C" int gt4hip_get_counter (gt4hip_context *ctx, const char *name, uint64
 {
   if (!ctx || !name || !value) return GT4HIP_EINVAL;
   if (!strcmp (name, "single_pass_fallbacks")) *value = ctx->single_pass_fallbacks;
-  else return fail (ctx, GT4HIP_EINVAL, "unknown counter %s", name);
+  else return gt4hip_fail (ctx, GT4HIP_EINVAL, "unknown counter %s", name);
   return GT4HIP_OK;
 }
 
@@ -223,7 +189,7 @@ static void pool_flush (gt4hip_context *ctx)
 
 /* Every device allocation of the library goes through here: when the driver is out of memory the
  * pooled blocks (freed list storage kept for reuse) are given back and the allocation is retried. */
-static hipError_t dev_alloc (gt4hip_context *ctx, void **p, size_t bytes)
+hipError_t gt4hip_dev_alloc (gt4hip_context *ctx, void **p, size_t bytes)
 {
   hipError_t e = hipMalloc (p, bytes);
   if (e != hipSuccess && ctx->pool && !ctx->pool->empty ()) {
@@ -237,10 +203,10 @@ static hipError_t dev_alloc (gt4hip_context *ctx, void **p, size_t bytes)
 
 /* ------------------------------------------------------------------ lists */
 
-static int list_new (gt4hip_context *ctx, uint64_t capacity, uint32_t word_length, gt4hip_list **out)
+int gt4hip_list_new (gt4hip_context *ctx, uint64_t capacity, uint32_t word_length, gt4hip_list **out)
 {
   gt4hip_list *l = new (std::nothrow) gt4hip_list ();
-  if (!l) return fail (ctx, GT4HIP_ENOMEM, "host allocation failed");
+  if (!l) return gt4hip_fail (ctx, GT4HIP_ENOMEM, "host allocation failed");
   l->ctx = ctx;
   l->dev = NULL;
   l->n_words = capacity;
@@ -267,10 +233,10 @@ static int list_new (gt4hip_context *ctx, uint64_t capacity, uint32_t word_lengt
     }
   }
   if (!l->dev) {
-    const hipError_t e = dev_alloc (ctx, &l->dev, bytes);
+    const hipError_t e = gt4hip_dev_alloc (ctx, &l->dev, bytes);
     if (e != hipSuccess) {
       delete l;
-      return fail (ctx, GT4HIP_ENOMEM, "hipMalloc of %zu bytes failed: %s", bytes, hipGetErrorString (e));
+      return gt4hip_fail (ctx, GT4HIP_ENOMEM, "hipMalloc of %zu bytes failed: %s", bytes, hipGetErrorString (e));
     }
     l->bytes = bytes;
   }
@@ -282,7 +248,7 @@ extern "C" int gt4hip_list_alloc (gt4hip_context *ctx, uint64_t capacity, uint32
 {
   if (!ctx || !out) return GT4HIP_EINVAL;
   HIPCHK (ctx, hipSetDevice (ctx->device));
-  return list_new (ctx, capacity, word_length, out);
+  return gt4hip_list_new (ctx, capacity, word_length, out);
 }
 
 extern "C" int gt4hip_list_upload (gt4hip_context *ctx, const void *host_records, uint64_t n_words, uint32_t word_length,
@@ -291,14 +257,13 @@ extern "C" int gt4hip_list_upload (gt4hip_context *ctx, const void *host_records
   if (!ctx || !out || (n_words && !host_records)) return GT4HIP_EINVAL;
   HIPCHK (ctx, hipSetDevice (ctx->device));
   gt4hip_list *l = NULL;
-  int rc = list_new (ctx, n_words, word_length, &l);
+  int rc = gt4hip_list_new (ctx, n_words, word_length, &l);
   if (rc) return rc;
   if (n_words) {
-    hipError_t e = hipMemcpyAsync (l->dev, host_records, (size_t) n_words * GT4HIP_RECORD_BYTES, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize (ctx->stream);
-    if (e != hipSuccess) {
+    rc = gt4hip_list_load (ctx, l, host_records, n_words); /* large buffers: pinned staging on the copy threads */
+    if (rc) {
       gt4hip_list_free (l);
-      return fail (ctx, GT4HIP_EHIP, "upload failed: %s", hipGetErrorString (e));
+      return rc;
     }
   }
   *out = l;
@@ -311,14 +276,14 @@ extern "C" int gt4hip_list_upload_index (gt4hip_context *ctx, const void *host_k
   if (!ctx || !out || (n_words && !host_kmers)) return GT4HIP_EINVAL;
   HIPCHK (ctx, hipSetDevice (ctx->device));
   gt4hip_list *l = NULL;
-  int rc = list_new (ctx, n_words, word_length, &l);
+  int rc = gt4hip_list_new (ctx, n_words, word_length, &l);
   if (rc) return rc;
   if (n_words) {
     void *tmp = NULL;
-    hipError_t e = dev_alloc (ctx, &tmp, (size_t) n_words * 16);
+    hipError_t e = gt4hip_dev_alloc (ctx, &tmp, (size_t) n_words * 16);
     if (e != hipSuccess) {
       gt4hip_list_free (l);
-      return fail (ctx, GT4HIP_ENOMEM, "hipMalloc of %llu bytes for the index table failed", (unsigned long long) n_words * 16);
+      return gt4hip_fail (ctx, GT4HIP_ENOMEM, "hipMalloc of %llu bytes for the index table failed", (unsigned long long) n_words * 16);
     }
     e = hipMemcpyAsync (tmp, host_kmers, (size_t) n_words * 16, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = launch_decode_index (ctx->stream, (const unsigned long long *) tmp, n_words, num_locations, (uint32_t *) l->dev);
@@ -326,7 +291,7 @@ extern "C" int gt4hip_list_upload_index (gt4hip_context *ctx, const void *host_k
     hipFree (tmp);
     if (e != hipSuccess) {
       gt4hip_list_free (l);
-      return fail (ctx, GT4HIP_EHIP, "index upload failed: %s", hipGetErrorString (e));
+      return gt4hip_fail (ctx, GT4HIP_EHIP, "index upload failed: %s", hipGetErrorString (e));
     }
   }
   *out = l;
@@ -336,9 +301,9 @@ extern "C" int gt4hip_list_upload_index (gt4hip_context *ctx, const void *host_k
 extern "C" int gt4hip_list_wrap (gt4hip_context *ctx, void *device_records, uint64_t n_words, uint32_t word_length, gt4hip_list **out)
 {
   if (!ctx || !out || (n_words && !device_records)) return GT4HIP_EINVAL;
-  if (((uintptr_t) device_records) & 3) return fail (ctx, GT4HIP_EINVAL, "device records must be 4-byte aligned");
+  if (((uintptr_t) device_records) & 3) return gt4hip_fail (ctx, GT4HIP_EINVAL, "device records must be 4-byte aligned");
   gt4hip_list *l = new (std::nothrow) gt4hip_list ();
-  if (!l) return fail (ctx, GT4HIP_ENOMEM, "host allocation failed");
+  if (!l) return gt4hip_fail (ctx, GT4HIP_ENOMEM, "host allocation failed");
   l->ctx = ctx;
   l->dev = device_records;
   l->n_words = n_words;
@@ -360,6 +325,8 @@ extern "C" int gt4hip_list_download_range (gt4hip_context *ctx, const gt4hip_lis
   if (!ctx || !list || first > list->n_words || count > list->n_words - first || (count && !host)) return GT4HIP_EINVAL;
   if (!count) return GT4HIP_OK;
   HIPCHK (ctx, hipSetDevice (ctx->device));
+  if ((size_t) count * GT4HIP_RECORD_BYTES >= ((size_t) 32 << 20))
+    return gt4hip_io_download (ctx, (const char *) list->dev + first * GT4HIP_RECORD_BYTES, host, (size_t) count * GT4HIP_RECORD_BYTES);
   HIPCHK (ctx, hipMemcpyAsync (host, (const char *) list->dev + first * GT4HIP_RECORD_BYTES, (size_t) count * GT4HIP_RECORD_BYTES,
                                hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK (ctx, hipStreamSynchronize (ctx->stream));
@@ -476,7 +443,7 @@ extern "C" int gt4hip_generate_ex (gt4hip_context *ctx, gt4hip_list *l, uint64_t
   unsigned __int128 st = space / n;
   if (st > 0xffffffffffffffffull) st = 0xffffffffffffffffull;
   const uint64_t stride = (uint64_t) st;
-  if (!stride) return fail (ctx, GT4HIP_EINVAL, "gt4hip_generate: %llu keys do not fit k=%u", (unsigned long long) n, l->word_length);
+  if (!stride) return gt4hip_fail (ctx, GT4HIP_EINVAL, "gt4hip_generate: %llu keys do not fit k=%u", (unsigned long long) n, l->word_length);
   HIPCHK (ctx, launch_generate (ctx->stream, (uint32_t *) l->dev, n, stride, key_seed, count_seed, max_count, mult, add));
   HIPCHK (ctx, hipStreamSynchronize (ctx->stream));
   return GT4HIP_OK;
@@ -485,6 +452,13 @@ extern "C" int gt4hip_generate_ex (gt4hip_context *ctx, gt4hip_list *l, uint64_t
 extern "C" int gt4hip_generate (gt4hip_context *ctx, gt4hip_list *l, uint64_t n, uint64_t seed, uint32_t max_count)
 {
   return gt4hip_generate_ex (ctx, l, n, seed, seed + 1, max_count, 1, 0);
+}
+
+extern "C" uint64_t gt4hip_shard_first_key (uint32_t word_length, uint32_t n_shards, uint32_t g)
+{
+  if (!n_shards || g >= n_shards) return 0;
+  const unsigned __int128 space = word_length >= 32 ? ((unsigned __int128) 1 << 64) : ((unsigned __int128) 1 << (2 * word_length));
+  return (uint64_t) (space * g / n_shards);
 }
 
 /* ------------------------------------------------------------------ workspace */
@@ -499,8 +473,8 @@ static int grow (gt4hip_context *ctx, void **p, size_t *have, size_t need)
     *have = 0;
   }
   need += need / 8; /* slack so that slightly larger follow-up calls do not reallocate */
-  hipError_t e = dev_alloc (ctx, p, need);
-  if (e != hipSuccess) return fail (ctx, GT4HIP_ENOMEM, "workspace hipMalloc of %zu bytes failed: %s", need, hipGetErrorString (e));
+  hipError_t e = gt4hip_dev_alloc (ctx, p, need);
+  if (e != hipSuccess) return gt4hip_fail (ctx, GT4HIP_ENOMEM, "workspace hipMalloc of %zu bytes failed: %s", need, hipGetErrorString (e));
   *have = need;
   return GT4HIP_OK;
 }
@@ -562,7 +536,7 @@ static int run_pair (gt4hip_context *ctx, const uint32_t *A, uint64_t nA, const 
   const int geom = ctx->force_geom ? (ctx->force_geom > 0 ? 1 : 0) : (count_only ? 0 : 1);
   const uint64_t tile_records = merge_tile_records (geom, p.ops);
   const uint64_t tiles = (total + tile_records - 1) / tile_records;
-  if (tiles >= 0xffffffffull) return fail (ctx, GT4HIP_EINVAL, "lists too long: %llu merge tiles", (unsigned long long) tiles);
+  if (tiles >= 0xffffffffull) return gt4hip_fail (ctx, GT4HIP_EINVAL, "lists too long: %llu merge tiles", (unsigned long long) tiles);
   run->tiles = tiles;
   int rc;
   if ((rc = grow (ctx, (void **) &ctx->part, &ctx->part_bytes, (size_t) (tiles + 1) * 16 + (size_t) (tiles / 64 + 3) * 8))) return rc; /* tile ranges + coarse co-ranks */
@@ -626,7 +600,7 @@ static int run_pair (gt4hip_context *ctx, const uint32_t *A, uint64_t nA, const 
       ctx->single_pass_fallbacks++;
       return run_pair (ctx, A, nA, B, nB, p, count_only, dst, run, true);
     }
-    return fail (ctx, GT4HIP_EINTERNAL, "merge kernel reported error flags 0x%x", flags);
+    return gt4hip_fail (ctx, GT4HIP_EINTERNAL, "merge kernel reported error flags 0x%x", flags);
   }
   for (int s = 0; s < 4; s++) {
     run->n_words[s] = ctx->ctl_host->n_words[s];
@@ -657,10 +631,10 @@ static int pair_with_outputs (gt4hip_context *ctx, const gt4hip_list *a, const g
       if (!((p.ops >> s) & 1u)) continue;
       const uint64_t need = worst_case (s, a->n_words, b->n_words);
       if (out[s]) {
-        if (out[s]->capacity < need) rc = fail (ctx, GT4HIP_EINVAL, "output %d: capacity %llu < worst case %llu", s,
+        if (out[s]->capacity < need) rc = gt4hip_fail (ctx, GT4HIP_EINVAL, "output %d: capacity %llu < worst case %llu", s,
                                                  (unsigned long long) out[s]->capacity, (unsigned long long) need);
       } else {
-        rc = list_new (ctx, need, a->word_length, &made[s]);
+        rc = gt4hip_list_new (ctx, need, a->word_length, &made[s]);
         if (!rc) out[s] = made[s];
       }
       if (!rc) dst[s] = (uint32_t *) out[s]->dev;
@@ -688,9 +662,9 @@ extern "C" int gt4hip_compare (gt4hip_context *ctx, const gt4hip_list *a, const 
                                 const gt4hip_compare_params *prm, gt4hip_compare_result *res)
 {
   if (!ctx || !a || !b || !prm || !res) return GT4HIP_EINVAL;
-  if (prm->ops & ~15u) return fail (ctx, GT4HIP_EINVAL, "gt4hip_compare: unknown op bits 0x%x", prm->ops);
-  if (prm->rule < 0 || prm->rule > 7) return fail (ctx, GT4HIP_EINVAL, "gt4hip_compare: unknown rule %d", prm->rule);
-  if (a->word_length != b->word_length) return fail (ctx, GT4HIP_EWORDLEN, "word lengths differ (%u != %u)", b->word_length, a->word_length);
+  if (prm->ops & ~15u) return gt4hip_fail (ctx, GT4HIP_EINVAL, "gt4hip_compare: unknown op bits 0x%x", prm->ops);
+  if (prm->rule < 0 || prm->rule > 7) return gt4hip_fail (ctx, GT4HIP_EINVAL, "gt4hip_compare: unknown rule %d", prm->rule);
+  if (a->word_length != b->word_length) return gt4hip_fail (ctx, GT4HIP_EWORDLEN, "word lengths differ (%u != %u)", b->word_length, a->word_length);
   HIPCHK (ctx, hipSetDevice (ctx->device));
   PairParams p;
   memset (&p, 0, sizeof p);
@@ -766,7 +740,7 @@ static int empty_result (gt4hip_context *ctx, uint32_t word_length, bool count_o
     res->out->n_words = 0;
     return GT4HIP_OK;
   }
-  return list_new (ctx, 0, word_length, &res->out);
+  return gt4hip_list_new (ctx, 0, word_length, &res->out);
 }
 
 extern "C" int gt4hip_union_multi (gt4hip_context *ctx, const gt4hip_list *const lists[], uint32_t n_lists, uint32_t cutoff,
@@ -776,10 +750,10 @@ extern "C" int gt4hip_union_multi (gt4hip_context *ctx, const gt4hip_list *const
   /* src/glistcompare.c:518-523 */
   if (rule == GT4HIP_RULE_DEFAULT) rule = GT4HIP_RULE_ADD;
   else if (rule != GT4HIP_RULE_ADD && rule != GT4HIP_RULE_MAX && rule != GT4HIP_RULE_NUMBER)
-    return fail (ctx, GT4HIP_ERULE, "union_multi: Invalid rule %u (only ADD, MAX and NUMBER allowed)", (unsigned) rule);
+    return gt4hip_fail (ctx, GT4HIP_ERULE, "union_multi: Invalid rule %u (only ADD, MAX and NUMBER allowed)", (unsigned) rule);
   for (uint32_t j = 0; j < n_lists; j++) {
     if (!lists[j]) return GT4HIP_EINVAL;
-    if (lists[j]->word_length != lists[0]->word_length) return fail (ctx, GT4HIP_EWORDLEN, "word lengths differ");
+    if (lists[j]->word_length != lists[0]->word_length) return gt4hip_fail (ctx, GT4HIP_EWORDLEN, "word lengths differ");
   }
   HIPCHK (ctx, hipSetDevice (ctx->device));
   res->device_ms = 0;
@@ -839,11 +813,11 @@ extern "C" int gt4hip_intersect_multi (gt4hip_context *ctx, const gt4hip_list *c
   /* src/glistcompare.c:622-627 */
   if (rule == GT4HIP_RULE_DEFAULT) rule = GT4HIP_RULE_MIN;
   else if (rule != GT4HIP_RULE_ADD && rule != GT4HIP_RULE_MIN && rule != GT4HIP_RULE_MAX && rule != GT4HIP_RULE_NUMBER)
-    return fail (ctx, GT4HIP_ERULE, "intersect_multi: Invalid rule %u (only ADD, MIN, MAX and NUMBER allowed)", (unsigned) rule);
+    return gt4hip_fail (ctx, GT4HIP_ERULE, "intersect_multi: Invalid rule %u (only ADD, MIN, MAX and NUMBER allowed)", (unsigned) rule);
   bool any_empty = false;
   for (uint32_t j = 0; j < n_lists; j++) {
     if (!lists[j]) return GT4HIP_EINVAL;
-    if (lists[j]->word_length != lists[0]->word_length) return fail (ctx, GT4HIP_EWORDLEN, "word lengths differ");
+    if (lists[j]->word_length != lists[0]->word_length) return gt4hip_fail (ctx, GT4HIP_EWORDLEN, "word lengths differ");
     any_empty |= lists[j]->n_words == 0;
   }
   HIPCHK (ctx, hipSetDevice (ctx->device));
@@ -906,12 +880,12 @@ extern "C" int gt4hip_union_table (gt4hip_context *ctx, const gt4hip_list *const
     gt4hip_list_free (u.out);
     return GT4HIP_OK;
   }
-  hipError_t e = dev_alloc (ctx, &table->device_keys, (size_t) n * 8);
-  if (e == hipSuccess) e = dev_alloc (ctx, &table->device_counts, (size_t) n * n_lists * 4);
+  hipError_t e = gt4hip_dev_alloc (ctx, &table->device_keys, (size_t) n * 8);
+  if (e == hipSuccess) e = gt4hip_dev_alloc (ctx, &table->device_counts, (size_t) n * n_lists * 4);
   if (e != hipSuccess) {
     gt4hip_list_free (u.out);
     gt4hip_table_free (table);
-    return fail (ctx, GT4HIP_ENOMEM, "count table allocation failed: %s", hipGetErrorString (e));
+    return gt4hip_fail (ctx, GT4HIP_ENOMEM, "count table allocation failed: %s", hipGetErrorString (e));
   }
   e = launch_extract_keys (ctx->stream, (const uint32_t *) u.out->dev, n, (unsigned long long *) table->device_keys);
   for (uint32_t j = 0; j < n_lists && e == hipSuccess; j++)
@@ -921,7 +895,7 @@ extern "C" int gt4hip_union_table (gt4hip_context *ctx, const gt4hip_list *const
   gt4hip_list_free (u.out);
   if (e != hipSuccess) {
     gt4hip_table_free (table);
-    return fail (ctx, GT4HIP_EHIP, "count table kernels failed: %s", hipGetErrorString (e));
+    return gt4hip_fail (ctx, GT4HIP_EHIP, "count table kernels failed: %s", hipGetErrorString (e));
   }
   return GT4HIP_OK;
 }
@@ -936,11 +910,11 @@ extern "C" int gt4hip_probe_table (gt4hip_context *ctx, const gt4hip_list *const
   table->n_keys = n;
   if (!n) return GT4HIP_OK;
   HIPCHK (ctx, hipSetDevice (ctx->device));
-  hipError_t e = dev_alloc (ctx, &table->device_keys, (size_t) n * 8);
-  if (e == hipSuccess) e = dev_alloc (ctx, &table->device_counts, (size_t) n * n_lists * 4);
+  hipError_t e = gt4hip_dev_alloc (ctx, &table->device_keys, (size_t) n * 8);
+  if (e == hipSuccess) e = gt4hip_dev_alloc (ctx, &table->device_counts, (size_t) n * n_lists * 4);
   if (e != hipSuccess) {
     gt4hip_table_free (table);
-    return fail (ctx, GT4HIP_ENOMEM, "count table allocation failed: %s", hipGetErrorString (e));
+    return gt4hip_fail (ctx, GT4HIP_ENOMEM, "count table allocation failed: %s", hipGetErrorString (e));
   }
   e = launch_extract_keys (ctx->stream, (const uint32_t *) base->dev, n, (unsigned long long *) table->device_keys);
   for (uint32_t j = 0; j < n_lists && e == hipSuccess; j++) {
@@ -951,7 +925,7 @@ extern "C" int gt4hip_probe_table (gt4hip_context *ctx, const gt4hip_list *const
   if (e == hipSuccess) e = hipStreamSynchronize (ctx->stream);
   if (e != hipSuccess) {
     gt4hip_table_free (table);
-    return fail (ctx, GT4HIP_EHIP, "count table kernels failed: %s", hipGetErrorString (e));
+    return gt4hip_fail (ctx, GT4HIP_EHIP, "count table kernels failed: %s", hipGetErrorString (e));
   }
   return GT4HIP_OK;
 }

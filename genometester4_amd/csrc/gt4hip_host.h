@@ -1,0 +1,72 @@
+/* gt4hip_host.h -- host-side internals shared by the C-ABI implementation files
+ * (gt4hip_api.hip, gt4hip_io.hip, gt4hip_comm.hip, gt4hip_kway.hip). */
+#ifndef GT4HIP_HOST_H
+#define GT4HIP_HOST_H
+
+#include "../../include/gt4hip.h"
+#include "gt4hip_internal.h"
+
+#include <stddef.h>
+#include <utility>
+#include <vector>
+
+struct gt4hip_io; /* gt4hip_io.hip: pinned staging + copy threads, created on first use */
+
+struct gt4hip_context {
+  int device;
+  hipStream_t stream;
+  hipEvent_t ev[4];
+  int n_cus;
+  int two_pass;
+  int64_t grid_override;
+  uint32_t spin_limit;       /* option "spin_limit": bound of the single-pass kernel's waits (0 = default) */
+  int force_geom; /* options "geom1" / "geom0": force the large / small geometry for every call (experiments); 0 = automatic */
+  uint64_t single_pass_fallbacks; /* calls that had to be rerun on the two-pass path */
+  /* freed list storage kept for reuse: hipMalloc / hipFree of tens of GB cost far more than the
+   * merges themselves (an 8-way union tree allocates seven outputs per call) */
+  std::vector<std::pair<void *, size_t>> *pool;
+  int pool_enabled;
+  size_t pool_bytes;         /* bytes the pool holds right now */
+  size_t pool_cap;           /* most it may hold (option "pool_cap_mb"; default: half of the device memory) */
+  /* workspace, grown on demand */
+  uint64_t *part;
+  size_t part_bytes;
+  unsigned long long *desc;
+  size_t desc_bytes;
+  unsigned long long *block_sums;
+  size_t block_sums_bytes;
+  gt4::PairControl *ctl;          /* device */
+  gt4::PairControl *ctl_host;     /* pinned */
+  unsigned long long *scratch;      /* device, 4 x u64 */
+  unsigned long long *scratch_host; /* pinned */
+  gt4hip_io *io;            /* file <-> HBM staging (gt4hip_io.hip), NULL until first used */
+  char err[512];
+  char info[256];
+};
+
+struct gt4hip_list {
+  gt4hip_context *ctx;
+  void *dev;
+  size_t bytes; /* size of the allocation behind dev when owned */
+  uint64_t n_words;
+  uint64_t capacity;
+  uint32_t word_length;
+  int owns;
+};
+
+
+int gt4hip_fail (gt4hip_context *ctx, int code, const char *fmt, ...);
+/* every device allocation of the library: gives the pooled blocks back and retries when the driver is out of memory */
+hipError_t gt4hip_dev_alloc (gt4hip_context *ctx, void **p, size_t bytes);
+int gt4hip_list_new (gt4hip_context *ctx, uint64_t capacity, uint32_t word_length, gt4hip_list **out);
+void gt4hip_io_destroy (gt4hip_context *ctx);
+int gt4hip_io_download (gt4hip_context *ctx, const void *dev, void *host, size_t bytes);
+
+#define HIPCHK(ctx, call)                                                                               \
+  do {                                                                                                  \
+    hipError_t e_ = (call);                                                                             \
+    if (e_ != hipSuccess) return gt4hip_fail ((ctx), e_ == hipErrorOutOfMemory ? GT4HIP_ENOMEM : GT4HIP_EHIP, \
+                                              "%s failed: %s", #call, hipGetErrorString (e_));          \
+  } while (0)
+
+#endif

@@ -1,0 +1,362 @@
+/*
+ * gt4hip_io.hip -- file <-> HBM transfers of list records.
+ *
+ * The reference reads its lists through mmap (gt4_mmap, src/utils.c:35-64, with a read-ahead
+ * "scout" thread, :72-99) or 3 KiB read()s (word-list-stream.c:85-125), and writes results with two
+ * fwrite calls per record (glistcompare.c:491-496).  Here a list body moves between a file
+ * descriptor (or host memory) and HBM in 8 MiB pieces through pinned staging buffers that belong to
+ * the context and are set up ONCE: every copy thread owns two buffers and one HIP stream, preads a
+ * piece into one buffer while the other one is in flight to the device (or, for results, copies
+ * device -> pinned and pwrites the piece at its file offset while the next one is in flight).
+ * Pieces are dealt round-robin to the threads; nothing is shared between them but the job record.
+ *
+ * Host-only code (no kernels); compiled with hipcc like the rest of the C-ABI implementation.
+ */
+#include "gt4hip_host.h"
+
+#include <errno.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+namespace {
+
+constexpr size_t PIECE = 8u << 20; /* bytes per staging buffer */
+constexpr int MAX_THREADS = 16;
+
+enum JobKind { JOB_NONE = 0, JOB_FD_TO_DEV, JOB_MEM_TO_DEV, JOB_DEV_TO_FD, JOB_DEV_TO_MEM, JOB_EXIT };
+
+struct Job {
+  int kind;
+  int fd;
+  off_t file_off;
+  const char *src_mem;
+  char *dst_mem;
+  char *dev;
+  size_t bytes;
+};
+
+struct Worker {
+  gt4hip_io *io;
+  int index;
+  pthread_t thread;
+  void *pinned[2];
+  hipStream_t stream;
+  int err;           /* errno-style: 0 ok, 1 read/write failed, 2 HIP failed */
+};
+
+}  // namespace
+
+struct gt4hip_io {
+  int device;
+  int n_threads;
+  Worker w[MAX_THREADS];
+  pthread_mutex_t mu;
+  pthread_cond_t cv_start, cv_done;
+  Job job;
+  unsigned long generation; /* bumped per job */
+  int running;              /* workers still busy with the current job */
+};
+
+namespace {
+
+int full_pread (int fd, void *buf, size_t len, off_t off)
+{
+  char *p = (char *) buf;
+  while (len) {
+    const ssize_t r = pread (fd, p, len, off);
+    if (r < 0) {
+      if (errno == EINTR) continue;
+      return 1;
+    }
+    if (r == 0) return 1; /* file shorter than its header promised */
+    p += r;
+    off += r;
+    len -= (size_t) r;
+  }
+  return 0;
+}
+
+int full_pwrite (int fd, const void *buf, size_t len, off_t off)
+{
+  const char *p = (const char *) buf;
+  while (len) {
+    const ssize_t r = pwrite (fd, p, len, off);
+    if (r < 0) {
+      if (errno == EINTR) continue;
+      return 1;
+    }
+    p += r;
+    off += r;
+    len -= (size_t) r;
+  }
+  return 0;
+}
+
+/* pieces index, index + T, ... of the job, double-buffered on this worker's stream */
+void run_job (Worker *w, const Job &j)
+{
+  const size_t n_pieces = (j.bytes + PIECE - 1) / PIECE;
+  const size_t T = (size_t) w->io->n_threads;
+  const bool to_dev = j.kind == JOB_FD_TO_DEV || j.kind == JOB_MEM_TO_DEV;
+  w->err = 0;
+  if (to_dev) {
+    int slot = 0;
+    bool busy[2] = { false, false };
+    hipEvent_t ev[2];
+    hipEventCreateWithFlags (&ev[0], hipEventDisableTiming);
+    hipEventCreateWithFlags (&ev[1], hipEventDisableTiming);
+    for (size_t p = (size_t) w->index; p < n_pieces && !w->err; p += T) {
+      const size_t off = p * PIECE, len = j.bytes - off < PIECE ? j.bytes - off : PIECE;
+      if (busy[slot] && hipEventSynchronize (ev[slot]) != hipSuccess) w->err = 2;
+      if (j.kind == JOB_FD_TO_DEV) {
+        if (full_pread (j.fd, w->pinned[slot], len, j.file_off + (off_t) off)) w->err = 1;
+      } else {
+        memcpy (w->pinned[slot], j.src_mem + off, len);
+      }
+      if (!w->err && hipMemcpyAsync (j.dev + off, w->pinned[slot], len, hipMemcpyHostToDevice, w->stream) != hipSuccess) w->err = 2;
+      hipEventRecord (ev[slot], w->stream);
+      busy[slot] = true;
+      slot ^= 1;
+    }
+    if (hipStreamSynchronize (w->stream) != hipSuccess) w->err = 2;
+    hipEventDestroy (ev[0]);
+    hipEventDestroy (ev[1]);
+  } else {
+    /* device -> pinned (async) -> file / memory: the copy of piece i+1 runs while piece i is written */
+    size_t p = (size_t) w->index;
+    int slot = 0;
+    size_t cur_off = 0, cur_len = 0;
+    bool have = false;
+    auto issue = [&] (size_t piece, int s) {
+      const size_t off = piece * PIECE, len = j.bytes - off < PIECE ? j.bytes - off : PIECE;
+      if (hipMemcpyAsync (w->pinned[s], j.dev + off, len, hipMemcpyDeviceToHost, w->stream) != hipSuccess) w->err = 2;
+    };
+    if (p < n_pieces) {
+      issue (p, slot);
+      cur_off = p * PIECE;
+      cur_len = j.bytes - cur_off < PIECE ? j.bytes - cur_off : PIECE;
+      have = true;
+    }
+    while (have && !w->err) {
+      if (hipStreamSynchronize (w->stream) != hipSuccess) w->err = 2;
+      const size_t nxt = p + T;
+      const int done_slot = slot;
+      const size_t done_off = cur_off, done_len = cur_len;
+      if (nxt < n_pieces) {
+        slot ^= 1;
+        issue (nxt, slot);
+        cur_off = nxt * PIECE;
+        cur_len = j.bytes - cur_off < PIECE ? j.bytes - cur_off : PIECE;
+        p = nxt;
+      } else {
+        have = false;
+      }
+      if (!w->err) {
+        if (j.kind == JOB_DEV_TO_FD) {
+          if (full_pwrite (j.fd, w->pinned[done_slot], done_len, j.file_off + (off_t) done_off)) w->err = 1;
+        } else {
+          memcpy (j.dst_mem + done_off, w->pinned[done_slot], done_len);
+        }
+      }
+    }
+    hipStreamSynchronize (w->stream);
+  }
+}
+
+void *worker_main (void *arg)
+{
+  Worker *w = (Worker *) arg;
+  gt4hip_io *io = w->io;
+  hipSetDevice (io->device);
+  unsigned long seen = 0;
+  for (;;) {
+    pthread_mutex_lock (&io->mu);
+    while (io->generation == seen) pthread_cond_wait (&io->cv_start, &io->mu);
+    seen = io->generation;
+    const Job j = io->job;
+    pthread_mutex_unlock (&io->mu);
+    if (j.kind == JOB_EXIT) return NULL;
+    run_job (w, j);
+    pthread_mutex_lock (&io->mu);
+    if (--io->running == 0) pthread_cond_signal (&io->cv_done);
+    pthread_mutex_unlock (&io->mu);
+  }
+}
+
+int io_get (gt4hip_context *ctx, gt4hip_io **out)
+{
+  if (ctx->io) {
+    *out = ctx->io;
+    return GT4HIP_OK;
+  }
+  gt4hip_io *io = (gt4hip_io *) calloc (1, sizeof (gt4hip_io));
+  if (!io) return gt4hip_fail (ctx, GT4HIP_ENOMEM, "host allocation failed");
+  io->device = ctx->device;
+  int T = 4;
+  const char *e = getenv ("GT4HIP_IO_THREADS");
+  if (e && atoi (e) > 0) T = atoi (e);
+  if (T > MAX_THREADS) T = MAX_THREADS;
+  pthread_mutex_init (&io->mu, NULL);
+  pthread_cond_init (&io->cv_start, NULL);
+  pthread_cond_init (&io->cv_done, NULL);
+  int made = 0;
+  bool bad = false;
+  for (; made < T && !bad; made++) {
+    Worker *w = &io->w[made];
+    w->io = io;
+    w->index = made;
+    if (hipHostMalloc (&w->pinned[0], PIECE, hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc (&w->pinned[1], PIECE, hipHostMallocDefault) != hipSuccess ||
+        hipStreamCreateWithFlags (&w->stream, hipStreamNonBlocking) != hipSuccess)
+      bad = true;
+  }
+  if (bad) {
+    (void) hipGetLastError ();
+    for (int i = 0; i < made; i++) {
+      if (io->w[i].pinned[0]) hipHostFree (io->w[i].pinned[0]);
+      if (io->w[i].pinned[1]) hipHostFree (io->w[i].pinned[1]);
+      if (io->w[i].stream) hipStreamDestroy (io->w[i].stream);
+    }
+    free (io);
+    return gt4hip_fail (ctx, GT4HIP_ENOMEM, "pinned staging buffers could not be allocated");
+  }
+  io->n_threads = T;
+  for (int i = 0; i < T; i++) pthread_create (&io->w[i].thread, NULL, worker_main, &io->w[i]);
+  ctx->io = io;
+  *out = io;
+  return GT4HIP_OK;
+}
+
+int io_run (gt4hip_context *ctx, const Job &job, const char *what)
+{
+  gt4hip_io *io = NULL;
+  int rc = io_get (ctx, &io);
+  if (rc) return rc;
+  /* everything enqueued on the context's own stream (the kernels that produced / will consume the
+   * records) is ordered against the copy streams by a full synchronisation on both sides */
+  HIPCHK (ctx, hipStreamSynchronize (ctx->stream));
+  pthread_mutex_lock (&io->mu);
+  io->job = job;
+  io->running = io->n_threads;
+  io->generation++;
+  pthread_cond_broadcast (&io->cv_start);
+  while (io->running) pthread_cond_wait (&io->cv_done, &io->mu);
+  pthread_mutex_unlock (&io->mu);
+  for (int i = 0; i < io->n_threads; i++) {
+    if (io->w[i].err == 1) return gt4hip_fail (ctx, GT4HIP_EIO, "%s: file I/O failed: %s", what, strerror (errno));
+    if (io->w[i].err == 2) {
+      (void) hipGetLastError ();
+      return gt4hip_fail (ctx, GT4HIP_EHIP, "%s: a HIP copy failed", what);
+    }
+  }
+  return GT4HIP_OK;
+}
+
+}  // namespace
+
+void gt4hip_io_destroy (gt4hip_context *ctx)
+{
+  gt4hip_io *io = ctx->io;
+  if (!io) return;
+  pthread_mutex_lock (&io->mu);
+  io->job.kind = JOB_EXIT;
+  io->generation++;
+  pthread_cond_broadcast (&io->cv_start);
+  pthread_mutex_unlock (&io->mu);
+  for (int i = 0; i < io->n_threads; i++) {
+    pthread_join (io->w[i].thread, NULL);
+    hipHostFree (io->w[i].pinned[0]);
+    hipHostFree (io->w[i].pinned[1]);
+    hipStreamDestroy (io->w[i].stream);
+  }
+  pthread_mutex_destroy (&io->mu);
+  pthread_cond_destroy (&io->cv_start);
+  pthread_cond_destroy (&io->cv_done);
+  free (io);
+  ctx->io = NULL;
+}
+
+/* below this size a plain hipMemcpy is as fast and the staging threads are not worth waking */
+static const size_t IO_THRESHOLD = 32u << 20;
+
+extern "C" int gt4hip_list_load_fd (gt4hip_context *ctx, gt4hip_list *list, int fd, uint64_t file_offset, uint64_t n_words)
+{
+  if (!ctx || !list || n_words > list->capacity) return GT4HIP_EINVAL;
+  HIPCHK (ctx, hipSetDevice (ctx->device));
+  list->n_words = n_words;
+  if (!n_words) return GT4HIP_OK;
+  Job j;
+  memset (&j, 0, sizeof j);
+  j.kind = JOB_FD_TO_DEV;
+  j.fd = fd;
+  j.file_off = (off_t) file_offset;
+  j.dev = (char *) list->dev;
+  j.bytes = (size_t) n_words * GT4HIP_RECORD_BYTES;
+  return io_run (ctx, j, "gt4hip_list_load_fd");
+}
+
+extern "C" int gt4hip_list_upload_fd (gt4hip_context *ctx, int fd, uint64_t file_offset, uint64_t n_words, uint32_t word_length, gt4hip_list **out)
+{
+  if (!ctx || !out) return GT4HIP_EINVAL;
+  HIPCHK (ctx, hipSetDevice (ctx->device));
+  gt4hip_list *l = NULL;
+  int rc = gt4hip_list_new (ctx, n_words, word_length, &l);
+  if (rc) return rc;
+  rc = gt4hip_list_load_fd (ctx, l, fd, file_offset, n_words);
+  if (rc) {
+    gt4hip_list_free (l);
+    return rc;
+  }
+  *out = l;
+  return GT4HIP_OK;
+}
+
+extern "C" int gt4hip_list_load (gt4hip_context *ctx, gt4hip_list *list, const void *host_records, uint64_t n_words)
+{
+  if (!ctx || !list || n_words > list->capacity || (n_words && !host_records)) return GT4HIP_EINVAL;
+  HIPCHK (ctx, hipSetDevice (ctx->device));
+  list->n_words = n_words;
+  if (!n_words) return GT4HIP_OK;
+  const size_t bytes = (size_t) n_words * GT4HIP_RECORD_BYTES;
+  if (bytes < IO_THRESHOLD) {
+    HIPCHK (ctx, hipMemcpyAsync (list->dev, host_records, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK (ctx, hipStreamSynchronize (ctx->stream));
+    return GT4HIP_OK;
+  }
+  Job j;
+  memset (&j, 0, sizeof j);
+  j.kind = JOB_MEM_TO_DEV;
+  j.src_mem = (const char *) host_records;
+  j.dev = (char *) list->dev;
+  j.bytes = bytes;
+  return io_run (ctx, j, "gt4hip_list_load");
+}
+
+extern "C" int gt4hip_list_write_fd (gt4hip_context *ctx, const gt4hip_list *list, uint64_t first, uint64_t count, int fd, uint64_t file_offset)
+{
+  if (!ctx || !list || first > list->n_words || count > list->n_words - first) return GT4HIP_EINVAL;
+  if (!count) return GT4HIP_OK;
+  HIPCHK (ctx, hipSetDevice (ctx->device));
+  Job j;
+  memset (&j, 0, sizeof j);
+  j.kind = JOB_DEV_TO_FD;
+  j.fd = fd;
+  j.file_off = (off_t) file_offset;
+  j.dev = (char *) list->dev + first * GT4HIP_RECORD_BYTES;
+  j.bytes = (size_t) count * GT4HIP_RECORD_BYTES;
+  return io_run (ctx, j, "gt4hip_list_write_fd");
+}
+
+/* used by gt4hip_list_download_range for large ranges */
+int gt4hip_io_download (gt4hip_context *ctx, const void *dev, void *host, size_t bytes)
+{
+  Job j;
+  memset (&j, 0, sizeof j);
+  j.kind = JOB_DEV_TO_MEM;
+  j.dst_mem = (char *) host;
+  j.dev = (char *) dev;
+  j.bytes = bytes;
+  return io_run (ctx, j, "gt4hip_list_download");
+}

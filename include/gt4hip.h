@@ -41,7 +41,9 @@ enum {
   GT4HIP_EHIP = 5,        /* a HIP call or kernel failed                     */
   GT4HIP_EWORDLEN = 6,    /* lists of different word length                  */
   GT4HIP_EINTERNAL = 7,   /* in-kernel consistency check tripped             */
-  GT4HIP_ECALLBACK = 8    /* (internal) walk stopped by the caller's callback */
+  GT4HIP_ECALLBACK = 8,   /* (internal) walk stopped by the caller's callback */
+  GT4HIP_EIO = 9,         /* reading or writing a file descriptor failed       */
+  GT4HIP_ECOMM = 10       /* RCCL could not be loaded / a collective failed    */
 };
 
 /* enum Rules of the reference, src/glistcompare.c:45-54 (same numeric values) */
@@ -78,6 +80,8 @@ const char *gt4hip_last_error (const gt4hip_context *ctx);
 const char *gt4hip_strerror (int code);
 /* Number of HIP devices visible; 0 when there is none or the runtime is unusable. */
 int gt4hip_device_count (void);
+/* Free and total bytes of the context's device memory right now (hipMemGetInfo). */
+int gt4hip_device_memory (gt4hip_context *ctx, uint64_t *free_bytes, uint64_t *total_bytes);
 /* "name|gcnArch|CUs|HBM bytes" of the context's device, for logs. */
 const char *gt4hip_device_info (const gt4hip_context *ctx);
 
@@ -102,6 +106,22 @@ int gt4hip_list_alloc (gt4hip_context *ctx, uint64_t capacity, uint32_t word_len
 /* A view of records [first, first+count) of `list` (shares storage; used for key-range shards). */
 int gt4hip_list_slice (gt4hip_context *ctx, const gt4hip_list *list, uint64_t first, uint64_t count,
                        gt4hip_list **out);
+/* File <-> HBM transfers (replace gt4_mmap + scout, src/utils.c:35-99, and the
+ * fwrite / write output loops, src/glistcompare.c:491-496, :579-582).  The body of a list moves in
+ * 8 MiB pieces through pinned staging buffers owned by the context (set up once, on first use) on
+ * GT4HIP_IO_THREADS (default 4) copy threads, each with its own HIP stream: pread -> pinned -> HBM
+ * and HBM -> pinned -> pwrite overlap piece by piece.  `fd` needs no particular file position.
+ *   _upload_fd  new list from n_words records at byte `file_offset` of `fd`
+ *   _load_fd    the same into an existing list (capacity >= n_words; sets n_words)
+ *   _load       the same from host memory (large pageable buffers go through the staging threads)
+ *   _write_fd   records [first, first+count) of `list` to `fd` at byte `file_offset` (pwrite: several
+ *               writers -- threads or processes -- may fill disjoint extents of one file) */
+int gt4hip_list_upload_fd (gt4hip_context *ctx, int fd, uint64_t file_offset, uint64_t n_words, uint32_t word_length,
+                           gt4hip_list **out);
+int gt4hip_list_load_fd (gt4hip_context *ctx, gt4hip_list *list, int fd, uint64_t file_offset, uint64_t n_words);
+int gt4hip_list_load (gt4hip_context *ctx, gt4hip_list *list, const void *host_records, uint64_t n_words);
+int gt4hip_list_write_fd (gt4hip_context *ctx, const gt4hip_list *list, uint64_t first, uint64_t count, int fd,
+                          uint64_t file_offset);
 /* Copies the records back to host memory (n_words * 12 bytes). */
 int gt4hip_list_download (gt4hip_context *ctx, const gt4hip_list *list, void *host_records);
 /* Copies records [first, first+count) back to host memory. */
@@ -197,6 +217,35 @@ int gt4hip_probe_table (gt4hip_context *ctx, const gt4hip_list *const lists[], u
 int gt4hip_table_download (gt4hip_context *ctx, const gt4hip_count_table *table, uint64_t first,
                            uint64_t count, uint64_t *host_keys, uint32_t *host_counts);
 void gt4hip_table_free (gt4hip_count_table *table);
+
+/* ---------------------------------------------------------------- (e) key-range shards across GPUs */
+
+/* Every set operation above is key-local, so the key space can be cut into contiguous ranges: shard
+ * g merges only the records of its range (cut out of every input with a lower_bound), and the shards'
+ * outputs concatenated in shard order are the sorted result.  One process per GPU.
+ * First key of shard g of n_shards equal-width ranges of the 4^word_length key space (2^64 for
+ * k = 32); shard g covers [first(g), first(g+1)), the last one everything from first(n_shards-1). */
+uint64_t gt4hip_shard_first_key (uint32_t word_length, uint32_t n_shards, uint32_t g);
+
+/* The exchange step: gatherv of the shards' records on `root` over RCCL (xGMI inside a node), as
+ * grouped ncclSend / ncclRecv (RCCL has no native gatherv).  librccl.so is loaded by the first call
+ * of this group only.  The communicator id is made by ONE rank (gt4hip_comm_unique_id) and handed
+ * to the others by whatever the host has (shared memory after fork, a file, MPI, torch.distributed). */
+#define GT4HIP_COMM_ID_BYTES 128
+typedef struct gt4hip_comm gt4hip_comm;
+int gt4hip_comm_unique_id (void *id_out);
+int gt4hip_comm_create (gt4hip_context *ctx, const void *id, int n_ranks, int rank, gt4hip_comm **comm);
+void gt4hip_comm_destroy (gt4hip_comm *comm);
+int gt4hip_comm_rank (const gt4hip_comm *comm);
+int gt4hip_comm_size (const gt4hip_comm *comm);
+/* Message of the last failed gt4hip_comm_unique_id (no context yet at that point). */
+const char *gt4hip_comm_last_error (void);
+/* counts[r] = records rank r contributes (every rank passes the same array: the all-gathered header
+ * totals).  Rank r sends the first counts[r] records of `local`; on `root`, `gathered` (capacity >=
+ * the sum) receives them in rank order and its n_words is set; other ranks pass NULL.  Blocks until
+ * this rank's part is done. */
+int gt4hip_comm_gatherv (gt4hip_comm *comm, const gt4hip_list *local, const uint64_t counts[], int root,
+                         gt4hip_list *gathered);
 
 /* ---------------------------------------------------------------- synthetic lists (bench) */
 
