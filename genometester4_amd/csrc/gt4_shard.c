@@ -590,7 +590,7 @@ int gt4_shard_run (const GT4ShardJob *job, GT4ShardResult *res)
       }
     }
     /* a worker that dies (not merely fails) would leave the others at a barrier: end them */
-    int left = G;
+    int left = G, killed = 0; /* killed: the remaining workers were ended by this process */
     while (left > 0) {
       int status = 0;
       const pid_t pid = waitpid (-1, &status, 0);
@@ -605,18 +605,23 @@ int gt4_shard_run (const GT4ShardJob *job, GT4ShardResult *res)
       pids[r] = 0;
       left--;
       if (!WIFEXITED (status)) {
-        fprintf (stderr, "Error: GPU worker %d ended abnormally (status 0x%x)\n", r, status);
+        if (!killed) fprintf (stderr, "Error: GPU worker %d ended abnormally (status 0x%x)\n", r, status);
         sh->failed = 1;
         rc = 1;
+        killed = 1;
         for (int q = 0; q < G; q++)
           if (pids[q] > 0) kill (pids[q], SIGKILL);
       } else if (WEXITSTATUS (status)) {
-        /* a worker that failed has left the pipeline: the others cannot complete the job (and in
-         * gather mode would wait for it inside a collective) */
+        /* a worker that failed has left the pipeline; the others see the flag, skip their remaining
+         * work and meet it at the final barrier -- except in gather mode, where they may be waiting
+         * for it inside a collective */
         rc = 1;
         sh->failed = 1;
-        for (int q = 0; q < G; q++)
-          if (pids[q] > 0) kill (pids[q], SIGKILL);
+        if (job->gather_rccl) {
+          killed = 1;
+          for (int q = 0; q < G; q++)
+            if (pids[q] > 0) kill (pids[q], SIGKILL);
+        }
       }
     }
     if (rc) {
