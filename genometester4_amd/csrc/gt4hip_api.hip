@@ -85,6 +85,7 @@ extern "C" int gt4hip_create (int device, gt4hip_context **out)
   }
   ctx->n_cus = prop.multiProcessorCount;
   ctx->pool_cap = prop.totalGlobalMem / 2;
+  ctx->kway_enabled = 1;
   snprintf (ctx->info, sizeof ctx->info, "%s|%s|%d|%zu", prop.name, prop.gcnArchName, prop.multiProcessorCount, prop.totalGlobalMem);
   if ((e = hipStreamCreateWithFlags (&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
     delete ctx->pool;
@@ -114,6 +115,7 @@ extern "C" void gt4hip_destroy (gt4hip_context *ctx)
     delete ctx->pool;
   }
   if (ctx->part) hipFree (ctx->part);
+  if (ctx->kway_part) hipFree (ctx->kway_part);
   if (ctx->desc) hipFree (ctx->desc);
   if (ctx->block_sums) hipFree (ctx->block_sums);
   if (ctx->ctl) hipFree (ctx->ctl);
@@ -155,6 +157,8 @@ extern "C" int gt4hip_set_option (gt4hip_context *ctx, const char *name, int64_t
     if (ctx->pool_bytes > ctx->pool_cap) pool_flush (ctx);
   }
   else if (!strcmp (name, "grid")) ctx->grid_override = value;
+  else if (!strcmp (name, "kway")) ctx->kway_enabled = value != 0;
+  else if (!strcmp (name, "kway_g")) ctx->kway_g = value;
   else if (!strcmp (name, "spin_limit")) ctx->spin_limit = value > 0 ? (uint32_t) value : 0u;
   else if (!strcmp (name, "geom1")) ctx->force_geom = value != 0 ? 1 : 0;
   else if (!strcmp (name, "geom0")) ctx->force_geom = value != 0 ? -1 : 0;
@@ -166,6 +170,8 @@ extern "C" int gt4hip_get_counter (gt4hip_context *ctx, const char *name, uint64
 {
   if (!ctx || !name || !value) return GT4HIP_EINVAL;
   if (!strcmp (name, "single_pass_fallbacks")) *value = ctx->single_pass_fallbacks;
+  else if (!strcmp (name, "kway_calls")) *value = ctx->kway_calls;
+  else if (!strcmp (name, "kway_overflows")) *value = ctx->kway_overflows;
   else return gt4hip_fail (ctx, GT4HIP_EINVAL, "unknown counter %s", name);
   return GT4HIP_OK;
 }
@@ -743,6 +749,127 @@ static int empty_result (gt4hip_context *ctx, uint32_t word_length, bool count_o
   return gt4hip_list_new (ctx, 0, word_length, &res->out);
 }
 
+/* N-way union by the one-pass tile kernel (gt4hip_kway.hip): groups of up to eight lists per launch;
+ * more than eight lists take levels of eight-way merges that keep every key (ADD / MAX are
+ * associative, NUMBER ignores the counts), the cutoff is applied once, at the last level (:574).
+ * *done = 0: nothing was produced, the caller takes the pairwise tree. */
+static int union_multi_kway (gt4hip_context *ctx, const std::vector<const gt4hip_list *> &work, uint32_t rule, uint32_t cutoff, uint32_t ovr,
+                             bool count_only, gt4hip_multi_result *res, int *done)
+{
+  *done = 0;
+  std::vector<const gt4hip_list *> cur = work;
+  std::vector<gt4hip_list *> owned;
+  const uint32_t wl = work[0]->word_length;
+  int rc = GT4HIP_OK;
+  uint64_t rd = 0, wr = 0;
+  double ms_total = 0;
+  auto drop = [&] () {
+    for (gt4hip_list *l : owned) gt4hip_list_free (l);
+    owned.clear ();
+  };
+  while (cur.size () > 8 && !rc) {
+    std::vector<const gt4hip_list *> next;
+    std::vector<gt4hip_list *> next_owned;
+    for (size_t i = 0; i < cur.size () && !rc; i += 8) {
+      const size_t g = cur.size () - i < 8 ? cur.size () - i : 8;
+      if (g < 3) { /* one or two left over: carried to the next level as they are */
+        for (size_t j = 0; j < g; j++) next.push_back (cur[i + j]);
+        continue;
+      }
+      uint64_t cap = 0;
+      for (size_t j = 0; j < g; j++) cap += cur[i + j]->n_words;
+      gt4hip_list *o = NULL;
+      rc = gt4hip_list_new (ctx, cap, wl, &o);
+      if (rc) break;
+      uint64_t n = 0, t = 0;
+      double ms = 0;
+      int used = 0;
+      rc = gt4hip_kway_union (ctx, &cur[i], (uint32_t) g, rule, cutoff, ovr, FILTER_RAW, false, o, &n, &t, &ms, &used);
+      if (rc || !used) {
+        gt4hip_list_free (o);
+        for (gt4hip_list *l : next_owned) gt4hip_list_free (l);
+        drop ();
+        return rc;
+      }
+      o->n_words = n;
+      rd += cap;
+      wr += n;
+      ms_total += ms;
+      next.push_back (o);
+      next_owned.push_back (o);
+    }
+    /* the previous level's temporaries are consumed, except those carried over */
+    for (gt4hip_list *l : owned) {
+      bool carried = false;
+      for (const gt4hip_list *n : next) carried |= (n == l);
+      if (carried) next_owned.push_back (l);
+      else gt4hip_list_free (l);
+    }
+    owned.swap (next_owned);
+    cur.swap (next);
+  }
+  if (rc) {
+    drop ();
+    return rc;
+  }
+  if (cur.size () < 3) {
+    /* (possible only behind a level of eight-way merges) the last one or two go through the pair kernel */
+    gt4hip_list empty_b;
+    memset (&empty_b, 0, sizeof empty_b);
+    empty_b.ctx = ctx;
+    empty_b.word_length = wl;
+    const PairParams fin = nway_params (GT4HIP_OP_UNION, rule, cutoff, ovr, FILTER_RESULT);
+    res->device_ms += ms_total;
+    res->records_read += rd;
+    res->records_written += wr;
+    rc = nway_final (ctx, cur[0], cur.size () > 1 ? cur[1] : &empty_b, fin, 0, count_only, res);
+    drop ();
+    *done = rc == GT4HIP_OK;
+    return rc;
+  }
+  uint64_t cap = 0;
+  for (const gt4hip_list *l : cur) cap += l->n_words;
+  gt4hip_list *o = NULL, *made = NULL;
+  if (!count_only) {
+    if (res->out) {
+      if (res->out->capacity < cap) {
+        drop ();
+        return gt4hip_fail (ctx, GT4HIP_EINVAL, "output: capacity %llu < worst case %llu", (unsigned long long) res->out->capacity, (unsigned long long) cap);
+      }
+      o = res->out;
+    } else {
+      rc = gt4hip_list_new (ctx, cap, wl, &made);
+      if (rc) {
+        drop ();
+        return rc;
+      }
+      o = made;
+    }
+  }
+  uint64_t n = 0, t = 0;
+  double ms = 0;
+  int used = 0;
+  rc = gt4hip_kway_union (ctx, cur.data (), (uint32_t) cur.size (), rule, cutoff, ovr, FILTER_RESULT, count_only, o, &n, &t, &ms, &used);
+  drop ();
+  if (rc || !used) {
+    if (made) gt4hip_list_free (made);
+    return rc;
+  }
+  if (o) {
+    o->n_words = n;
+    o->word_length = wl;
+  }
+  res->n_words = n;
+  res->total_count = t;
+  res->out = count_only ? NULL : o;
+  res->device_ms += ms_total + ms;
+  res->records_read += rd + cap;
+  res->records_written += wr + (count_only ? 0 : n);
+  ctx->kway_calls++;
+  *done = 1;
+  return GT4HIP_OK;
+}
+
 extern "C" int gt4hip_union_multi (gt4hip_context *ctx, const gt4hip_list *const lists[], uint32_t n_lists, uint32_t cutoff,
                                     int32_t rule, uint32_t ovr, int32_t count_only, gt4hip_multi_result *res)
 {
@@ -764,6 +891,13 @@ extern "C" int gt4hip_union_multi (gt4hip_context *ctx, const gt4hip_list *const
     if (lists[j]->n_words) work.push_back (lists[j]); /* :525-532 empty lists are dropped */
   const uint32_t wl = lists[0]->word_length;
   if (work.empty ()) return empty_result (ctx, wl, count_only != 0, res);
+  if (ctx->kway_enabled && work.size () >= 3) {
+    int done = 0;
+    const int krc = union_multi_kway (ctx, work, (uint32_t) rule, cutoff, ovr, count_only != 0, res, &done);
+    if (krc || done) return krc;
+    res->device_ms = 0;
+    res->records_read = res->records_written = 0;
+  }
   gt4hip_list empty_b;
   memset (&empty_b, 0, sizeof empty_b);
   empty_b.ctx = ctx;

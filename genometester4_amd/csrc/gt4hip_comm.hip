@@ -15,7 +15,9 @@
 #include "gt4hip_host.h"
 
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <rccl/rccl.h>
+#include <unistd.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -38,6 +40,31 @@ struct Rccl {
 
 Rccl g_rccl;
 char g_comm_err[256] = "";
+
+/* RCCL prints a version banner on stderr when the first communicator is made; a drop-in command-line
+ * tool must not add lines to its transcript, so stderr points to /dev/null for the duration of the
+ * call (failures come back as return codes and are reported by the caller).  GT4HIP_RCCL_VERBOSE=1
+ * keeps the banner. */
+struct QuietStderr {
+  int saved;
+  QuietStderr () : saved (-1)
+  {
+    if (getenv ("GT4HIP_RCCL_VERBOSE")) return;
+    fflush (stderr);
+    const int nul = open ("/dev/null", O_WRONLY);
+    if (nul < 0) return;
+    saved = dup (2);
+    if (saved >= 0) dup2 (nul, 2);
+    close (nul);
+  }
+  ~QuietStderr ()
+  {
+    if (saved < 0) return;
+    fflush (stderr);
+    dup2 (saved, 2);
+    close (saved);
+  }
+};
 
 const Rccl *rccl ()
 {
@@ -87,6 +114,7 @@ extern "C" int gt4hip_comm_unique_id (void *id_out)
   const Rccl *r = rccl ();
   if (!r) return GT4HIP_ECOMM;
   ncclUniqueId id;
+  QuietStderr quiet;
   const ncclResult_t e = r->GetUniqueId (&id);
   if (e != ncclSuccess) {
     snprintf (g_comm_err, sizeof g_comm_err, "ncclGetUniqueId: %s", r->GetErrorString (e));
@@ -109,7 +137,11 @@ extern "C" int gt4hip_comm_create (gt4hip_context *ctx, const void *id_bytes, in
   c->rank = rank;
   ncclUniqueId id;
   memcpy (&id, id_bytes, sizeof id);
-  const ncclResult_t e = r->CommInitRank (&c->comm, n_ranks, id, rank);
+  ncclResult_t e;
+  {
+    QuietStderr quiet;
+    e = r->CommInitRank (&c->comm, n_ranks, id, rank);
+  }
   if (e != ncclSuccess) {
     delete c;
     return gt4hip_fail (ctx, GT4HIP_ECOMM, "ncclCommInitRank (rank %d of %d): %s", rank, n_ranks, r->GetErrorString (e));

@@ -1,0 +1,276 @@
+/* gt4hip_device.h -- device helpers shared by the kernel files (gt4hip_kernels.hip: pair merge;
+ * gt4hip_kway.hip: N-way tile merge): record access, wave scans, the chained scan of tile totals
+ * (scanner wavefront + offset resolve), tile write-out.  gfx950 only, wave64. */
+#ifndef GT4HIP_DEVICE_H
+#define GT4HIP_DEVICE_H
+
+#include "gt4hip_internal.h"
+
+namespace gt4 {
+namespace {
+
+constexpr int WAVE = 64;
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+typedef u32 u32x4 __attribute__ ((ext_vector_type (4)));
+
+/* ------------------------------------------------------------------ record access */
+
+/* record i of a packed list viewed as dwords: key = words 3i, 3i+1; count = word 3i+2
+ * (reference src/word-map.h:89-99: u64 at +0, u32 at +8, stride 12) */
+__device__ __forceinline__ u64 load_key (const u32 *__restrict__ rec, u64 i)
+{
+  const u32 *p = rec + 3 * i;
+  return (u64) p[0] | ((u64) p[1] << 32);
+}
+
+
+/* ------------------------------------------------------------------ wave / block scans */
+
+__device__ __forceinline__ u64 shfl_up_u64 (u64 v, int d)
+{
+  const u32 lo = __shfl_up ((u32) v, d, WAVE), hi = __shfl_up ((u32) (v >> 32), d, WAVE);
+  return (u64) lo | ((u64) hi << 32);
+}
+
+__device__ __forceinline__ u64 shfl_xor_u64 (u64 v, int m)
+{
+  const u32 lo = __shfl_xor ((u32) v, m, WAVE), hi = __shfl_xor ((u32) (v >> 32), m, WAVE);
+  return (u64) lo | ((u64) hi << 32);
+}
+
+__device__ __forceinline__ u64 wave_inclusive_scan (u64 v, int lane)
+{
+#pragma unroll
+  for (int d = 1; d < WAVE; d <<= 1) {
+    const u64 o = shfl_up_u64 (v, d);
+    if (lane >= d) v += o;
+  }
+  return v;
+}
+
+__device__ __forceinline__ u64 wave_sum (u64 v)
+{
+#pragma unroll
+  for (int m = WAVE / 2; m > 0; m >>= 1) v += shfl_xor_u64 (v, m);
+  return v;
+}
+
+/* Inclusive prefix sum over the 64 lanes with DPP (no LDS crossbar, no dependent ds_bpermute
+ * chain: ~12 VALU instructions instead of ~1000 cycles of shuffles).  gfx9 data-parallel
+ * primitives: row_shr:n inside each row of 16 lanes, then row_bcast:15 / row_bcast:31 carry the
+ * row totals into the following rows; lanes without a source contribute 0.  Lane 63 ends up
+ * with the wave total. */
+__device__ __forceinline__ u32 dpp_inclusive_scan_u32 (u32 v)
+{
+  v += (u32) __builtin_amdgcn_update_dpp (0, (int) v, 0x111, 0xf, 0xf, false); /* row_shr:1 */
+  v += (u32) __builtin_amdgcn_update_dpp (0, (int) v, 0x112, 0xf, 0xf, false); /* row_shr:2 */
+  v += (u32) __builtin_amdgcn_update_dpp (0, (int) v, 0x114, 0xf, 0xf, false); /* row_shr:4 */
+  v += (u32) __builtin_amdgcn_update_dpp (0, (int) v, 0x118, 0xf, 0xf, false); /* row_shr:8 */
+  v += (u32) __builtin_amdgcn_update_dpp (0, (int) v, 0x142, 0xa, 0xf, false); /* row_bcast:15 -> rows 1, 3 */
+  v += (u32) __builtin_amdgcn_update_dpp (0, (int) v, 0x143, 0xc, 0xf, false); /* row_bcast:31 -> rows 2, 3 */
+  return v;
+}
+
+__device__ __forceinline__ u32 dpp_wave_sum_u32 (u32 v)
+{
+  return (u32) __builtin_amdgcn_readlane ((int) dpp_inclusive_scan_u32 (v), WAVE - 1);
+}
+
+/* Exclusive prefix of the chunk ballots' popcounts (up to 128 chunks: two per lane, packed into
+ * the halves of one dword for a single scan) and the empty sentinel chunk behind them; returns the
+ * tile total.  Every lane of the calling wavefront takes part. */
+template <int NCH>
+__device__ __forceinline__ u32 chunk_scan (u64 *km, u32 *cp, int lane)
+{
+  static_assert (NCH <= 2 * WAVE, "two chunks per lane");
+  const u32 v0 = lane < NCH ? (u32) __popcll (km[lane]) : 0u;
+  const u32 v1 = (NCH > WAVE && lane + WAVE < NCH) ? (u32) __popcll (km[NCH > WAVE ? lane + WAVE : 0]) : 0u;
+  const u32 incl = dpp_inclusive_scan_u32 (v0 | (v1 << 16));
+  const u32 last = (u32) __builtin_amdgcn_readlane ((int) incl, WAVE - 1);
+  const u32 t0 = last & 0xffffu, total = t0 + (last >> 16);
+  if (lane < NCH) cp[lane] = (incl & 0xffffu) - v0;
+  if (NCH > WAVE && lane + WAVE < NCH) cp[lane + WAVE] = t0 + (incl >> 16) - v1;
+  if (lane == 0) {
+    cp[NCH] = total;
+    km[NCH] = 0;
+  }
+  return total;
+}
+
+/* ------------------------------------------------------------------ tile descriptors (chained scan) */
+
+/* Two-level chained scan of the tiles' output counts.  Per output stream s, zeroed before every
+ * launch:
+ *   agg[s][t]      u32, one per tile: bit 31 = published, low bits = records tile t keeps
+ *   carry[s][r]    u64, one per row of 64 tiles: bit 63 = published, low bits = records kept by
+ *                  all tiles of rows 0..r-1
+ * Workers publish agg.  ONE scanner wavefront per stream walks the rows in order, sums each
+ * complete row and publishes the running carry.  A tile's global output offset is carry[its row]
+ * plus the counts of the tiles before it in its own row -- one coalesced 64-word load, summed by
+ * the worker itself.  Every word is written once by a single relaxed agent-scope store and read
+ * by relaxed agent-scope loads: value and flag travel in the same naturally aligned word, so no
+ * fence is needed (cdna_hip_programming.md Guideline 16, form R2). */
+constexpr u32 AGG_READY = 1u << 31;
+constexpr u64 CARRY_READY = 1ull << 63;
+
+__device__ __forceinline__ void publish_u32 (u32 *p, u32 v) { __hip_atomic_store (p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void publish_u64 (u64 *p, u64 v) { __hip_atomic_store (p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ u32 peek_u32 (u32 *p) { return __hip_atomic_load (p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ u64 peek_u64 (u64 *p) { return __hip_atomic_load (p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+#ifdef GT4_PROFILE_PHASES
+#ifndef GT4_STAMP_TID
+#define GT4_STAMP_TID 0
+#endif
+/* one asm statement with its own wait, fenced from the scheduler (cdna_hip_programming.md section 7, In-kernel stamps) */
+#define PHASE_STAMP(i) do { __builtin_amdgcn_sched_barrier (0); u64 t_; asm volatile ("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier (0); if (tid == GT4_STAMP_TID) { ph[i] += t_ - t_last; } t_last = t_; } while (0)
+#else
+#define PHASE_STAMP(i) do { } while (0)
+#endif
+
+constexpr u32 SPIN_LIMIT = 1u << 22; /* bounded: ~seconds; sets ctl->error instead of hanging */
+#ifndef GT4_SCAN_ROWS
+#define GT4_SCAN_ROWS 16
+#endif
+constexpr int SCAN_ROWS = GT4_SCAN_ROWS;        /* rows of 64 tiles a scanner wavefront keeps in flight */
+
+/* The scanner: one wavefront per stream.  Loads SCAN_ROWS x 64 tile counts at once (so that its
+ * rate is set by L2 bandwidth, not by one round trip per row), waits for each row to be complete,
+ * publishes the carry into the next row. */
+__device__ void scanner_wave (u32 *agg, u64 *carry_out, u64 num_tiles, PairControl *ctl, int lane, u32 spin_limit)
+{
+  /* the scanner shares its SIMD with worker wavefronts and is the one serial resource of the
+   * kernel: it must win the instruction arbitration */
+  __builtin_amdgcn_s_setprio (3);
+  u64 carry = 0;
+  const u64 rows = (num_tiles + WAVE - 1) / WAVE;
+  if (lane == 0) publish_u64 (&carry_out[0], CARRY_READY);
+  /* two batches of SCAN_ROWS rows in flight: while one is summed and published, the loads of the
+   * next are already under way (a batch costs one memory round trip otherwise) */
+  u32 v[SCAN_ROWS], w[SCAN_ROWS];
+  auto load_batch = [&] (u32 (&dst)[SCAN_ROWS], u64 r0) {
+#pragma unroll
+    for (int j = 0; j < SCAN_ROWS; j++) {
+      const u64 idx = (r0 + j) * WAVE + lane;
+      dst[j] = (r0 + j < rows && idx < num_tiles) ? peek_u32 (&agg[idx]) : AGG_READY;
+    }
+  };
+  load_batch (v, 0);
+  for (u64 r0 = 0; r0 < rows; r0 += SCAN_ROWS) {
+    const int n = rows - r0 < (u64) SCAN_ROWS ? (int) (rows - r0) : SCAN_ROWS;
+    load_batch (w, r0 + SCAN_ROWS);
+    int done = 0;
+    u32 spins = 0;
+#ifdef GT4_PROFILE_PHASES
+    u64 st_rounds = 0, st_first = 0;
+#endif
+    for (;;) {
+#ifdef GT4_PROFILE_PHASES
+      const int done_before = done;
+#endif
+      /* retire, in order, every row that is complete */
+#pragma unroll
+      for (int j = 0; j < SCAN_ROWS; j++) {
+        if (j == done && j < n && __all ((v[j] & AGG_READY) != 0)) {
+          carry += dpp_wave_sum_u32 (v[j] & ~AGG_READY);
+          if (lane == 0) publish_u64 (&carry_out[r0 + j + 1], CARRY_READY | carry);
+          done++;
+        }
+      }
+#ifdef GT4_PROFILE_PHASES
+      st_rounds++;
+      if (spins == 0) st_first += (u64) (done - done_before);
+      if (done >= n && lane == 0) {
+        atomicAdd (&ctl->resolve_stats[5], st_rounds);
+        atomicAdd (&ctl->resolve_stats[6], st_first);
+        atomicAdd (&ctl->resolve_stats[7], (u64) n);
+      }
+#endif
+      if (done >= n) break;
+      /* somebody else gave up (the host reruns the call on the two-pass path): give up at this look too */
+      if ((spins & 63u) == 63u && peek_u32 (&ctl->error)) spins = spin_limit;
+      if (++spins > spin_limit) {
+        if (lane == 0) atomicOr (&ctl->error, 4u);
+        return;
+      }
+      /* one round trip re-reads the missing words of ALL pending rows: at the frontier the
+       * scanner must advance several rows per round trip to keep up with the workers */
+#pragma unroll
+      for (int j = 0; j < SCAN_ROWS; j++) {
+        const u64 idx = (r0 + j) * WAVE + lane;
+        if (j >= done && j < n && !(v[j] & AGG_READY)) v[j] = peek_u32 (&agg[idx]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < SCAN_ROWS; j++) v[j] = w[j];
+  }
+}
+
+/* A tile's global output offset: carry of its row + counts of the tiles before it in the row.
+ * `a` and `c` are the values of an earlier, speculative load of the same words (or 0). */
+__device__ __forceinline__ u64 resolve_offset (u32 *agg, u64 *carry, u64 tile, int lane, u32 a, u64 c, PairControl *ctl, u32 spin_limit)
+{
+  const u64 row = tile / WAVE;
+  const u32 pos = (u32) (tile % WAVE);
+  u32 *const wa = &agg[row * WAVE + lane];
+  u64 *const wc = &carry[row];
+  const bool mine = (u32) lane < pos;
+  u32 spins = 0;
+#ifdef GT4_PROFILE_PHASES
+  const bool agg_ok0 = __all (!mine || (a & AGG_READY) != 0), carry_ok0 = (c & CARRY_READY) != 0;
+#endif
+  while (!__all (!mine || (a & AGG_READY) != 0) || !(c & CARRY_READY)) {
+    if (++spins > spin_limit) {
+      if (lane == 0) atomicOr (&ctl->error, 1u);
+      break;
+    }
+    /* once any wait of the launch has given up (the scanner stops publishing then) every other wait
+     * ends at its next look instead of spinning to its own bound, so the rest of the launch runs at
+     * its normal pace: the offset returned is not above the true one (stores stay inside the output)
+     * and is not used -- the host discards the outputs and reruns the call on the two-pass path */
+    if ((spins & 15u) == 0 && peek_u32 (&ctl->error)) break;
+    if (spins > 1) __builtin_amdgcn_s_sleep (1);
+    if (mine && !(a & AGG_READY)) a = peek_u32 (wa);
+    if (!(c & CARRY_READY)) c = peek_u64 (wc);
+  }
+#ifdef GT4_PROFILE_PHASES
+  if (lane == 0 && (tile & 63) == 17) { /* sample 1 in 64 so that the statistics do not perturb the run */
+    atomicAdd (&ctl->resolve_stats[0], 1ull);
+    atomicAdd (&ctl->resolve_stats[1], (u64) spins);
+    atomicAdd (&ctl->resolve_stats[3], agg_ok0 ? 0ull : 1ull);
+    atomicAdd (&ctl->resolve_stats[4], carry_ok0 ? 0ull : 1ull);
+  }
+#endif
+  return (c & ~CARRY_READY) + dpp_wave_sum_u32 (mine ? (a & ~AGG_READY) : 0u);
+}
+
+/* Tile write-out: `tot` packed records from an LDS staging slot (16-byte aligned) to the output
+ * list at record offset `excl`, as 16-byte buffer stores (dword alignment suffices; the
+ * range-checked descriptor drops the dwords past the last record of the partial last chunk). */
+template <int NT>
+__device__ __forceinline__ void write_out_tile (u32 *out_rec, u64 excl, u32 tot, const u32 *slot, int tid)
+{
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc ((void *) (out_rec + 3 * excl), 0, (int) (12 * tot), 0x00020000);
+  const u32 chunks = (3 * tot + 3) >> 2;
+  for (u32 c = (u32) tid; c < chunks; c += NT) {
+    const u32x4 w = *reinterpret_cast<const u32x4 *> (slot + 4 * c);
+    __builtin_amdgcn_raw_buffer_store_b128 (w, r, 16 * c, 0, 0);
+  }
+}
+
+
+/* values read back from LDS are the same in every lane; say so, so that addresses, descriptors and
+ * loop bounds derived from them live in SGPRs (no waterfall loops around the buffer loads) */
+__device__ __forceinline__ u32 uniform32 (u32 v) { return __builtin_amdgcn_readfirstlane (v); }
+__device__ __forceinline__ u64 uniform64 (u64 v)
+{
+  /* the builtin returns int: go through u32 or a low word >= 2^31 sign-extends into the high half */
+  return (u64) uniform32 ((u32) v) | ((u64) uniform32 ((u32) (v >> 32)) << 32);
+}
+
+}  // namespace
+}  // namespace gt4
+
+#endif

@@ -1,0 +1,154 @@
+"""The one-pass N-way union (k_kway_merge, genometester4_amd/csrc/gt4hip_kway.hip) against the CPU
+oracle's union_multi (reference src/glistcompare.c:500-603): rules ADD / MAX / NUMBER, cutoff on the
+resulting count, zero counts, u32 wrap, empty members, more than eight lists (levels of eight-way
+merges), tiles that hold one list only, identical lists (every key eight times), the fallback to the
+pairwise tree when a tile would not fit LDS, and the count-only form."""
+import numpy as np
+import pytest
+
+import gpu_util as U
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from genometester4_amd import capi
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def _check(ctx, lists, k=20, rule=0, cutoff=1, ovr=5, expect_kway=True):
+    dev = [ctx.upload(x, k) for x in lists]
+    before = ctx.get_counter("kway_calls")
+    rc_o, n_o, t_o, r_o = O.union_multi(lists, cutoff, rule, ovr)
+    rc_g, n_g, t_g, out = ctx.union_multi(dev, cutoff, rule, ovr)
+    assert rc_g == rc_o == 0
+    assert (n_g, t_g) == (n_o, t_o)
+    assert out.download().tobytes() == r_o.tobytes()
+    rc_c, n_c, t_c, _ = ctx.union_multi(dev, cutoff, rule, ovr, True)
+    assert (n_c, t_c) == (n_o, t_o)
+    if expect_kway:
+        assert ctx.get_counter("kway_calls") >= before + 2
+    for d in dev:
+        d.free()
+
+
+def _random_lists(rng, n_lists, universe, k_bits=40, zero_counts=True):
+    keys = np.unique(rng.integers(0, 1 << k_bits, size=universe, dtype=np.uint64))
+    lists = []
+    for j in range(n_lists):
+        m = rng.random(len(keys)) < rng.uniform(0.05, 0.9)
+        c = rng.integers(0 if zero_counts else 1, 7, size=int(m.sum()), dtype=np.uint32)
+        lists.append(U.make_records(keys[m], c))
+    return lists
+
+
+@pytest.mark.parametrize("n_lists", [3, 4, 5, 7, 8])
+@pytest.mark.parametrize("rule,cutoff", [(0, 1), (1, 0), (4, 3), (7, 2), (1, 9)])
+def test_random_lists(ctx, n_lists, rule, cutoff):
+    rng = np.random.default_rng(1000 * n_lists + 10 * rule + cutoff)
+    _check(ctx, _random_lists(rng, n_lists, 60000), rule=rule, cutoff=cutoff)
+
+
+@pytest.mark.parametrize("universe", [1, 5, 700, 6143, 6144, 6145, 12289, 200001])
+def test_sizes_around_the_tile_capacity(ctx, universe):
+    rng = np.random.default_rng(universe)
+    keys = np.unique(rng.integers(0, 1 << 44, size=universe, dtype=np.uint64))
+    lists = [U.make_records(keys, rng.integers(1, 9, size=len(keys), dtype=np.uint32)) for _ in range(3)]
+    lists += [U.make_records(keys[::3], rng.integers(1, 9, size=len(keys[::3]), dtype=np.uint32))]
+    _check(ctx, lists, k=22, expect_kway=len(keys) > 0)
+
+
+def test_eight_identical_lists_and_u32_wrap(ctx):
+    rng = np.random.default_rng(8)
+    keys = np.unique(rng.integers(0, 1 << 50, size=150000, dtype=np.uint64))
+    cnt = rng.integers(1, 5, size=len(keys), dtype=np.uint32)
+    cnt[::1000] = 0xFFFFFFFF  # eight times 0xFFFFFFFF wraps to 0xFFFFFFF8; with 0x20000000 x 8 -> 0
+    cnt[1::1000] = 0x20000000
+    lists = [U.make_records(keys, cnt) for _ in range(8)]
+    _check(ctx, lists, k=25)
+    _check(ctx, lists, k=25, rule=4, cutoff=2)
+
+
+def test_disjoint_key_ranges_and_skewed_sizes(ctx):
+    rng = np.random.default_rng(9)
+    lists = []
+    for j in range(6):  # list j owns keys [j * 2^30, (j + 1) * 2^30): every tile holds one list only
+        k = np.unique(rng.integers(j << 30, (j + 1) << 30, size=30000 + 7000 * j, dtype=np.uint64))
+        lists.append(U.make_records(k, rng.integers(1, 9, size=len(k), dtype=np.uint32)))
+    _check(ctx, lists, k=20)
+    _check(ctx, lists[::-1], k=20)
+    big = np.unique(rng.integers(0, 1 << 40, size=900000, dtype=np.uint64))
+    lists = [U.make_records(big, rng.integers(1, 9, size=len(big), dtype=np.uint32))]
+    for n in (1, 17, 300, 5000):
+        s = np.sort(rng.choice(big, size=n, replace=False))
+        lists.append(U.make_records(s, rng.integers(1, 9, size=n, dtype=np.uint32)))
+    own = np.unique(rng.integers(0, 1 << 40, size=2000, dtype=np.uint64))
+    lists.append(U.make_records(own, np.ones(len(own), np.uint32)))
+    _check(ctx, lists, k=20, cutoff=2)
+
+
+def test_k32_keys_up_to_all_ones(ctx):
+    rng = np.random.default_rng(10)
+    base = np.unique(rng.integers(0, 1 << 63, size=40000, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=40000, dtype=np.uint64))
+    top = np.array([0xFFFFFFFFFFFFFFFE, 0xFFFFFFFFFFFFFFFF], dtype=np.uint64)
+    lists = []
+    for j in range(5):
+        m = rng.random(len(base)) < 0.5
+        k = np.concatenate([base[m], top[j % 2:]])
+        lists.append(U.make_records(k, rng.integers(1, 9, size=len(k), dtype=np.uint32)))
+    _check(ctx, lists, k=32)
+
+
+@pytest.mark.parametrize("n_lists", [9, 12, 17, 26])
+def test_more_than_eight_lists(ctx, n_lists):
+    rng = np.random.default_rng(n_lists)
+    lists = _random_lists(rng, n_lists, 40000)
+    lists.insert(3, lists[0][:0])  # an empty member is skipped (:525-532)
+    _check(ctx, lists, rule=1, cutoff=2)
+    _check(ctx, lists, rule=4, cutoff=0)
+
+
+def test_tile_overflow_falls_back_to_the_pairwise_tree(ctx):
+    """64 samples per tile = 16384 records expected per tile > the LDS capacity: the partition check
+    refuses, the call takes the pairwise tree and still gives the reference's bytes."""
+    rng = np.random.default_rng(11)
+    lists = _random_lists(rng, 5, 300000)
+    before = ctx.get_counter("kway_overflows")
+    ctx.set_option("kway_g", 64)
+    try:
+        _check(ctx, lists, expect_kway=False)
+    finally:
+        ctx.set_option("kway_g", 0)
+    assert ctx.get_counter("kway_overflows") > before
+    ctx.set_option("kway", 0)
+    try:
+        _check(ctx, lists, expect_kway=False)
+    finally:
+        ctx.set_option("kway", 1)
+
+
+def test_generated_eight_lists_against_the_oracle(ctx):
+    """Eight 2.5e6-record k=25 lists generated in HBM (the bench's construction: even lists share
+    one key set, odd lists own disjoint residue classes), three sample levels deep."""
+    n = 2_500_000
+    dev, host = [], []
+    for j in range(8):
+        lst = ctx.alloc(n, 25)
+        shared = j % 2 == 0
+        ctx.generate_ex(lst, n, 7 if shared else 100 + j, 50 + j, 8, 16, 0 if shared else 1 + j)
+        dev.append(lst)
+        host.append(lst.download())
+    rc_o, n_o, t_o, r_o = O.union_multi(host, 1, 0, 1)
+    before = ctx.get_counter("kway_calls")
+    rc_g, n_g, t_g, out = ctx.union_multi(dev)
+    assert ctx.get_counter("kway_calls") == before + 1
+    assert (n_g, t_g) == (n_o, t_o) and n_g == 5 * n
+    assert out.download().tobytes() == r_o.tobytes()
+    rc_o, n_o, t_o, r_o = O.union_multi(host, 12, 0, 1)
+    rc_g, n_g, t_g, out = ctx.union_multi(dev, 12)
+    assert (n_g, t_g) == (n_o, t_o)
+    assert out.download().tobytes() == r_o.tobytes()

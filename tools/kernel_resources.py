@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-kernel register / LDS / spill table of gt4hip_kernels.hip as hipcc sees it
-(-Rpass-analysis=kernel-resource-usage).  Usage: tools/kernel_resources.py [substring]"""
+(-Rpass-analysis=kernel-resource-usage).  Usage: tools/kernel_resources.py [substring] [source file in csrc]"""
 import os
 import re
 import subprocess
@@ -12,9 +12,10 @@ SRC = os.path.join(ROOT, "genometester4_amd", "csrc", "gt4hip_kernels.hip")
 
 def main():
     pat = sys.argv[1] if len(sys.argv) > 1 else ""
+    src = os.path.join(os.path.dirname(SRC), sys.argv[2]) if len(sys.argv) > 2 else SRC
     r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm",
                         "-amdgpu-atomic-optimizer-strategy=None", "-Rpass-analysis=kernel-resource-usage",
-                        "-c", SRC, "-o", "/dev/null"], capture_output=True, text=True, cwd=os.path.dirname(SRC))
+                        "-c", src, "-o", "/dev/null"], capture_output=True, text=True, cwd=os.path.dirname(SRC))
     blocks = re.split(r"remark: Function Name: ", r.stderr)[1:]
     names = [b.split("\n")[0].split()[0].strip() for b in blocks]
     dem = subprocess.run(["c++filt"] + names, capture_output=True, text=True).stdout.strip().split("\n")
