@@ -85,7 +85,7 @@ extern "C" int gt4hip_create (int device, gt4hip_context **out)
   }
   ctx->n_cus = prop.multiProcessorCount;
   ctx->pool_cap = prop.totalGlobalMem / 2;
-  ctx->kway_enabled = 1;
+  ctx->kway_enabled = 0; /* measured slower than the pairwise tree (DESIGN.md, N-way): option "kway" = 1 selects it */
   snprintf (ctx->info, sizeof ctx->info, "%s|%s|%d|%zu", prop.name, prop.gcnArchName, prop.multiProcessorCount, prop.totalGlobalMem);
   if ((e = hipStreamCreateWithFlags (&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
     delete ctx->pool;
@@ -159,6 +159,7 @@ extern "C" int gt4hip_set_option (gt4hip_context *ctx, const char *name, int64_t
   else if (!strcmp (name, "grid")) ctx->grid_override = value;
   else if (!strcmp (name, "kway")) ctx->kway_enabled = value != 0;
   else if (!strcmp (name, "kway_g")) ctx->kway_g = value;
+  else if (!strcmp (name, "kway_vt")) ctx->kway_vt = value;
   else if (!strcmp (name, "spin_limit")) ctx->spin_limit = value > 0 ? (uint32_t) value : 0u;
   else if (!strcmp (name, "geom1")) ctx->force_geom = value != 0 ? 1 : 0;
   else if (!strcmp (name, "geom0")) ctx->force_geom = value != 0 ? -1 : 0;
@@ -825,6 +826,7 @@ static int union_multi_kway (gt4hip_context *ctx, const std::vector<const gt4hip
     rc = nway_final (ctx, cur[0], cur.size () > 1 ? cur[1] : &empty_b, fin, 0, count_only, res);
     drop ();
     *done = rc == GT4HIP_OK;
+    if (*done) ctx->kway_calls++;
     return rc;
   }
   uint64_t cap = 0;

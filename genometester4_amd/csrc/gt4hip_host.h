@@ -44,6 +44,7 @@ struct gt4hip_context {
   size_t kway_part_bytes;
   int kway_enabled;          /* option "kway": 0 = always the pairwise tree */
   int64_t kway_g;            /* option "kway_g": samples per tile (0 = automatic) */
+  int64_t kway_vt;           /* option "kway_vt": positions per thread in a merge pass, at least (0 = default) */
   uint64_t kway_overflows;   /* calls that fell back to the tree because a tile would not fit LDS */
   uint64_t kway_calls;       /* N-way unions done by the one-pass kernel */
   gt4hip_io *io;            /* file <-> HBM staging (gt4hip_io.hip), NULL until first used */

@@ -28,6 +28,7 @@
 #include "gt4hip_host.h"
 
 #include <math.h>
+#include <stdio.h>
 #include <string.h>
 
 namespace gt4 {
@@ -35,7 +36,7 @@ namespace gt4 {
 namespace {
 
 constexpr int KWAY_MAX = 8;
-constexpr int KWAY_SAMPLE = 256; /* S: one sample per 256 records (3 KB): the strided gather costs ~4 % of a streaming read */
+constexpr int KWAY_SAMPLE = 128; /* S: one sample per 128 records (1.5 KB): the strided gather costs ~8 % of a streaming read of the inputs */
 
 enum : int { KWAY_COUNT = 0, KWAY_UNION = 1, KWAY_DUPS = 2 };
 
@@ -49,6 +50,7 @@ struct KwayParams {
   u32 filter;          /* FILTER_RAW: keep every key; FILTER_RESULT: count >= cutoff */
   u32 spin_limit;
   u32 num_tiles;
+  u32 vt_min;          /* positions per thread in a merge pass, at least (the split search is paid per thread) */
 };
 
 /* ------------------------------------------------------------------ K5 / K6: samples and tile boundaries */
@@ -111,16 +113,25 @@ __global__ void k_kway_check (const u64 *__restrict__ part, u32 num_tiles, u32 c
 
 /* ------------------------------------------------------------------ K7: tile merge in LDS */
 
+typedef u32 u32x3 __attribute__ ((ext_vector_type (3)));
+
 template <int NT, int CAP>
 struct KwayShared {
-  alignas (16) u32 buf[2][3 * CAP + 4 * KWAY_MAX]; /* two record buffers (the runs of the first pass start on 16-byte boundaries) */
-  u64 rng[2][KWAY_MAX];
-  u32 wave_tot[NT / WAVE];
+  /* two record buffers for the merge passes: 16 bytes per record {key lo, key hi, count, -}, so that
+   * a record is one aligned ds_read_b128 / ds_write_b128 and a key one ds_read_b64 */
+  alignas (16) u32x4 rec[2][CAP + 2]; /* (+2: the merge steps read up to two records ahead) */
+  /* the tile's kept records, packed 12-byte as in the output list; written out during the NEXT tile */
+  alignas (16) u32 stage[3 * CAP + 4];
+  /* run table of the tile being loaded / merged, two deep */
+  u64 tab_start[2][KWAY_MAX];  /* first record of the run in its list */
+  u32 tab_len[2][KWAY_MAX];    /* records */
+  u32 tab_total[2];
+  u64 tab_base[2];             /* sum of the first records (MODE_DUPS: where the tile's output starts) */
+  u64 rng[3][2][KWAY_MAX];     /* part[] entries of the next tiles, three deep */
+  u32 wave_tot[WAVE];         /* kept records per (row of NT positions, wavefront) */
   u64 excl;
   u32 tick[2];
 };
-
-__device__ __forceinline__ u64 lds_key (const u32 *b, u32 dw) { return (u64) b[dw] | ((u64) b[dw + 1] << 32); }
 
 /* P = number of pairwise passes = log2 (run slots): 2 for three or four lists, 3 for five to eight */
 template <int NT, int CAP, int MODE, int P>
@@ -129,6 +140,7 @@ k_kway_merge (KwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
 {
   constexpr int NW = NT / WAVE;
   constexpr int SLOTS = 1 << P;
+  constexpr int J = (CAP / WAVE + KWAY_MAX + NW - 1) / NW; /* 64-record wave slots a wavefront fetches per tile, at most */
   typedef KwayShared<NT, CAP> Shared;
   __shared__ Shared sh;
   const int tid = threadIdx.x, lane = tid & (WAVE - 1);
@@ -151,57 +163,153 @@ k_kway_merge (KwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
   }
   const u32 n_workers = MODE == KWAY_UNION ? gridDim.x - 1 : gridDim.x;
   const u32 wk = MODE == KWAY_UNION ? role - 1 : blockIdx.x;
+  const u64 ntl = p.num_tiles;
+  auto tile_at = [&] (int j) -> u64 { return (u64) wk + (u64) j * n_workers; };
+
+  /* threads 0 .. 7: the run table of the tile whose part[] entries lie in ring slot r */
+  auto build_table = [&] (int r, int slot) {
+    if (tid < KWAY_MAX) {
+      const u64 s = sh.rng[r][0][tid], e = sh.rng[r][1][tid];
+      const bool live = (u32) tid < p.k;
+      sh.tab_start[slot][tid] = live ? s : 0;
+      sh.tab_len[slot][tid] = live ? (u32) (e - s) : 0u;
+    }
+    if (tid == 0) {
+      u32 total = 0;
+      u64 base = 0;
+      for (u32 i = 0; i < p.k; i++) {
+        total += (u32) (sh.rng[r][1][i] - sh.rng[r][0][i]);
+        base += sh.rng[r][0][i];
+      }
+      sh.tab_total[slot] = total;
+      sh.tab_base[slot] = base;
+    }
+  };
+
+  /* The tile's records, fetched one tile ahead into registers.  A wavefront fetches 64 consecutive
+   * records of ONE run per instruction (wave slot w of the tile: the runs' slots are numbered one
+   * run after the other, every run rounded up to whole slots), so run, descriptor and addresses are
+   * scalar and the range-checked descriptor zero-fills past the run's end: no per-lane bounds. */
+  u32x3 pre[J];
+  u32 pre_dst[J]; /* record position in buffer 0, or ~0 */
+  auto fetch = [&] (int slot, int part) { /* part j of J, or -1: all */
+    u32 len[KWAY_MAX];
+#pragma unroll
+    for (int i = 0; i < KWAY_MAX; i++) len[i] = uniform32 (sh.tab_len[slot][i]);
+#pragma unroll
+    for (int j = 0; j < J; j++) {
+      if (part >= 0 && part != j) continue;
+      const u32 w = (u32) wid + (u32) j * NW; /* wave slot */
+      /* run of this slot, its first slot and its first record position in the buffer (scalar) */
+      u32 i = 0, w0 = 0, r0 = 0, acc_w = 0, acc_r = 0;
+#pragma unroll
+      for (int m = 0; m < KWAY_MAX; m++) {
+        const u32 nw = (len[m] + WAVE - 1) / WAVE;
+        if (nw && w >= acc_w) {
+          i = m;
+          w0 = acc_w;
+          r0 = acc_r;
+        }
+        acc_w += nw;
+        acc_r += len[m];
+      }
+      pre_dst[j] = 0xffffffffu;
+      pre[j] = u32x3 { 0, 0, 0 };
+      if (w < acc_w) {
+        const u32 r = (w - w0) * WAVE + (u32) lane; /* record of the run */
+        const u64 s = uniform64 (sh.tab_start[slot][i]);
+        const u32 *base = p.list[0];
+#pragma unroll
+        for (int m = 1; m < KWAY_MAX; m++) base = i == (u32) m ? p.list[m] : base; /* scalar selects: no dynamic indexing of the kernel arguments */
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc ((void *) (base + 3 * s), 0, (int) (12 * len[i]), 0x00020000);
+        pre[j] = __builtin_amdgcn_raw_buffer_load_b96 (rs, 12 * r, 0, 0);
+        if (r < len[i]) pre_dst[j] = r0 + r;
+      }
+    }
+  };
+
+  /* ---- prologue: part[] of the first two tiles, table and fetch of the first */
+  if (tid < 2 * KWAY_MAX) {
+    for (int r = 0; r < 2; r++) {
+      const u64 t = tile_at (r);
+      if (t < ntl) sh.rng[r][tid / KWAY_MAX][tid % KWAY_MAX] = part[(t + tid / KWAY_MAX) * KWAY_MAX + tid % KWAY_MAX];
+    }
+  }
+  __syncthreads ();
+  if (tile_at (0) < ntl) build_table (0, 0);
+  __syncthreads ();
+  if (tile_at (0) < ntl) fetch (0, -1);
 
   u64 acc_sum = 0; /* per-thread sum of kept counts */
   u64 blk_cnt = 0; /* thread 0: records kept */
-
-  for (u64 tile = wk; tile < p.num_tiles; tile += n_workers) {
-    /* ---- the tile's ranges */
-    if (tid < KWAY_MAX) {
-      sh.rng[0][tid] = part[tile * KWAY_MAX + tid];
-      sh.rng[1][tid] = part[(tile + 1) * KWAY_MAX + tid];
-    }
-    __syncthreads ();
-    u32 rlen[SLOTS], roff[SLOTS]; /* wave-uniform: current runs (records, first dword in the current buffer) */
-    u32 total = 0, dw = 0;
-    u64 out_base = 0;
+  /* deferred write-out: the previous tile's kept records wait in sh.stage; its global offset is
+   * resolved at the top of this iteration, a whole tile after its total was published */
+  u32 pend_tot = 0;
+  u64 pend_tile = 0, pend_base = 0;
+  bool pend = false;
+  int it = 0;
+#ifdef GT4_PROFILE_PHASES
+  u64 ph[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+  u64 t_last;
+  asm volatile ("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_last) :: "memory");
+#endif
+  for (u64 tile = tile_at (0); tile < ntl; tile = tile_at (++it)) {
+    const int slot = it & 1;
+    const u64 nxt = tile_at (it + 1), nn = tile_at (it + 2);
+    u32x4 *X = sh.rec[0], *Y = sh.rec[1];
+    /* ---- registers -> LDS: the runs lie one after the other in buffer 0 */
 #pragma unroll
-    for (int i = 0; i < SLOTS; i++) {
-      const u64 s = i < KWAY_MAX ? uniform64 (sh.rng[0][i]) : 0, e = i < KWAY_MAX ? uniform64 (sh.rng[1][i]) : 0;
-      rlen[i] = (u32) i < p.k ? (u32) (e - s) : 0u;
-      roff[i] = dw;
-      dw += (3 * rlen[i] + 3) & ~3u;
-      total += rlen[i];
-      out_base += (u32) i < p.k ? s : 0;
+    for (int j = 0; j < J; j++)
+      if (pre_dst[j] != 0xffffffffu) X[pre_dst[j]] = u32x4 { pre[j].x, pre[j].y, pre[j].z, 0u };
+    /* part[] entries two tiles ahead (consumed at the end of the iteration), table of the next tile */
+    u64 hk = 0;
+    if (tid < 2 * KWAY_MAX && nn < ntl) hk = __hip_atomic_load (&part[(nn + tid / KWAY_MAX) * KWAY_MAX + tid % KWAY_MAX], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (nxt < ntl) build_table ((it + 1) % 3, slot ^ 1);
+    if (MODE == KWAY_UNION && pend && wid == NW - 1) {
+      const u64 x = resolve_offset (agg, carry, pend_tile, lane, 0, 0, ctl, spin_limit);
+      if (lane == 0) sh.excl = x;
     }
+    PHASE_STAMP (0); /* wait for the prefetched records, LDS stores, next table, resolve of the previous tile */
+    __syncthreads ();
+    /* The next tile's records are fetched and the previous tile's kept records leave for HBM in J
+     * resp. three portions, one behind each barrier of the passes: a CU gets ~12 bytes per cycle
+     * from HBM, a tile moves ~55 KB -- issued all at once the wavefronts would queue in front of the
+     * memory pipeline for thousands of cycles with nothing else to do. */
+    const u64 w_excl = MODE == KWAY_UNION ? uniform64 (sh.excl) : pend_base;
+    const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc ((void *) (out + 3 * w_excl), 0, (int) (12 * pend_tot), 0x00020000);
+    auto write_part = [&] (int k) {
+      const u32 c = (u32) tid + (u32) k * NT;
+      if (MODE != KWAY_COUNT && pend && c < ((3 * pend_tot + 3) >> 2)) __builtin_amdgcn_raw_buffer_store_b128 (*reinterpret_cast<const u32x4 *> (sh.stage + 4 * c), w_rs, 16 * c, 0, 0);
+    };
+    static_assert ((3 * CAP / 4 + NT - 1) / NT <= 3, "the write-out has three portions");
+    if (nxt < ntl) fetch (slot ^ 1, 0);
+    write_part (0);
+    PHASE_STAMP (1); /* barrier, first fetch and write-out portions */
+
+    u32 rlen[SLOTS], roff[SLOTS]; /* wave-uniform: current runs (records, first record in the current buffer) */
+    {
+      u32 acc = 0;
+#pragma unroll
+      for (int i = 0; i < SLOTS; i++) {
+        rlen[i] = i < KWAY_MAX ? uniform32 (sh.tab_len[slot][i < KWAY_MAX ? i : 0]) : 0u;
+        roff[i] = acc;
+        acc += rlen[i];
+      }
+    }
+    const u32 total = uniform32 (sh.tab_total[slot]);
+    const u64 out_base = uniform64 (sh.tab_base[slot]);
     if (total > (u32) CAP) {
       if (tid == 0) atomicOr (&ctl->error, 2u);
       break;
     }
-    /* ---- load: run i lies in buffer 0 from dword roff[i] exactly as in HBM (packed 12-byte records) */
-    u32 *X = sh.buf[0], *Y = sh.buf[1];
-#pragma unroll
-    for (int i = 0; i < SLOTS; i++) {
-      if (i >= KWAY_MAX || !rlen[i]) continue;
-      const u64 s = uniform64 (sh.rng[0][i]);
-      const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc ((void *) (p.list[i] + 3 * s), 0, (int) (12 * rlen[i]), 0x00020000);
-      const u32 chunks = (3 * rlen[i] + 3) >> 2;
-      for (u32 q = (u32) tid; q < chunks; q += NT) {
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128 (r, 16 * q, 0, 0);
-        *reinterpret_cast<u32x4 *> (X + roff[i] + 4 * q) = v;
-      }
-    }
-    __syncthreads ();
 
-    /* ---- P pairwise passes inside LDS: runs (2m, 2m+1) of buffer X -> run m of buffer Y, which is
-     * contiguous (run m starts where the records of runs 0 .. 2m-1 end) */
+    /* ---- P pairwise passes inside LDS: runs (2m, 2m+1) of buffer X -> run m of buffer Y */
 #pragma unroll
     for (int pass = 0; pass < P; pass++) {
-      constexpr int DUMMY = 0;
-      (void) DUMMY;
       const int M = SLOTS >> (pass + 1); /* merges of this pass */
       /* positions per thread; every merge rounds its thread count up, hence the M spare threads */
-      const u32 VT = total ? (total + (u32) NT - (u32) M - 1u) / ((u32) NT - (u32) M) : 1u;
+      u32 VT = total ? (total + (u32) NT - (u32) M - 1u) / ((u32) NT - (u32) M) : 1u;
+      VT = VT < p.vt_min ? p.vt_min : VT;
       u32 thr[SLOTS / 2 + 1], oo[SLOTS / 2 + 1], iters = 0;
       thr[0] = 0;
       oo[0] = 0;
@@ -212,8 +320,8 @@ k_kway_merge (KwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
         thr[m + 1] = thr[m] + (s + VT - 1) / VT;
         oo[m + 1] = oo[m] + s;
         const u32 mn = lx < ly ? lx : ly;
-        const u32 it = mn ? 32u - (u32) __builtin_clz (mn) : 0u;
-        iters = it > iters ? it : iters;
+        const u32 itn = mn ? 32u - (u32) __builtin_clz (mn) : 0u;
+        iters = itn > iters ? itn : iters;
       }
       /* this thread's merge and its descriptor (per-lane selects over at most four merges) */
       u32 xo = roff[0], lx = rlen[0], yo = roff[1], ly = rlen[1], ob = 0, t0 = 0;
@@ -231,37 +339,40 @@ k_kway_merge (KwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
       const u32 s = lx + ly;
       const u32 d0 = ((u32) tid - t0) * VT;
       const bool work = (u32) tid < thr[M] && d0 < s;
-      /* merge-path split: a = records of X among the first d0 of merge (X, Y), X first on ties */
-      u32 lo = d0 > ly ? d0 - ly : 0u, hi = d0 < lx ? d0 : lx;
-      if (!work) lo = hi = 0;
-      for (u32 it = 0; it < iters; it++) {
-        const bool act = lo < hi;
-        const u32 mid = (lo + hi) >> 1;
-        const u32 ia = act ? mid : 0u, ib = act ? d0 - 1u - mid : 0u;
-        const u64 kx = lds_key (X, xo + 3 * ia), ky = lds_key (X, yo + 3 * ib);
-        const bool c = kx <= ky;
-        lo = (act && c) ? mid + 1u : lo;
-        hi = (act && !c) ? mid : hi;
-      }
-      u32 pa = xo + 3 * lo, pb = yo + 3 * (d0 - lo);
-      const u32 ea = xo + 3 * lx, eb = yo + 3 * ly;
-      u32 po = 3 * (ob + d0);
-      const u32 pend = 3 * (ob + (d0 + VT < s ? d0 + VT : s));
-      if (work) {
-        for (u32 j = 0; j < VT; j++) {
-          if (po >= pend) break;
-          const bool ax = pa < ea, bx = pb < eb;
-          const u32 qa = ax ? pa : xo, qb = bx ? pb : yo; /* exhausted side: any address inside the buffer */
-          const u64 kx = lds_key (X, qa), ky = lds_key (X, qb);
-          const u32 cx = X[qa + 2], cy = X[qb + 2];
-          const bool take = ax && (!bx || kx <= ky);
-          const u64 key = take ? kx : ky;
-          Y[po] = (u32) key;
-          Y[po + 1] = (u32) (key >> 32);
-          Y[po + 2] = take ? cx : cy;
-          pa += take ? 3u : 0u;
-          pb += take ? 0u : 3u;
-          po += 3;
+      if (__builtin_amdgcn_ballot_w64 (work)) { /* wavefronts without a single position skip the pass */
+        /* merge-path split: lo = records of X among the first d0 of merge (X, Y), X first on ties
+         * (measured: a four-way split search with six LDS reads in flight per round and a serial merge
+         * that prefetches the successors of both heads were both SLOWER than this plain form -- the
+         * passes are bound by instruction issue and LDS cycles, not by the length of the chain) */
+        u32 lo = d0 > ly ? d0 - ly : 0u, hi = d0 < lx ? d0 : lx;
+        if (!work) lo = hi = 0;
+        const u64 *const kx_base = reinterpret_cast<const u64 *> (X + xo);
+        const u64 *const ky_base = reinterpret_cast<const u64 *> (X + yo);
+        for (u32 itn = 0; itn < iters; itn++) {
+          const bool act = lo < hi;
+          const u32 mid = (lo + hi) >> 1;
+          const u32 ia = act ? mid : 0u, ib = act ? d0 - 1u - mid : 0u;
+          const u64 kx = kx_base[2 * ia], ky = ky_base[2 * ib];
+          const bool c = kx <= ky;
+          lo = (act && c) ? mid + 1u : lo;
+          hi = (act && !c) ? mid : hi;
+        }
+        u32 pa = xo + lo, pb = yo + (d0 - lo);
+        const u32 ea = xo + lx, eb = yo + ly;
+        u32 po = ob + d0;
+        const u32 pend_o = ob + (d0 + VT < s ? d0 + VT : s);
+        if (work) {
+          for (u32 j = 0; j < VT; j++) {
+            if (po >= pend_o) break;
+            const bool ax = pa < ea, bx = pb < eb;
+            const u32x4 ra = X[ax ? pa : xo], rb = X[bx ? pb : yo]; /* exhausted side: any record inside the buffer */
+            const u64 kx = (u64) ra.x | ((u64) ra.y << 32), ky = (u64) rb.x | ((u64) rb.y << 32);
+            const bool take = ax && (!bx || kx <= ky);
+            Y[po] = take ? ra : rb;
+            pa += take ? 1u : 0u;
+            pb += take ? 0u : 1u;
+            po += 1;
+          }
         }
       }
       __syncthreads ();
@@ -270,83 +381,118 @@ k_kway_merge (KwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
       for (int m = 0; m < SLOTS / 2; m++) {
         if (m >= M) continue;
         rlen[m] = oo[m + 1] - oo[m];
-        roff[m] = 3 * oo[m];
+        roff[m] = oo[m];
       }
-      u32 *const tmp = X;
+      u32x4 *const tmp = X;
       X = Y;
       Y = tmp;
+      /* next portions of the fetch and of the write-out, behind this pass's barrier */
+      if (nxt < ntl) {
+        if (pass + 1 < J) fetch (slot ^ 1, pass + 1);
+        if (pass == P - 1)
+          for (int j = P + 1; j < J; j++) fetch (slot ^ 1, j);
+      }
+      if (pass < 2) write_part (pass + 1);
+      if (pass == 0) PHASE_STAMP (2);
+      if (pass == 1) PHASE_STAMP (3);
+      if (pass == 2) PHASE_STAMP (4);
     }
-    /* X: the tile's records in key order, equal keys of different lists next to each other */
+    /* X: the tile's records in key order, equal keys of different lists next to each other.  The
+     * write-out of the previous tile (issued before the passes) has read sh.stage by now: every
+     * wavefront passed at least one barrier behind its LDS reads. */
 
+    u32 tile_total = 0;
     if (MODE == KWAY_DUPS) {
-      write_out_tile<NT> (out, out_base, total, X, tid);
-      __syncthreads (); /* the next tile's load may overwrite this buffer */
-      continue;
-    }
-
-    /* ---- combine equal keys (union_multi :548-571), keep test (:574), compaction */
-    const u32 VTF = (total + (u32) NT - 1u) / (u32) NT;
-    const u32 p0 = (u32) tid * VTF, p1 = p0 + VTF < total ? p0 + VTF : total;
-    u32 e = 0;
-    if (p0 < total) {
-      u32 q = p0;
-      if (p0 > 0) {
-        const u64 pk = lds_key (X, 3 * (p0 - 1));
-        while (q < total && lds_key (X, 3 * q) == pk) q++; /* the tail of a key that started in an earlier thread's range */
+      __syncthreads (); /* every wavefront has read its last write-out portion from sh.stage */
+      for (u32 q = (u32) tid; q < total; q += NT) {
+        const u32x4 r = X[q];
+        sh.stage[3 * q] = r.x;
+        sh.stage[3 * q + 1] = r.y;
+        sh.stage[3 * q + 2] = r.z;
       }
-      while (q < p1) {
-        const u64 key = lds_key (X, 3 * q);
-        u32 f = p.rule == 7u ? p.count_override : X[3 * q + 2];
-        q++;
-        while (q < total && lds_key (X, 3 * q) == key) {
-          const u32 c = X[3 * q + 2];
-          f = p.rule == 1u ? f + c : (p.rule == 4u ? (c > f ? c : f) : p.count_override);
-          q++;
+      tile_total = total;
+    } else {
+      /* ---- combine equal keys (union_multi :548-571), keep test (:574), compaction.  Lane-consecutive
+       * positions (p = tid + i * NT): every LDS read is 64 consecutive records.  A position whose
+       * left neighbour has another key is the head of its key's run (at most eight records: one per
+       * list) and folds the counts of the positions behind it. */
+      constexpr int NR = (CAP + NT - 1) / NT; /* rows of NT positions */
+      u64 hkey[NR];
+      u32 hf[NR];
+      u32 kept_mask = 0;
+#pragma unroll
+      for (int i = 0; i < NR; i++) {
+        const u32 q = (u32) tid + (u32) i * NT;
+        const bool in = q < total;
+        const u32x4 r = X[in ? q : 0u];
+        const u64 key = (u64) r.x | ((u64) r.y << 32);
+        const u64 prev = *reinterpret_cast<const u64 *> (X + (in && q ? q - 1u : 0u));
+        const bool head = in && (q == 0 || prev != key);
+        u32 f = p.rule == 7u ? p.count_override : r.z;
+        bool more = head;
+#pragma unroll
+        for (int d = 1; d < KWAY_MAX; d++) {
+          if (!__builtin_amdgcn_ballot_w64 (more)) break;
+          const bool ok = more && q + (u32) d < total;
+          const u32x4 r2 = X[ok ? q + (u32) d : 0u];
+          more = ok && (((u64) r2.x | ((u64) r2.y << 32)) == key);
+          f = !more ? f : (p.rule == 1u ? f + r2.z : (p.rule == 4u ? (r2.z > f ? r2.z : f) : p.count_override));
         }
-        const bool keep = p.filter == FILTER_RAW || f >= p.cutoff;
-        if (keep) {
-          if (MODE != KWAY_COUNT) {
-            Y[3 * (p0 + e)] = (u32) key;
-            Y[3 * (p0 + e) + 1] = (u32) (key >> 32);
-            Y[3 * (p0 + e) + 2] = f;
-          }
-          e++;
-          acc_sum += f;
-        }
+        const bool keep = head && (p.filter == FILTER_RAW || f >= p.cutoff);
+        hkey[i] = key;
+        hf[i] = f;
+        kept_mask |= keep ? 1u << i : 0u;
+        acc_sum += keep ? f : 0u;
+        const u64 m = __builtin_amdgcn_ballot_w64 (keep);
+        if (lane == 0) sh.wave_tot[i * NW + wid] = (u32) __popcll (m);
       }
-    }
-    const u32 incl = dpp_inclusive_scan_u32 (e);
-    if (lane == WAVE - 1) sh.wave_tot[wid] = incl;
-    __syncthreads ();
-    u32 wbase = 0, tile_total = 0;
-    {
-      const u32 wt = lane < NW ? sh.wave_tot[lane] : 0u;
-      tile_total = dpp_wave_sum_u32 (wt);
-      wbase = dpp_wave_sum_u32 (lane < wid ? wt : 0u);
-    }
-    if (tid == 0) {
-      blk_cnt += tile_total;
-      if (MODE == KWAY_UNION) publish_u32 (&agg[tile], AGG_READY | tile_total);
-    }
-    if (MODE == KWAY_COUNT) {
+      PHASE_STAMP (5); /* combine */
       __syncthreads ();
-      continue;
+      /* exclusive prefix over (row, wavefront) in position order: NR * NW <= 64 values, one DPP scan */
+      static_assert (NR * NW <= WAVE, "one wavefront pass scans the row / wavefront counts");
+      const u32 wt = lane < NR * NW ? sh.wave_tot[lane] : 0u;
+      const u32 wincl = dpp_inclusive_scan_u32 (wt);
+      tile_total = (u32) __builtin_amdgcn_readlane ((int) wincl, WAVE - 1);
+      if (tid == 0) {
+        blk_cnt += tile_total;
+        if (MODE == KWAY_UNION) publish_u32 (&agg[tile], AGG_READY | tile_total);
+      }
+      if (MODE == KWAY_UNION) {
+#pragma unroll
+        for (int i = 0; i < NR; i++) {
+          const bool keep = (kept_mask >> i) & 1u;
+          const u64 m = __builtin_amdgcn_ballot_w64 (keep);
+          const u32 before = (u32) __builtin_amdgcn_readlane ((int) (wincl - wt), i * NW + wid); /* kept in earlier rows / wavefronts */
+          const u32 slot_o = before + __builtin_amdgcn_mbcnt_hi ((u32) (m >> 32), __builtin_amdgcn_mbcnt_lo ((u32) m, 0u));
+          if (keep) {
+            sh.stage[3 * slot_o] = (u32) hkey[i];
+            sh.stage[3 * slot_o + 1] = (u32) (hkey[i] >> 32);
+            sh.stage[3 * slot_o + 2] = hf[i];
+          }
+        }
+      }
+      PHASE_STAMP (6); /* barrier behind the combine, totals, staging */
     }
-    /* provisional per-thread positions (buffer Y) -> output order (buffer X, which everybody has
-     * finished reading: the barrier above) */
-    const u32 slot = wbase + incl - e;
-    for (u32 i = 0; i < e; i++) {
-      X[3 * (slot + i)] = Y[3 * (p0 + i)];
-      X[3 * (slot + i) + 1] = Y[3 * (p0 + i) + 1];
-      X[3 * (slot + i) + 2] = Y[3 * (p0 + i) + 2];
-    }
-    if (wid == 0) {
-      const u64 x = resolve_offset (agg, carry, tile, lane, 0, 0, ctl, spin_limit);
+    pend = MODE != KWAY_COUNT;
+    pend_tot = tile_total;
+    pend_tile = tile;
+    pend_base = out_base;
+    if (tid < 2 * KWAY_MAX && nn < ntl) sh.rng[(it + 2) % 3][tid / KWAY_MAX][tid % KWAY_MAX] = hk;
+    __syncthreads (); /* the next tile's records may overwrite the buffers; sh.stage is complete */
+    PHASE_STAMP (7); /* end barrier */
+  }
+#ifdef GT4_PROFILE_PHASES
+  if (tid == GT4_STAMP_TID)
+    for (int i = 0; i < 8; i++) atomicAdd (&ctl->phase_cycles[i], ph[i]);
+#endif
+  /* drain: the last tile is still staged */
+  if (MODE != KWAY_COUNT && pend) {
+    if (MODE == KWAY_UNION && wid == 0) {
+      const u64 x = resolve_offset (agg, carry, pend_tile, lane, 0, 0, ctl, spin_limit);
       if (lane == 0) sh.excl = x;
     }
     __syncthreads ();
-    write_out_tile<NT> (out, uniform64 (sh.excl), tile_total, X, tid);
-    __syncthreads ();
+    write_out_tile<NT> (out, MODE == KWAY_UNION ? uniform64 (sh.excl) : pend_base, pend_tot, sh.stage, tid);
   }
 
   if (MODE != KWAY_DUPS) {
@@ -357,7 +503,7 @@ k_kway_merge (KwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
 }
 
 constexpr int KWAY_NT = 1024;
-constexpr int KWAY_CAP = 6144;
+constexpr int KWAY_CAP = 3520;
 
 template <int MODE, int P>
 hipError_t launch_kway (hipStream_t s, int grid, const KwayParams &p, const u64 *part, u32 *out, u64 *desc, PairControl *ctl)
@@ -485,6 +631,7 @@ int gt4hip_kway_union (gt4hip_context *ctx, const gt4hip_list *const lists[], ui
     lv.p.count_override = ovr;
     lv.p.filter = filter;
     lv.p.spin_limit = ctx->spin_limit;
+    lv.p.vt_min = ctx->kway_vt > 0 ? (u32) ctx->kway_vt : 6u;
     if ((rc = kway_grow (ctx, (void **) &ctx->kway_part, &ctx->kway_part_bytes, (size_t) (tiles + 1) * KWAY_MAX * 8))) break;
     {
       const u64 threads = (tiles + 1) * KWAY_MAX;
@@ -548,6 +695,16 @@ int gt4hip_kway_union (gt4hip_context *ctx, const gt4hip_list *const lists[], ui
         cleanup ();
         return GT4HIP_OK;
       }
+#ifdef GT4_PROFILE_PHASES
+      {
+        static const char *names[8] = { "wait+store+resolve", "B0+fetch+writeout", "pass0", "pass1", "pass2", "combine", "B+move", "end barrier" };
+        unsigned long long tot = 0;
+        for (int i = 0; i < 8; i++) tot += ctx->ctl_host->phase_cycles[i];
+        fprintf (stderr, "[kway phases] tiles %llu:", (unsigned long long) tiles);
+        for (int i = 0; i < 8; i++) fprintf (stderr, " %s %.1f%%", names[i], tot ? 100.0 * ctx->ctl_host->phase_cycles[i] / tot : 0.0);
+        fprintf (stderr, " | avg cycles/tile %.0f\n", tiles ? (double) tot / tiles : 0.0);
+      }
+#endif
       *n_words = ctx->ctl_host->n_words[0];
       *total_count = ctx->ctl_host->total_count[0];
       float ms = 0;

@@ -271,11 +271,15 @@ int gt4hip_synchronize (gt4hip_context *ctx);
  *   "pool_cap_mb" = n  most the pool may hold (default: half of the device memory); every device
  *                      allocation that fails gives the pooled blocks back and retries
  *   "grid" = n         workgroups of the merge kernel (0: one per resident slot)
+ *   "kway" = 1         N-way unions by the one-pass tile kernel (gt4hip_kway.hip) instead of the
+ *                      pairwise tree; "kway_g" / "kway_vt": its samples per tile / positions per thread
  *   "spin_limit" = n   bound of the single-pass kernel's inter-workgroup waits (0: default, ~seconds)
  *   "geom0" / "geom1"  force the 512- / 1024-thread geometry (experiments). */
 int gt4hip_set_option (gt4hip_context *ctx, const char *name, int64_t value);
 /* Diagnostic counters of a context.  "single_pass_fallbacks": calls whose single-pass merge gave up a
- * bounded wait (a worker not resident: shared device) and were rerun on the two-pass path. */
+ * bounded wait (a worker not resident: shared device) and were rerun on the two-pass path;
+ * "kway_calls" / "kway_overflows": N-way unions done by the one-pass kernel / sent back to the tree
+ * because a tile would not fit LDS. */
 int gt4hip_get_counter (gt4hip_context *ctx, const char *name, uint64_t *value);
 
 #ifdef __cplusplus

@@ -11,7 +11,10 @@ for j in range(8):
     ctx.generate_ex(l, n, 7 if shared else 100 + j, 50 + j, 8, 16, 0 if shared else 1 + j)
     lists.append(l)
 print("generated", flush=True)
-for rep in range(2):
+for vt in [int(x) for x in os.environ.get("KWAY_VT", "0").split(",")]:
+  ctx.set_option("kway_vt", vt)
+  print("kway_vt", vt, flush=True)
+  for rep in range(2):
     rc, nw, tot, out = ctx.union_multi(lists)
-    print("rep", rep, rc, nw, tot, "device ms %.2f" % ctx.last_multi_device_ms, "sorted", out.is_sorted(), flush=True)
+    print("  rep", rep, rc, nw, tot, "device ms %.2f" % ctx.last_multi_device_ms, "sorted", out.is_sorted(), flush=True)
     out.free()
