@@ -166,7 +166,7 @@ def union8_roofline(ctx, n_list, n_out_local, device_ms):
     """Rank 0's shard: algorithmic bytes (every input record read once, every output record written
     once) against the device time of its pairwise tree, and the bytes the tree really moved."""
     rd, wr = ctx.last_multi_records
-    alg = 12 * (8 * n_list + n_out_local)
+    alg = 12 * (8 * n_list + n_out_local)  # n_list: this shard's records per list (average)
     achieved = alg / (device_ms * 1e-3) / 1e9
     return {"bound": "hbm", "kernel": "k_pair_merge<1024, 4, 1, 1> (3-level pairwise union tree, 7 launches)",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -176,31 +176,44 @@ def union8_roofline(ctx, n_list, n_out_local, device_ms):
 
 
 def bench_union8(args, ctx, capi, rank, local_rank, world):
-    """BASELINE configs[3]: 8-way union (MakeUnion.pl replacement) of eight lists, key-range sharded
-    over the ranks; per step every rank unions its eight slices (pairwise tree in HBM), the header
-    totals are all-gathered and the payload is gathered on rank 0 over RCCL (grouped send/recv)."""
+    """BASELINE configs[3]: 8-way union (MakeUnion.pl replacement) of eight lists -- ONE job, sharded
+    by key range over the ranks (strong scaling): every rank keeps its key range of every list
+    resident in HBM, unions its eight shards (pairwise tree in HBM), the header totals are
+    all-gathered and the payload is gathered on rank 0 over RCCL (gt4hip_comm_gatherv of the C ABI:
+    grouped ncclSend / ncclRecv -- the entry point the C command-line tool uses)."""
     import torch
     import torch.distributed as dist
     from genometester4_amd import distributed as D
-    n_list = args.n8 // world  # this rank's slice of each of the eight lists
-    lists = []
+    n8 = args.n8
+    full = []
     for j in range(8):
-        lst = ctx.alloc(n_list, args.k)
+        lst = ctx.alloc(n8, args.k)
         # disjoint residue classes mod 16 for half of the lists' keys, shared class 0 for the rest:
         # every key of class 0 is present in all lists that draw it (same key seed)
         shared = j % 2 == 0
-        ctx.generate_ex(lst, n_list, (7 if shared else 100 + j) + 1000 * rank, 50 + j, 8, 16, 0 if shared else 1 + j)
-        lists.append(lst)
-    cap = 8 * n_list
-    buf = torch.empty(3 * cap + 4, dtype=torch.int32, device="cuda")
-    out = ctx.wrap(buf.data_ptr(), cap, args.k)
+        ctx.generate_ex(lst, n8, 7 if shared else 100 + j, 50 + j, 8, 16, 0 if shared else 1 + j)
+        full.append(lst)
+    comm_id = None
+    if world > 1:
+        box = [capi.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        comm_id = box[0]
+    sh = D.DeviceShards(ctx, rank, world, comm_id)
+    shards = [sh.shard_of(l, args.k) for l in full]
+    n_local_in = sum(s.n_words for s in shards)
+    out = ctx.alloc(max(1, n_local_in), args.k)
+    op = D.gpu_union_multi_op(ctx)
 
-    def step():
-        rc, n, total, _ = ctx.union_multi(lists, out=out)
-        assert rc == 0
-        totals = D.exchange_totals(n, total, device="cuda") if world > 1 else [(n, total)]
-        g = D.gatherv_records(buf[: 3 * n], [t[0] for t in totals], root=0) if world > 1 else buf[: 3 * n]
-        return totals, g
+    def totals_exchange(n, total):
+        return D.exchange_totals(n, total, device="cuda")
+
+    state = {"gathered": None}
+
+    def step(gather=True):
+        n, total, res, totals = sh.run(shards, op, totals_exchange, root=0, out=out, gathered=state["gathered"], gather=gather)
+        if gather and world > 1 and rank == 0:
+            state["gathered"] = res  # allocated by the first step, reused afterwards
+        return n, total, totals, dict(sh.last_ms)
 
     def fence():
         ctx.synchronize()
@@ -209,46 +222,49 @@ def bench_union8(args, ctx, capi, rank, local_rank, world):
             dist.barrier()
         torch.cuda.synchronize()
 
-    dev_ms = []
-
-    def merge_only_step():
-        rc, n, total, _ = ctx.union_multi(lists, out=out)
-        assert rc == 0
-        dev_ms.append(ctx.last_multi_device_ms)
-
     for _ in range(args.warmup):
         step()
     fence()
     t0 = time.perf_counter()
+    ms = []
     for _ in range(args.steps):
-        totals, g = step()
+        n_out, total_out, totals, m = step()
+        ms.append(m)
     fence()
     elapsed = time.perf_counter() - t0
     # the same steps without the gather of the payload (what the shards alone sustain)
+    dev_ms = []
     t1 = time.perf_counter()
     for _ in range(args.steps):
-        merge_only_step()
+        step(gather=False)
+        dev_ms.append(ctx.last_multi_device_ms)
     fence()
     merge_only = time.perf_counter() - t1
+    per_rank = [{"rank": rank, "shard_input_records": n_local_in, "merge_ms": statistics.mean(x["merge"] for x in ms),
+                 "exchange_and_gather_ms": statistics.mean(x["exchange_and_gather"] for x in ms)}]
     if world > 1:
         t = torch.tensor([elapsed, merge_only], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, merge_only = float(t[0].item()), float(t[1].item())
+        box = [None] * world
+        dist.all_gather_object(box, per_rank[0])
+        per_rank = box
     if rank == 0:
-        n_in = 8 * n_list * world
-        n_out = sum(t[0] for t in totals)
+        n_in = 8 * n8
         print(json.dumps({
             "metric": "k-mers merged/sec, 8-way k=%d union (MakeUnion.pl replacement), lists resident in HBM, result gathered on rank 0" % args.k,
             "value": n_in * args.steps / elapsed, "unit": "k-mers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u64 keys + u32 counts", "data": "synthetic",
-            "config": {"workload": "8-way union, eight %d-entry k=%d lists, key-range sharded over %d GPU(s), RCCL gatherv" % (n_list * world, args.k, world),
-                       "entries_per_list": n_list * world, "output_records": n_out, "device": ctx.device_info(),
+            "config": {"workload": "8-way union, eight %d-entry k=%d lists, ONE job key-range sharded over %d GPU(s), RCCL gatherv to rank 0" % (n8, args.k, world),
+                       "entries_per_list": n8, "output_records": n_out, "output_total_count": total_out, "device": ctx.device_info(),
+                       "per_rank": per_rank,
                        "merge_only_k_mers_per_s": n_in * args.steps / merge_only,
                        "merge_only_ms_per_step": merge_only / args.steps * 1e3,
                        "gathered_bytes_per_step": 12 * (n_out - totals[0][0]) if world > 1 else 0},
-            "roofline": union8_roofline(ctx, n_list, totals[0][0], statistics.mean(dev_ms)),
+            "roofline": union8_roofline(ctx, n_local_in // 8, totals[0][0], statistics.mean(dev_ms)),
         }), flush=True)
+    sh.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -303,7 +303,9 @@ int main (int argc, const char *argv[])
       continue;
     }
     if (code != GT4_LIST_CODE_VALUE && code != GT4_INDEX_CODE_VALUE) {
+      /* the reference reports both: no object was made, so the interface lookup fails as well (:272-279) */
       fprintf (stderr, "Error: File %s has unknown format\n", fnames[f]);
+      fprintf (stderr, "Error: File %s is invalid or corrupted\n", fnames[f]);
       err = 1;
       continue;
     }

@@ -9,10 +9,14 @@ per-rank outputs in rank order is the globally sorted result.  The only exchange
      a grouped send/recv (`batch_isend_irecv` = ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd);
      on the fully connected xGMI node every non-root rank sends over its own link to the root.
 
-One process per GPU, `torch.distributed` with the "nccl" backend (= RCCL on ROCm).  The same code
-runs under "gloo" on CPU tensors, which is how the CPU test-suite covers it (world_size 2, with
-the CPU oracle standing in for the per-shard merge).  Plumbing only: the per-shard merge itself is
-the C ABI call (`capi.Context.union_multi` / `compare`).
+One process per GPU.  Two forms of the same scheme live here:
+
+  * `DeviceShards` -- the production form: lists resident in HBM, shards cut on the device, the
+    merge and the RCCL gatherv both through the C ABI (`gt4hip_union_multi`, `gt4hip_comm_gatherv`),
+    no host copy of the payload anywhere;
+  * `sharded_nway` / `gatherv_records` / `exchange_totals` -- the same steps over `torch.distributed`
+    tensors (backend "nccl" = RCCL on GPUs, "gloo" on CPU), which is how the CPU test-suite covers
+    the scheme with world sizes 2 and 3 (the CPU oracle standing in for the per-shard merge).
 """
 from __future__ import annotations
 
@@ -128,22 +132,75 @@ def sharded_nway(lists_host: Sequence[np.ndarray], word_length: int,
     return sum(t[0] for t in totals), sum(t[1] for t in totals) & 0xFFFFFFFFFFFFFFFF, tensor_to_records(gathered)
 
 
-def gpu_union_multi_op(ctx, word_length: int, cutoff: int = 1, rule: int = 0, count_override: int = 1):
-    """local_op for sharded_nway: N-way union of the slices on this rank's GPU (C ABI)."""
-    def op(slices):
-        dev = [ctx.upload(s, word_length) for s in slices]
-        rc, n, total, out = ctx.union_multi(dev, cutoff, rule, count_override)
+class DeviceShards:
+    """Key-range sharded N-way operations on lists that are RESIDENT in this rank's HBM.
+
+    No host bounce anywhere: shard g of a list is the view between two device lower bounds
+    (`gt4hip_list_lower_bound` + `gt4hip_list_slice`), the per-shard merge writes into a device list,
+    and the payload is gathered from that buffer over RCCL by the C ABI (`gt4hip_comm_gatherv`:
+    grouped ncclSend / ncclRecv) -- the same entry point the C command-line tool uses.  The
+    communicator id is made by rank 0 (`capi.comm_unique_id`) and handed over by the caller
+    (`torch.distributed.broadcast_object_list`, a file, MPI ...); `comm_id=None` means a world of one.
+    """
+
+    def __init__(self, ctx, rank=0, world=1, comm_id=None):
+        self.ctx, self.rank, self.world = ctx, rank, world
+        self.comm = ctx.comm_create(comm_id, world, rank) if (comm_id is not None) else None
+        self.last_ms = {}
+
+    def close(self):
+        if self.comm is not None:
+            from . import capi
+            capi.comm_destroy(self.comm)
+            self.comm = None
+
+    def shard_of(self, lst, word_length):
+        """This rank's key range of a device list, as a view."""
+        from . import capi
+        lo = capi.lib().gt4hip_shard_first_key(word_length, self.world, self.rank)
+        first = lst.lower_bound(lo) if self.rank else 0
+        if self.rank + 1 < self.world:
+            last = lst.lower_bound(capi.lib().gt4hip_shard_first_key(word_length, self.world, self.rank + 1))
+        else:
+            last = lst.n_words
+        return lst.slice(first, last - first)
+
+    def run(self, shards, op, totals_exchange, root=0, out=None, gathered=None, gather=True):
+        """`op(shards, out) -> (n_words, total_count, device list)` on this rank's shards, then the
+        totals all-gather (`totals_exchange(n, total) -> [(n, total)] by rank`) and the gatherv.
+        Returns (n_words, total_count, gathered device list or None, per-rank totals)."""
+        import time
+        t0 = time.perf_counter()
+        n, total, local = op(shards, out)
+        self.ctx.synchronize()
+        t1 = time.perf_counter()
+        totals = totals_exchange(n, total) if self.world > 1 else [(n, total)]
+        res = local
+        if gather and self.comm is not None:
+            counts = [t[0] for t in totals]
+            if self.rank == root and gathered is None:
+                gathered = self.ctx.alloc(max(1, sum(counts)), local.word_length)
+            self.ctx.comm_gatherv(self.comm, local, counts, root, gathered if self.rank == root else None)
+            res = gathered if self.rank == root else None
+        t2 = time.perf_counter()
+        self.last_ms = {"merge": (t1 - t0) * 1e3, "exchange_and_gather": (t2 - t1) * 1e3}
+        return sum(t[0] for t in totals), sum(t[1] for t in totals) & 0xFFFFFFFFFFFFFFFF, res, totals
+
+
+def gpu_union_multi_op(ctx, cutoff: int = 1, rule: int = 0, count_override: int = 1):
+    """op for DeviceShards.run: N-way union of device-resident shards (C ABI), result stays in HBM."""
+    def op(shards, out=None):
+        rc, n, total, res = ctx.union_multi(shards, cutoff, rule, count_override, out=out)
         if rc:
             raise RuntimeError("union_multi rejected rule %d" % rule)
-        return n, total, out.download()
+        return n, total, res
     return op
 
 
-def gpu_intersect_multi_op(ctx, word_length: int, cutoff: int = 1, rule: int = 0, count_override: int = 1):
-    def op(slices):
-        dev = [ctx.upload(s, word_length) for s in slices]
-        rc, n, total, out = ctx.intersect_multi(dev, cutoff, rule, count_override)
+def gpu_intersect_multi_op(ctx, cutoff: int = 1, rule: int = 0, count_override: int = 1):
+    def op(shards, out=None):
+        rc, n, total, res = ctx.intersect_multi(shards, cutoff, rule, count_override, out=out)
         if rc:
             raise RuntimeError("intersect_multi rejected rule %d" % rule)
-        return n, total, out.download()
+        return n, total, res
     return op

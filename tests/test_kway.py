@@ -153,3 +153,28 @@ def test_generated_eight_lists_against_the_oracle(ctx):
     rc_g, n_g, t_g, out = ctx.union_multi(dev, 12)
     assert (n_g, t_g) == (n_o, t_o)
     assert out.download().tobytes() == r_o.tobytes()
+
+
+def test_device_shards_world_of_one_with_rccl_gather(ctx):
+    """genometester4_amd.distributed.DeviceShards on one GPU: shards cut on the device, the union
+    through the C ABI, totals, and the RCCL gatherv of the C ABI with a communicator of one rank --
+    the payload never leaves HBM."""
+    from genometester4_amd import capi
+    from genometester4_amd import distributed as D
+    rng = np.random.default_rng(77)
+    lists = _random_lists(rng, 6, 120000, zero_counts=False)
+    dev = [ctx.upload(x, 20) for x in lists]
+    sh = D.DeviceShards(ctx, 0, 1, capi.comm_unique_id())
+    try:
+        shards = [sh.shard_of(d, 20) for d in dev]
+        assert [s.n_words for s in shards] == [len(x) for x in lists]
+        for cutoff, rule in ((1, 0), (3, 4)):
+            n, total, res, totals = sh.run(shards, D.gpu_union_multi_op(ctx, cutoff, rule), lambda n, t: [(n, t)])
+            rc_o, n_o, t_o, r_o = O.union_multi(lists, cutoff, rule, 1)
+            assert (n, total) == (n_o, t_o) and totals == [(n_o, t_o)]
+            assert res.n_words == n_o and res.download().tobytes() == r_o.tobytes()
+        n, total, res, _ = sh.run(shards, D.gpu_intersect_multi_op(ctx), lambda n, t: [(n, t)])
+        rc_o, n_o, t_o, r_o = O.intersect_multi(lists, 1, 0, 1)
+        assert (n, total) == (n_o, t_o) and res.download().tobytes() == r_o.tobytes()
+    finally:
+        sh.close()
