@@ -11,6 +11,8 @@
  *     the sorted k-mer lists they contain, as in the reference);
  *   - --stream and --disable_scouts are accepted and ignored (the whole list is uploaded to HBM;
  *     results are identical for well-formed files);
+ *   - GT4HIP_VERBOSE=1 prints the device, kernel times and the chunk plan on stderr (-D prints exactly
+ *     what the reference prints);
  *   - GT4HIP_CHECK_SORTED=1 rejects an input that is not strictly ascending (the reference trusts it);
  *   - --gpus N / GT4HIP_GPUS=N shards the job by key range over N GPUs (one worker process each, forked
  *     before any HIP call; every worker writes its own extents of the output files, or with
@@ -168,6 +170,8 @@ int main (int argc, const char *argv[])
   int find_union = 0, find_intrsec = 0, find_diff = 0, find_ddiff = 0, subtraction = 0, countonly = 0, print_operation = 0;
   int find_subset = 0, stream = 0, debug = 0;
   int n_gpus = getenv ("GT4HIP_GPUS") ? atoi (getenv ("GT4HIP_GPUS")) : 0;
+  /* lines of this implementation's own (device, kernel times, chunk plan): -D stays the reference's transcript */
+  const int verbose = getenv ("GT4HIP_VERBOSE") && atoi (getenv ("GT4HIP_VERBOSE"));
   const char *outputname = "out";
   char *end;
 
@@ -384,7 +388,7 @@ int main (int argc, const char *argv[])
       fprintf (stderr, "Error: %s\n", gt4hip_last_error (NULL));
       exit (1);
     }
-    if (debug) fprintf (stderr, "Device: %s\n", gt4hip_device_info (ctx));
+    if (verbose) fprintf (stderr, "Device: %s\n", gt4hip_device_info (ctx));
     /* inputs + worst-case outputs (+ the N-way tree's intermediates) must fit, else stream in chunks */
     uint64_t free_b = 0, total_b = 0, need = 0, in_records = 0;
     gt4hip_device_memory (ctx, &free_b, &total_b);
@@ -392,7 +396,7 @@ int main (int argc, const char *argv[])
     if (nfiles == 2) need = 12 * in_records * (1 + (uint64_t) (find_union + find_intrsec + find_diff + find_ddiff));
     else need = 12 * in_records * 4;
     if (free_b && need > free_b / 100 * 85) {
-      if (debug) fprintf (stderr, "Inputs and outputs need %llu bytes, %llu are free: streaming in key-range chunks\n", (unsigned long long) need, (unsigned long long) free_b);
+      if (verbose) fprintf (stderr, "Inputs and outputs need %llu bytes, %llu are free: streaming in key-range chunks\n", (unsigned long long) need, (unsigned long long) free_b);
       gt4hip_destroy (ctx);
       ctx = NULL;
       use_shards = 1;
@@ -407,7 +411,7 @@ int main (int argc, const char *argv[])
     job.n_ranks = n_gpus >= 1 ? n_gpus : 1;
     job.hbm_limit = hbm_limit;
     job.gather_rccl = getenv ("GT4HIP_GATHER") && !strcmp (getenv ("GT4HIP_GATHER"), "rccl");
-    job.debug = debug;
+    job.debug = verbose;
     job.prm.rule = rule;
     job.prm.cutoff = cutoff;
     job.prm.subtract = subtraction;
@@ -433,7 +437,7 @@ int main (int argc, const char *argv[])
       GT4ShardResult res;
       if (job.prm.ops) {
         if (gt4_shard_run (&job, &res)) exit (1);
-        if (debug) fprintf (stderr, "Sharded run: %u chunks over %d GPU(s)\n", res.n_chunks, job.n_ranks);
+        if (verbose) fprintf (stderr, "Sharded run: %u chunks over %d GPU(s)\n", res.n_chunks, job.n_ranks);
         for (int s = 0; s < 4; s++) {
           if (!((job.prm.ops >> s) & 1u)) continue;
           if (countonly) fprintf (stdout, "NUnique\t%llu\nNTotal\t%llu\n", (unsigned long long) res.n_words[s], (unsigned long long) res.total_count[s]);
@@ -517,7 +521,7 @@ int main (int argc, const char *argv[])
         fprintf (stderr, "Error: %s\n", gt4hip_last_error (ctx));
         exit (1);
       }
-      if (debug) fprintf (stderr, "GPU merge kernel: %.3f ms (%llu tiles), device total %.3f ms\n", res.merge_kernel_ms,
+      if (verbose) fprintf (stderr, "GPU merge kernel: %.3f ms (%llu tiles), device total %.3f ms\n", res.merge_kernel_ms,
                           (unsigned long long) res.merge_tiles, res.device_ms);
     }
     for (int s = 0; s < 4; s++) {

@@ -113,8 +113,8 @@ def test_medium_files_every_mode_writes_the_same_bytes(big_files):
             "rccl1": {"GT4HIP_GPUS": "1", "GT4HIP_GATHER": "rccl", "GT4HIP_HBM_LIMIT": "1500M"}}
     got = {}
     for name, env in runs.items():
-        p = subprocess.run([CLI, "a.list", "b.list", "-u", "-i", "-d", "-dd", "-c", "2", "-o", name, "-D"], cwd=d, capture_output=True,
-                           timeout=900, env=dict(os.environ, **env))
+        p = subprocess.run([CLI, "a.list", "b.list", "-u", "-i", "-d", "-dd", "-c", "2", "-o", name], cwd=d, capture_output=True,
+                           timeout=900, env=dict(os.environ, GT4HIP_VERBOSE="1", **env))
         assert p.returncode == 0, p.stderr.decode()
         got[name] = _outputs(d, name)
         assert len(got[name]) == 4
