@@ -8,6 +8,14 @@
  *   setops_driver union L1 L2 ...                         -> one line per callback: key\tc0\tc1...
  *   setops_driver is_union L1 L2 ...                      -> same, gt4_is_union
  *   setops_driver union_stop N L1 L2 ...                  -> callback returns 7 on its N-th call
+ *
+ * and glistquery's multi-list forms, printed as the reference's glistquery prints them
+ * (src/glistquery.c:82-106, :776-812, :702-717):
+ *
+ *   setops_driver dump L1 L2 ...            = glistquery L1 L2 ...             (KMER\tc0\tc1...)
+ *   setops_driver dump_is_union L1 L2 ...   = glistquery L1 L2 ... --is_union
+ *   setops_driver search_multi Q L1 L2 ...  = glistquery L1 L2 ... -l Q         (KMER\t0:c\t1:c...)
+ *   setops_driver zipper L Q                = glistquery L -l Q                 (KMER\tcount)
  */
 #include <fcntl.h>
 #include <stdio.h>
@@ -30,6 +38,46 @@ static unsigned int print_cb (uint64_t word, uint32_t *counts, void *data)
   return (stop_after && calls == stop_after) ? 7 : 0;
 }
 
+static unsigned int wlen_g;
+
+static unsigned int dump_cb (uint64_t word, uint32_t *counts, void *data)
+{
+  char b[64];
+  (void) data;
+  gt4_word2string (b, word, wlen_g);
+  fputs (b, stdout);
+  for (unsigned int j = 0; j < n_lists_g; j++) printf ("\t%u", counts[j]);
+  printf ("\n");
+  return 0;
+}
+
+static uint64_t multi_last = 0;
+static int multi_open = 0;
+
+static unsigned int multi_cb (uint64_t word, unsigned int list, uint32_t count, void *data)
+{
+  (void) data;
+  if (!multi_open || word != multi_last) {
+    char b[64];
+    if (multi_open) printf ("\n");
+    gt4_word2string (b, word, wlen_g);
+    fputs (b, stdout);
+    multi_open = 1;
+    multi_last = word;
+  }
+  printf ("\t%u:%u", list, count);
+  return 0;
+}
+
+static unsigned int zipper_cb (uint64_t word, uint32_t count, void *data)
+{
+  char b[64];
+  (void) data;
+  gt4_word2string (b, word, wlen_g);
+  printf ("%s\t%u\n", b, count);
+  return 0;
+}
+
 int main (int argc, const char **argv)
 {
   GT4HipWordList *objs[64];
@@ -42,6 +90,19 @@ int main (int argc, const char **argv)
     n++;
   }
   n_lists_g = n;
+  wlen_g = n ? gt4_hip_word_list_word_length (objs[0]) : 0;
+  if (!strcmp (argv[1], "dump") || !strcmp (argv[1], "dump_is_union")) {
+    r = !strcmp (argv[1], "dump") ? gt4_union (objs, n, dump_cb, NULL) : gt4_is_union (objs, n, dump_cb, NULL);
+    for (unsigned int j = 0; j < n; j++) gt4_hip_word_list_delete (objs[j]);
+    return (int) r;
+  }
+  if (!strcmp (argv[1], "search_multi") && n >= 2) {
+    n_lists_g = n - 1;
+    r = gt4_search_lists_multi (objs[0], objs + 1, n - 1, multi_cb, NULL);
+    if (multi_open) printf ("\n");
+    return (int) r;
+  }
+  if (!strcmp (argv[1], "zipper") && n == 2) return (int) gt4_search_list_zipper (objs[0], objs[1], zipper_cb, NULL);
   if (!strcmp (argv[1], "write_union")) {
     GT4ListHeader h;
     int fd = creat (argv[3], 0644);

@@ -48,7 +48,7 @@ SYMBOLS = [
     "gt4hip_list_download", "gt4hip_list_download_range", "gt4hip_list_free", "gt4hip_list_n_words",
     "gt4hip_list_word_length", "gt4hip_list_device_ptr", "gt4hip_list_set_n_words", "gt4hip_list_sum_counts",
     "gt4hip_list_is_sorted", "gt4hip_list_lower_bound", "gt4hip_list_get_word", "gt4hip_compare",
-    "gt4hip_union_multi", "gt4hip_intersect_multi", "gt4hip_union_table", "gt4hip_probe_table", "gt4hip_table_download",
+    "gt4hip_union_multi", "gt4hip_intersect_multi", "gt4hip_union_table", "gt4hip_probe_table", "gt4hip_probe_table_ex", "gt4hip_table_download",
     "gt4hip_table_free", "gt4hip_generate", "gt4hip_generate_ex", "gt4hip_synchronize", "gt4hip_set_option",
     "gt4hip_get_counter", "gt4hip_device_memory", "gt4hip_list_upload_fd", "gt4hip_list_load_fd", "gt4hip_list_load",
     "gt4hip_list_write_fd", "gt4hip_shard_first_key", "gt4hip_comm_unique_id", "gt4hip_comm_create", "gt4hip_comm_destroy",
@@ -100,6 +100,7 @@ def lib():
             "gt4hip_intersect_multi": (C.c_int, [vp, C.POINTER(vp), u32, u32, i32, u32, i32, C.POINTER(MultiResult)]),
             "gt4hip_union_table": (C.c_int, [vp, C.POINTER(vp), u32, C.POINTER(CountTable)]),
             "gt4hip_probe_table": (C.c_int, [vp, C.POINTER(vp), u32, C.POINTER(CountTable)]),
+            "gt4hip_probe_table_ex": (C.c_int, [vp, C.POINTER(vp), u32, C.c_int, C.POINTER(CountTable)]),
             "gt4hip_table_download": (C.c_int, [vp, C.POINTER(CountTable), u64, u64, vp, vp]),
             "gt4hip_table_free": (None, [C.POINTER(CountTable)]),
             "gt4hip_generate": (C.c_int, [vp, vp, u64, u64, u32]),
@@ -346,11 +347,13 @@ class Context:
     def intersect_multi(self, lists, cutoff=1, rule=0, count_override=1, count_only=False, out=None):
         return self._multi(lib().gt4hip_intersect_multi, lists, cutoff, rule, count_override, count_only, out)
 
-    def union_table(self, lists, probe=False):
+    def union_table(self, lists, probe=False, presence=False):
         arr = (C.c_void_p * len(lists))(*[l.h for l in lists])
         t = CountTable()
-        fn = lib().gt4hip_probe_table if probe else lib().gt4hip_union_table
-        self._chk(fn(self.h, arr, len(lists), C.byref(t)))
+        if probe:
+            self._chk(lib().gt4hip_probe_table_ex(self.h, arr, len(lists), 1 if presence else 0, C.byref(t)))
+        else:
+            self._chk(lib().gt4hip_union_table(self.h, arr, len(lists), C.byref(t)))
         keys = np.empty(t.n_keys, dtype=np.uint64)
         counts = np.empty((t.n_keys, len(lists)), dtype=np.uint32)
         if t.n_keys:

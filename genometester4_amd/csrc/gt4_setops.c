@@ -232,3 +232,106 @@ unsigned int gt4_is_union (GT4HipWordList *objs[], unsigned int n_objs, unsigned
 {
   return table_walk (objs, n_objs, 1, callback, data);
 }
+
+/* ------------------------------------------------------------------ glistquery's searches */
+
+unsigned int gt4_word2string (char *b, uint64_t word, unsigned int wordlength)
+{
+  static const char alphabet[4] = { 'A', 'C', 'G', 'T' };
+  for (unsigned int i = 0; i < wordlength; i++) {
+    b[wordlength - i - 1] = alphabet[word & 3];
+    word >>= 2;
+  }
+  b[wordlength] = 0;
+  return wordlength;
+}
+
+unsigned int gt4_search_lists_multi (GT4HipWordList *query, GT4HipWordList *lists[], unsigned int n_lists,
+                                     unsigned int (*callback) (uint64_t, unsigned int, uint32_t, void *), void *data)
+{
+  if (!query || !lists || !n_lists || n_lists >= GT4_MAX_SETS || !callback) return 1;
+  gt4hip_context *ctx = gt4_hip_default_context ();
+  if (!ctx) return 1;
+  const unsigned int n = n_lists + 1;
+  const gt4hip_list **devs = (const gt4hip_list **) malloc (n * sizeof *devs);
+  if (!devs) return 1;
+  devs[0] = query->dev;
+  for (unsigned int j = 0; j < n_lists; j++) devs[j + 1] = lists[j]->dev;
+  /* two tables over the query's words: the lists' counts, and which lists hold the word at all */
+  gt4hip_count_table tc, tp;
+  int rc = gt4hip_probe_table_ex (ctx, devs, n, 0, &tc);
+  if (!rc) {
+    rc = gt4hip_probe_table_ex (ctx, devs, n, 1, &tp);
+    if (rc) gt4hip_table_free (&tc);
+  }
+  free (devs);
+  if (rc) {
+    fprintf (stderr, "gt4_search_lists_multi: %s\n", gt4hip_last_error (ctx));
+    return 1;
+  }
+  unsigned int result = 0;
+  const uint64_t total = tc.n_keys, rows = total < TABLE_CHUNK ? total : TABLE_CHUNK;
+  uint64_t *keys = (uint64_t *) malloc ((size_t) (rows ? rows : 1) * 8);
+  uint32_t *counts = (uint32_t *) malloc ((size_t) (rows ? rows : 1) * n * 4), *present = (uint32_t *) malloc ((size_t) (rows ? rows : 1) * n * 4);
+  if (!keys || !counts || !present) result = 1;
+  for (uint64_t first = 0; first < total && !result; first += TABLE_CHUNK) {
+    const uint64_t cnt = total - first < TABLE_CHUNK ? total - first : TABLE_CHUNK;
+    if (gt4hip_table_download (ctx, &tc, first, cnt, keys, counts) || gt4hip_table_download (ctx, &tp, first, cnt, NULL, present)) {
+      fprintf (stderr, "gt4_search_lists_multi: %s\n", gt4hip_last_error (ctx));
+      result = 1;
+      break;
+    }
+    for (uint64_t i = 0; i < cnt && !result; i++)
+      for (unsigned int j = 1; j < n && !result; j++)
+        if (present[i * n + j]) result = callback (keys[i], j - 1, counts[i * n + j], data);
+  }
+  free (keys);
+  free (counts);
+  free (present);
+  gt4hip_table_free (&tc);
+  gt4hip_table_free (&tp);
+  return result;
+}
+
+unsigned int gt4_search_list_zipper (GT4HipWordList *list, GT4HipWordList *query, unsigned int (*callback) (uint64_t, uint32_t, void *), void *data)
+{
+  if (!list || !query || !callback) return 1;
+  gt4hip_context *ctx = gt4_hip_default_context ();
+  if (!ctx) return 1;
+  /* the words of `query` that `list` holds, with the query's counts: an intersection under rule
+   * FIRST with every matched key kept (cutoff 0 lets zero counts through the input test; the
+   * reference's loop has no count test at all) -- except keys whose count in `query` is 0, which
+   * the reference prints and the intersection's "count != 0" test drops: those come from the
+   * presence table instead, so use the table form when the query holds zero counts */
+  const gt4hip_list *devs[2] = { query->dev, list->dev };
+  gt4hip_count_table tp;
+  if (gt4hip_probe_table_ex (ctx, devs, 2, 1, &tp)) {
+    fprintf (stderr, "gt4_search_list_zipper: %s\n", gt4hip_last_error (ctx));
+    return 1;
+  }
+  unsigned int result = 0;
+  const uint64_t total = tp.n_keys, rows = total < TABLE_CHUNK ? total : TABLE_CHUNK;
+  uint64_t *keys = (uint64_t *) malloc ((size_t) (rows ? rows : 1) * 8);
+  uint32_t *present = (uint32_t *) malloc ((size_t) (rows ? rows : 1) * 2 * 4);
+  unsigned char *recs = (unsigned char *) malloc ((size_t) (rows ? rows : 1) * 12);
+  if (!keys || !present || !recs) result = 1;
+  for (uint64_t first = 0; first < total && !result; first += TABLE_CHUNK) {
+    const uint64_t cnt = total - first < TABLE_CHUNK ? total - first : TABLE_CHUNK;
+    if (gt4hip_table_download (ctx, &tp, first, cnt, keys, present) || gt4hip_list_download_range (ctx, query->dev, first, cnt, recs)) {
+      fprintf (stderr, "gt4_search_list_zipper: %s\n", gt4hip_last_error (ctx));
+      result = 1;
+      break;
+    }
+    for (uint64_t i = 0; i < cnt && !result; i++) {
+      if (!present[2 * i + 1]) continue;
+      uint32_t c;
+      memcpy (&c, recs + 12 * i + 8, 4);
+      result = callback (keys[i], c, data);
+    }
+  }
+  free (keys);
+  free (present);
+  free (recs);
+  gt4hip_table_free (&tp);
+  return result;
+}

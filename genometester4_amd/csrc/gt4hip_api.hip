@@ -996,19 +996,43 @@ extern "C" int gt4hip_intersect_multi (gt4hip_context *ctx, const gt4hip_list *c
 
 /* ------------------------------------------------------------------ per-key count table (gt4_union) */
 
+/* A column of the table is itself a MERGE: with K the table's key list (every key of list j is in
+ * K), union (K, L_j) under rule SECOND, every key kept, is K's keys with L_j's count or 0 -- a list
+ * aligned with K, whose count column is copied into the table.  One streaming pass over K and L_j
+ * per list instead of a binary search over L_j per key. */
+static int table_column_by_union (gt4hip_context *ctx, const gt4hip_list *keys, const gt4hip_list *lj, gt4hip_list *tmp, gt4hip_count_table *t,
+                                  uint32_t column)
+{
+  PairParams p = nway_params (GT4HIP_OP_UNION, GT4HIP_RULE_SECOND, 0, 0, FILTER_RAW);
+  uint32_t *dst[4] = { (uint32_t *) tmp->dev, NULL, NULL, NULL };
+  PairRun run;
+  int rc = run_pair (ctx, (const uint32_t *) keys->dev, keys->n_words, (const uint32_t *) lj->dev, lj->n_words, p, false, dst, &run);
+  if (rc) return rc;
+  if (run.n_words[0] != keys->n_words) return gt4hip_fail (ctx, GT4HIP_EINTERNAL, "count table: a list holds keys outside the key list");
+  HIPCHK (ctx, launch_extract_column (ctx->stream, (const uint32_t *) tmp->dev, keys->n_words, (uint32_t *) t->device_counts, t->n_lists, column));
+  return GT4HIP_OK;
+}
+
+static int table_alloc (gt4hip_context *ctx, gt4hip_count_table *table, uint64_t n, uint32_t n_lists)
+{
+  hipError_t e = gt4hip_dev_alloc (ctx, &table->device_keys, (size_t) n * 8);
+  if (e == hipSuccess) e = gt4hip_dev_alloc (ctx, &table->device_counts, (size_t) n * n_lists * 4);
+  if (e != hipSuccess) {
+    gt4hip_table_free (table);
+    return gt4hip_fail (ctx, GT4HIP_ENOMEM, "count table allocation failed: %s", hipGetErrorString (e));
+  }
+  return GT4HIP_OK;
+}
+
 extern "C" int gt4hip_union_table (gt4hip_context *ctx, const gt4hip_list *const lists[], uint32_t n_lists, gt4hip_count_table *table)
 {
   if (!ctx || !lists || !n_lists || !table) return GT4HIP_EINVAL;
   memset (table, 0, sizeof *table);
   table->n_lists = n_lists;
-  /* all distinct keys ascending = N-way union with nothing filtered out */
+  /* all distinct keys ascending = N-way union with nothing filtered out (count >= 0) */
   gt4hip_multi_result u;
   memset (&u, 0, sizeof u);
-  int rc;
-  {
-    /* FILTER_RESULT with cutoff 0 keeps every key (count >= 0) */
-    rc = gt4hip_union_multi (ctx, lists, n_lists, 0, GT4HIP_RULE_MAX, 0, 0, &u);
-  }
+  int rc = gt4hip_union_multi (ctx, lists, n_lists, 0, GT4HIP_RULE_MAX, 0, 0, &u);
   if (rc) return rc;
   const uint64_t n = u.n_words;
   table->n_keys = n;
@@ -1016,29 +1040,32 @@ extern "C" int gt4hip_union_table (gt4hip_context *ctx, const gt4hip_list *const
     gt4hip_list_free (u.out);
     return GT4HIP_OK;
   }
-  hipError_t e = gt4hip_dev_alloc (ctx, &table->device_keys, (size_t) n * 8);
-  if (e == hipSuccess) e = gt4hip_dev_alloc (ctx, &table->device_counts, (size_t) n * n_lists * 4);
-  if (e != hipSuccess) {
-    gt4hip_list_free (u.out);
-    gt4hip_table_free (table);
-    return gt4hip_fail (ctx, GT4HIP_ENOMEM, "count table allocation failed: %s", hipGetErrorString (e));
+  uint64_t longest = 0;
+  for (uint32_t j = 0; j < n_lists; j++)
+    if (lists[j]->n_words > longest) longest = lists[j]->n_words;
+  gt4hip_list *tmp = NULL;
+  rc = table_alloc (ctx, table, n, n_lists);
+  if (!rc) rc = gt4hip_list_new (ctx, n + longest, lists[0]->word_length, &tmp);
+  if (!rc) {
+    hipError_t e = launch_extract_keys (ctx->stream, (const uint32_t *) u.out->dev, n, (unsigned long long *) table->device_keys);
+    if (e != hipSuccess) rc = gt4hip_fail (ctx, GT4HIP_EHIP, "count table kernels failed: %s", hipGetErrorString (e));
   }
-  e = launch_extract_keys (ctx->stream, (const uint32_t *) u.out->dev, n, (unsigned long long *) table->device_keys);
-  for (uint32_t j = 0; j < n_lists && e == hipSuccess; j++)
-    e = launch_counts_table (ctx->stream, (const uint32_t *) u.out->dev, n, (const uint32_t *) lists[j]->dev, lists[j]->n_words,
-                             (uint32_t *) table->device_counts, n_lists, j);
-  if (e == hipSuccess) e = hipStreamSynchronize (ctx->stream);
+  for (uint32_t j = 0; j < n_lists && !rc; j++) rc = table_column_by_union (ctx, u.out, lists[j], tmp, table, j);
+  if (!rc && hipStreamSynchronize (ctx->stream) != hipSuccess) rc = gt4hip_fail (ctx, GT4HIP_EHIP, "count table kernels failed");
+  if (tmp) gt4hip_list_free (tmp);
   gt4hip_list_free (u.out);
-  if (e != hipSuccess) {
-    gt4hip_table_free (table);
-    return gt4hip_fail (ctx, GT4HIP_EHIP, "count table kernels failed: %s", hipGetErrorString (e));
-  }
-  return GT4HIP_OK;
+  if (rc) gt4hip_table_free (table);
+  return rc;
 }
 
-extern "C" int gt4hip_probe_table (gt4hip_context *ctx, const gt4hip_list *const lists[], uint32_t n_lists, gt4hip_count_table *table)
+/* keys = the keys of lists[0]; column j = the count of each of them in list j (0 when absent), or,
+ * with `presence`, 1 when list j holds the key and 0 when it does not (a count may be 0 itself).
+ * Two merges per list: lists[0] n L_j keeping L_j's count, then aligned with lists[0] as above. */
+extern "C" int gt4hip_probe_table_ex (gt4hip_context *ctx, const gt4hip_list *const lists[], uint32_t n_lists, int presence, gt4hip_count_table *table)
 {
   if (!ctx || !lists || !n_lists || !table || !lists[0]) return GT4HIP_EINVAL;
+  for (uint32_t j = 0; j < n_lists; j++)
+    if (!lists[j]) return GT4HIP_EINVAL;
   memset (table, 0, sizeof *table);
   table->n_lists = n_lists;
   const gt4hip_list *base = lists[0];
@@ -1046,24 +1073,33 @@ extern "C" int gt4hip_probe_table (gt4hip_context *ctx, const gt4hip_list *const
   table->n_keys = n;
   if (!n) return GT4HIP_OK;
   HIPCHK (ctx, hipSetDevice (ctx->device));
-  hipError_t e = gt4hip_dev_alloc (ctx, &table->device_keys, (size_t) n * 8);
-  if (e == hipSuccess) e = gt4hip_dev_alloc (ctx, &table->device_counts, (size_t) n * n_lists * 4);
-  if (e != hipSuccess) {
-    gt4hip_table_free (table);
-    return gt4hip_fail (ctx, GT4HIP_ENOMEM, "count table allocation failed: %s", hipGetErrorString (e));
+  gt4hip_list *tmp = NULL, *inter = NULL;
+  int rc = table_alloc (ctx, table, n, n_lists);
+  if (!rc) rc = gt4hip_list_new (ctx, 2 * n, base->word_length, &tmp);
+  if (!rc) rc = gt4hip_list_new (ctx, n, base->word_length, &inter);
+  if (!rc) {
+    hipError_t e = launch_extract_keys (ctx->stream, (const uint32_t *) base->dev, n, (unsigned long long *) table->device_keys);
+    if (e != hipSuccess) rc = gt4hip_fail (ctx, GT4HIP_EHIP, "count table kernels failed: %s", hipGetErrorString (e));
   }
-  e = launch_extract_keys (ctx->stream, (const uint32_t *) base->dev, n, (unsigned long long *) table->device_keys);
-  for (uint32_t j = 0; j < n_lists && e == hipSuccess; j++) {
-    if (!lists[j]) e = hipErrorInvalidValue;
-    else e = launch_counts_table (ctx->stream, (const uint32_t *) base->dev, n, (const uint32_t *) lists[j]->dev, lists[j]->n_words,
-                                  (uint32_t *) table->device_counts, n_lists, j);
+  for (uint32_t j = 0; j < n_lists && !rc; j++) {
+    PairParams p = nway_params (GT4HIP_OP_INTRSEC, presence ? GT4HIP_RULE_NUMBER : GT4HIP_RULE_SECOND, 0, 1, FILTER_RAW);
+    uint32_t *dst[4] = { NULL, (uint32_t *) inter->dev, NULL, NULL };
+    PairRun run;
+    rc = run_pair (ctx, (const uint32_t *) base->dev, n, (const uint32_t *) lists[j]->dev, lists[j]->n_words, p, false, dst, &run);
+    if (rc) break;
+    inter->n_words = run.n_words[1];
+    rc = table_column_by_union (ctx, base, inter, tmp, table, j);
   }
-  if (e == hipSuccess) e = hipStreamSynchronize (ctx->stream);
-  if (e != hipSuccess) {
-    gt4hip_table_free (table);
-    return gt4hip_fail (ctx, GT4HIP_EHIP, "count table kernels failed: %s", hipGetErrorString (e));
-  }
-  return GT4HIP_OK;
+  if (!rc && hipStreamSynchronize (ctx->stream) != hipSuccess) rc = gt4hip_fail (ctx, GT4HIP_EHIP, "count table kernels failed");
+  if (tmp) gt4hip_list_free (tmp);
+  if (inter) gt4hip_list_free (inter);
+  if (rc) gt4hip_table_free (table);
+  return rc;
+}
+
+extern "C" int gt4hip_probe_table (gt4hip_context *ctx, const gt4hip_list *const lists[], uint32_t n_lists, gt4hip_count_table *table)
+{
+  return gt4hip_probe_table_ex (ctx, lists, n_lists, 0, table);
 }
 
 extern "C" int gt4hip_table_download (gt4hip_context *ctx, const gt4hip_count_table *t, uint64_t first, uint64_t count,

@@ -155,6 +155,7 @@ extern "C" void gt4hip_comm_destroy (gt4hip_comm *c)
   if (!c) return;
   const Rccl *r = rccl ();
   if (r) {
+    QuietStderr quiet;
     hipSetDevice (c->ctx->device);
     hipStreamSynchronize (c->ctx->stream);
     r->CommDestroy (c->comm);
@@ -174,6 +175,7 @@ extern "C" int gt4hip_comm_gatherv (gt4hip_comm *c, const gt4hip_list *local, co
   const uint64_t mine = counts[c->rank];
   if (mine && (!local || local->n_words < mine)) return gt4hip_fail (ctx, GT4HIP_EINVAL, "gatherv: local list shorter than counts[rank]");
   HIPCHK (ctx, hipSetDevice (ctx->device));
+  QuietStderr quiet; /* (the version banner comes with the first collective on some RCCL builds) */
   ncclResult_t e = ncclSuccess;
   if (c->rank != root) {
     if (mine) {

@@ -75,8 +75,7 @@ hipError_t launch_sum_counts (hipStream_t s, const uint32_t *rec, uint64_t n, un
 hipError_t launch_check_sorted (hipStream_t s, const uint32_t *rec, uint64_t n, unsigned int *bad);
 hipError_t launch_lower_bound (hipStream_t s, const uint32_t *rec, uint64_t n, uint64_t key,
                                unsigned long long *idx);
-hipError_t launch_counts_table (hipStream_t s, const uint32_t *keys_rec, uint64_t n_keys, const uint32_t *list,
-                                uint64_t n_list, uint32_t *counts, uint32_t n_lists, uint32_t column);
+hipError_t launch_extract_column (hipStream_t s, const uint32_t *rec, uint64_t n, uint32_t *counts, uint32_t n_lists, uint32_t column);
 hipError_t launch_extract_keys (hipStream_t s, const uint32_t *rec, uint64_t n, unsigned long long *keys);
 hipError_t launch_decode_index (hipStream_t s, const unsigned long long *kmers, uint64_t n, uint64_t num_locations, uint32_t *rec);
 

@@ -1037,21 +1037,11 @@ __global__ void k_lower_bound (const u32 *__restrict__ rec, u64 n, u64 key, u64 
   *idx = lo;
 }
 
-/* column `column` of the per-key count table: count of each union key in `list`, or 0 */
-__global__ void k_counts_table (const u32 *__restrict__ keys_rec, u64 n_keys, const u32 *__restrict__ list, u64 n_list,
-                                u32 *__restrict__ counts, u32 n_lists, u32 column)
+/* column `column` of the per-key count table from a list aligned with the table's keys */
+__global__ void k_extract_column (const u32 *__restrict__ rec, u64 n, u32 *__restrict__ counts, u32 n_lists, u32 column)
 {
   const u64 step = (u64) gridDim.x * blockDim.x;
-  for (u64 i = (u64) blockIdx.x * blockDim.x + threadIdx.x; i < n_keys; i += step) {
-    const u64 key = load_key (keys_rec, i);
-    u64 lo = 0, hi = n_list;
-    while (lo < hi) {
-      const u64 mid = (lo + hi) >> 1;
-      if (load_key (list, mid) < key) lo = mid + 1;
-      else hi = mid;
-    }
-    counts[i * n_lists + column] = (lo < n_list && load_key (list, lo) == key) ? list[3 * lo + 2] : 0u;
-  }
+  for (u64 i = (u64) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) counts[i * n_lists + column] = rec[3 * i + 2];
 }
 
 __global__ void k_extract_keys (const u32 *__restrict__ rec, u64 n, u64 *__restrict__ keys)
@@ -1235,11 +1225,9 @@ hipError_t launch_lower_bound (hipStream_t s, const uint32_t *rec, uint64_t n, u
   return hipGetLastError ();
 }
 
-hipError_t launch_counts_table (hipStream_t s, const uint32_t *keys_rec, uint64_t n_keys, const uint32_t *list,
-                                uint64_t n_list, uint32_t *counts, uint32_t n_lists, uint32_t column)
+hipError_t launch_extract_column (hipStream_t s, const uint32_t *rec, uint64_t n, uint32_t *counts, uint32_t n_lists, uint32_t column)
 {
-  hipLaunchKernelGGL (k_counts_table, dim3 (grid_for (n_keys, 256, 4096)), dim3 (256), 0, s, keys_rec, n_keys, list, n_list,
-                      counts, n_lists, column);
+  hipLaunchKernelGGL (k_extract_column, dim3 (grid_for (n, 256, 4096)), dim3 (256), 0, s, rec, n, counts, n_lists, column);
   return hipGetLastError ();
 }
 

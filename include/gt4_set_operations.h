@@ -55,6 +55,22 @@ unsigned int gt4_union (GT4HipWordList *objs[], unsigned int n_objs, unsigned in
  * (src/set-operations.c:185-228). */
 unsigned int gt4_is_union (GT4HipWordList *objs[], unsigned int n_objs, unsigned int (*callback) (uint64_t, uint32_t *, void *), void *data);
 
+/* glistquery's list-against-lists searches, as merges on the device:
+ *
+ * gt4_search_lists_multi -- search_lists_multi, reference src/glistquery.c:776-812: for every word of
+ * `query` ascending, callback (word, j, count) for every list j (ascending) that holds the word; words
+ * found in no list are skipped.  A non-zero callback result stops the walk and is returned.
+ *
+ * gt4_search_list_zipper -- search_list_zipper, src/glistquery.c:702-717: callback (word, count in
+ * `query`) for every word of `query` that `list` holds, ascending. */
+unsigned int gt4_search_lists_multi (GT4HipWordList *query, GT4HipWordList *lists[], unsigned int n_lists,
+                                     unsigned int (*callback) (uint64_t word, unsigned int list, uint32_t count, void *data), void *data);
+unsigned int gt4_search_list_zipper (GT4HipWordList *list, GT4HipWordList *query,
+                                     unsigned int (*callback) (uint64_t word, uint32_t count, void *data), void *data);
+/* word2string, src/sequence.c:103-114: 2 bits per base, A C G T, first base in the highest bits.
+ * `b` needs wordlength + 1 bytes; returns wordlength. */
+unsigned int gt4_word2string (char *b, uint64_t word, unsigned int wordlength);
+
 #ifdef __cplusplus
 }
 #endif

@@ -198,7 +198,9 @@ int gt4hip_intersect_multi (gt4hip_context *ctx, const gt4hip_list *const lists[
                             gt4hip_multi_result *result);
 
 /* Per-key count table of an N-way union: for every distinct key ascending, counts[j] = count in
- * list j or 0 (what gt4_union hands to its callback, src/set-operations.c:161-179).
+ * list j or 0 (what gt4_union hands to its callback, src/set-operations.c:161-179).  Built by
+ * merges only: the N-way union gives the keys, and each column is one more streaming merge of the
+ * key list with list j (rule SECOND keeps list j's count, absent keys get 0).
  * keys_out: n_keys u64; counts_out: n_keys * n_lists u32, row-major.  Both are device buffers
  * owned by the result; release with gt4hip_table_free. */
 typedef struct {
@@ -213,6 +215,11 @@ int gt4hip_union_table (gt4hip_context *ctx, const gt4hip_list *const lists[], u
  * src/set-operations.c:207-226): n_keys = n_words of lists[0], column 0 = its own counts. */
 int gt4hip_probe_table (gt4hip_context *ctx, const gt4hip_list *const lists[], uint32_t n_lists,
                         gt4hip_count_table *table);
+/* The same with `presence` != 0: column j holds 1 where list j contains the key and 0 where it does
+ * not (a list may hold a key with count 0): what search_lists_multi needs beside the counts
+ * (reference src/glistquery.c:776-812). */
+int gt4hip_probe_table_ex (gt4hip_context *ctx, const gt4hip_list *const lists[], uint32_t n_lists, int presence,
+                           gt4hip_count_table *table);
 /* Copies rows [first, first+count) of the table to host memory. */
 int gt4hip_table_download (gt4hip_context *ctx, const gt4hip_count_table *table, uint64_t first,
                            uint64_t count, uint64_t *host_keys, uint32_t *host_counts);
