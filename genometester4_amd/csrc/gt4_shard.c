@@ -357,6 +357,7 @@ static int worker_main (const GT4ShardJob *job, Shared *sh, int rank)
 {
   Worker *w = (Worker *) calloc (1, sizeof (Worker));
   if (!w) return 1;
+  FILE *errf = stderr;
   w->job = job;
   w->sh = sh;
   w->rank = rank;
@@ -370,7 +371,7 @@ static int worker_main (const GT4ShardJob *job, Shared *sh, int rank)
     const char *dev = getenv ("GT4HIP_DEVICE");
     w->device = n_dev > 0 ? ((dev ? atoi (dev) : 0) + rank) % n_dev : 0;
     if (gt4hip_create (w->device, &ctx)) worker_fail (w, "Error: %s", gt4hip_last_error (NULL));
-    if (ctx && job->debug) fprintf (stderr, "Worker %d of %d: device %d: %s\n", rank, G, w->device, gt4hip_device_info (ctx));
+    if (ctx && job->debug) fprintf (errf, "Worker %d of %d: device %d: %s\n", rank, G, w->device, gt4hip_device_info (ctx));
   }
   /* ---- worker 0 fixes the memory budget (the plan must be the same everywhere) and the RCCL id */
   if (rank == 0) {
@@ -457,7 +458,7 @@ static int worker_main (const GT4ShardJob *job, Shared *sh, int rank)
       for (int s = 0; s < 4; s++)
         if (w->out[slot][s]) gt4hip_list_free (w->out[slot][s]);
   if (job->debug)
-    fprintf (stderr, "Worker %d: %u of %u chunks, load %.3f s, merge %.3f s, write %.3f s (threads overlap)\n", rank, w->n_mine, plan.n_chunks,
+    fprintf (errf, "Worker %d: %u of %u chunks, load %.3f s, merge %.3f s, write %.3f s (threads overlap)\n", rank, w->n_mine, plan.n_chunks,
              w->t_load, w->t_merge, w->t_write);
   if (w->comm) gt4hip_comm_destroy (w->comm);
   /* a worker that stopped early still marks its chunks so that nobody waits for them */
@@ -488,11 +489,11 @@ static int worker_main (const GT4ShardJob *job, Shared *sh, int rank)
       gt4_list_header_init (&lw.header, job->word_length);
       lw.fd = w->out_fd[s];
       if (gt4_listwriter_finish (&lw, n, t)) {
-        fprintf (stderr, "Error: writing %s failed: %s\n", tmp, strerror (errno));
+        fprintf (errf, "Error: writing %s failed: %s\n", tmp, strerror (errno));
         unlink (tmp);
         rc = 1;
       } else if (rename (tmp, job->out_name[s])) {
-        fprintf (stderr, "Error: Cannot rename %s to %s\n", tmp, job->out_name[s]);
+        fprintf (errf, "Error: Cannot rename %s to %s\n", tmp, job->out_name[s]);
         rc = 1;
       }
     }
@@ -500,6 +501,7 @@ static int worker_main (const GT4ShardJob *job, Shared *sh, int rank)
   if (ctx) gt4hip_destroy (ctx);
   free (plan.cut);
   free (w);
+  if (errf != stderr) fflush (errf);
   return rc;
 }
 
@@ -523,13 +525,13 @@ int gt4_shard_run (const GT4ShardJob *job, GT4ShardResult *res)
     return 1;
   }
   const int G = job->n_ranks;
-  if (G > 1) {
+  if (G > 1 || job->gather_rccl) {
     pthread_barrierattr_init (&sh->bar_attr);
     pthread_barrierattr_setpshared (&sh->bar_attr, PTHREAD_PROCESS_SHARED);
     pthread_barrier_init (&sh->bar, &sh->bar_attr, (unsigned int) G);
   }
   int rc = 0;
-  if (G == 1) {
+  if (G == 1 && !job->gather_rccl) {
     /* the plan needs the budget, which needs the device: worker_main checks n_chunks against its own
      * plan, so tell it to accept whatever it computes */
     sh->n_chunks = 0;
@@ -563,7 +565,8 @@ int gt4_shard_run (const GT4ShardJob *job, GT4ShardResult *res)
     }
     rc = worker_main (&j1, sh, 0);
   } else {
-    /* several GPUs: the budget must be explicit or defaulted WITHOUT touching HIP in this process */
+    /* several GPUs (or the RCCL path, whose library is kept out of the calling process): the budget
+     * must be explicit or defaulted WITHOUT touching HIP in this process */
     GT4ShardJob jn = *job;
     if (!jn.hbm_limit) jn.hbm_limit = 128ull << 30; /* per worker; GT4HIP_HBM_LIMIT overrides */
     Plan p;
@@ -644,7 +647,7 @@ int gt4_shard_run (const GT4ShardJob *job, GT4ShardResult *res)
         res->total_count[s] += sh->chunk[c].t[s];
       }
   if (rc && sh->message[0] && !sh->rule_rejected) fprintf (stderr, "%s\n", sh->message);
-  if (G > 1) pthread_barrier_destroy (&sh->bar);
+  if (G > 1 || job->gather_rccl) pthread_barrier_destroy (&sh->bar);
   munmap (sh, bytes);
   return rc;
 }

@@ -15,9 +15,7 @@
 #include "gt4hip_host.h"
 
 #include <dlfcn.h>
-#include <fcntl.h>
 #include <rccl/rccl.h>
-#include <unistd.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -41,36 +39,15 @@ struct Rccl {
 Rccl g_rccl;
 char g_comm_err[256] = "";
 
-/* RCCL prints a version banner on stderr when the first communicator is made; a drop-in command-line
- * tool must not add lines to its transcript, so stderr points to /dev/null for the duration of the
- * call (failures come back as return codes and are reported by the caller).  GT4HIP_RCCL_VERBOSE=1
- * keeps the banner. */
-struct QuietStderr {
-  int saved;
-  QuietStderr () : saved (-1)
-  {
-    if (getenv ("GT4HIP_RCCL_VERBOSE")) return;
-    fflush (stderr);
-    const int nul = open ("/dev/null", O_WRONLY);
-    if (nul < 0) return;
-    saved = dup (2);
-    if (saved >= 0) dup2 (nul, 2);
-    close (nul);
-  }
-  ~QuietStderr ()
-  {
-    if (saved < 0) return;
-    fflush (stderr);
-    dup2 (saved, 2);
-    close (saved);
-  }
-};
-
 const Rccl *rccl ()
 {
   if (g_rccl.handle) return &g_rccl;
   static const char *const names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
   void *h = NULL;
+  /* With NCCL_DEBUG unset RCCL prints a five-line version banner on STDOUT when the first
+   * communicator is made; a drop-in tool's stdout must stay the reference's.  NCCL_DEBUG=NONE
+   * silences it (measured: tools/rccl_probe.sh); a value the user has set is respected. */
+  if (!getenv ("GT4HIP_RCCL_VERBOSE")) setenv ("NCCL_DEBUG", "NONE", 0);
   const char *env = getenv ("GT4HIP_RCCL_LIB");
   if (env) h = dlopen (env, RTLD_NOW | RTLD_GLOBAL);
   for (size_t i = 0; !h && i < sizeof names / sizeof names[0]; i++) h = dlopen (names[i], RTLD_NOW | RTLD_GLOBAL);
@@ -114,7 +91,6 @@ extern "C" int gt4hip_comm_unique_id (void *id_out)
   const Rccl *r = rccl ();
   if (!r) return GT4HIP_ECOMM;
   ncclUniqueId id;
-  QuietStderr quiet;
   const ncclResult_t e = r->GetUniqueId (&id);
   if (e != ncclSuccess) {
     snprintf (g_comm_err, sizeof g_comm_err, "ncclGetUniqueId: %s", r->GetErrorString (e));
@@ -137,11 +113,7 @@ extern "C" int gt4hip_comm_create (gt4hip_context *ctx, const void *id_bytes, in
   c->rank = rank;
   ncclUniqueId id;
   memcpy (&id, id_bytes, sizeof id);
-  ncclResult_t e;
-  {
-    QuietStderr quiet;
-    e = r->CommInitRank (&c->comm, n_ranks, id, rank);
-  }
+  const ncclResult_t e = r->CommInitRank (&c->comm, n_ranks, id, rank);
   if (e != ncclSuccess) {
     delete c;
     return gt4hip_fail (ctx, GT4HIP_ECOMM, "ncclCommInitRank (rank %d of %d): %s", rank, n_ranks, r->GetErrorString (e));
@@ -155,7 +127,6 @@ extern "C" void gt4hip_comm_destroy (gt4hip_comm *c)
   if (!c) return;
   const Rccl *r = rccl ();
   if (r) {
-    QuietStderr quiet;
     hipSetDevice (c->ctx->device);
     hipStreamSynchronize (c->ctx->stream);
     r->CommDestroy (c->comm);
@@ -175,7 +146,6 @@ extern "C" int gt4hip_comm_gatherv (gt4hip_comm *c, const gt4hip_list *local, co
   const uint64_t mine = counts[c->rank];
   if (mine && (!local || local->n_words < mine)) return gt4hip_fail (ctx, GT4HIP_EINVAL, "gatherv: local list shorter than counts[rank]");
   HIPCHK (ctx, hipSetDevice (ctx->device));
-  QuietStderr quiet; /* (the version banner comes with the first collective on some RCCL builds) */
   ncclResult_t e = ncclSuccess;
   if (c->rank != root) {
     if (mine) {

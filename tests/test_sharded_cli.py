@@ -24,7 +24,9 @@ pytestmark = pytest.mark.gpu
 MODES = {
     "chunks": {"GT4HIP_HBM_LIMIT": "1K"},
     "gpus2": {"GT4HIP_GPUS": "2", "GT4HIP_HBM_LIMIT": "6K"},
-    "rccl1": {"GT4HIP_GPUS": "1", "GT4HIP_GATHER": "rccl", "GT4HIP_HBM_LIMIT": "64K"},
+    # (NCCL_DEBUG: an environment that asks RCCL for its version banner gets it on stdout; the transcripts
+    # are compared with the library quiet -- the tool itself only sets NCCL_DEBUG=NONE when it is unset)
+    "rccl1": {"GT4HIP_GPUS": "1", "GT4HIP_GATHER": "rccl", "GT4HIP_HBM_LIMIT": "64K", "NCCL_DEBUG": "NONE"},
 }
 GPU_CASES = [c for c in GL_CASES if c["id"] not in NO_GPU_IDS]
 # the forked / RCCL modes start several HIP contexts per run: a spread of the cases, not all of them
@@ -63,7 +65,7 @@ def test_two_worker_processes_reproduce_reference(case, workdir):
     _check(case, workdir, MODES["gpus2"])
 
 
-@pytest.mark.parametrize("case", SUBSET, ids=lambda c: c["id"])
+@pytest.mark.parametrize("case", SUBSET[::3], ids=lambda c: c["id"])
 def test_rccl_gather_path_reproduces_reference(case, workdir):
     _check(case, workdir, MODES["rccl1"])
 
