@@ -488,12 +488,12 @@ static int grow (gt4hip_context *ctx, void **p, size_t *have, size_t need)
 
 /* ------------------------------------------------------------------ pair operation core */
 
-/* descriptor workspace: single pass agg u32[4][rows*64] + carry u64[4][rows+1]; the two-pass path
- * keeps u64[4] per tile in the same buffer */
+/* descriptor workspace: single pass agg u32[4][rows*64] + carry u64[4][rows+1] + rowsum u64[4][rows];
+ * the two-pass path keeps u64[4] per tile in the same buffer */
 static size_t desc_bytes_for (uint64_t tiles)
 {
   const uint64_t rows = (tiles + 63) / 64;
-  const size_t single = (size_t) rows * 64 * 16 + (size_t) (rows + 1) * 32;
+  const size_t single = (size_t) rows * 64 * 16 + (size_t) (rows + 1) * 32 + (size_t) rows * 32;
   const size_t two = (size_t) tiles * 32;
   return ((single > two ? single : two) + 255) & ~(size_t) 255;
 }
@@ -555,10 +555,10 @@ static int run_pair (gt4hip_context *ctx, const uint32_t *A, uint64_t nA, const 
     if ((rc = grow (ctx, (void **) &ctx->block_sums, &ctx->block_sums_bytes, nb))) return rc;
   }
   const int first_mode = count_only ? MODE_COUNT : (two_pass ? MODE_COUNT : MODE_LOOKBACK);
-  int grid = ctx->n_cus * merge_blocks_per_cu (geom, first_mode, p.ops);
+  int grid = ctx->n_cus * merge_blocks_per_cu (geom, first_mode, p.ops, &p);
   if (ctx->grid_override > 0) grid = (int) ctx->grid_override;
   if ((uint64_t) grid > tiles + 1) grid = (int) tiles + 1; /* workers + the scanner workgroup */
-  int grid2 = ctx->n_cus * merge_blocks_per_cu (geom, MODE_OFFSETS, p.ops);
+  int grid2 = ctx->n_cus * merge_blocks_per_cu (geom, MODE_OFFSETS, p.ops, &p);
   if ((uint64_t) grid2 > tiles) grid2 = (int) tiles;
 
   PairOutputs outs;

@@ -208,6 +208,107 @@ __device__ void scanner_wave (u32 *agg, u64 *carry_out, u64 num_tiles, PairContr
   }
 }
 
+/* The scanner split over several wavefronts of the scanner workgroup, for launches with more rows
+ * than one wavefront can both sum and chain (2e6 tiles of the small geometry: 3e4 rows in ~12 ms).
+ * SUMMER wavefronts (any number) take the rows round-robin, sum each complete row and publish
+ * rowsum[row] (64-bit, flag in bit 63); ONE chainer wavefront reads 64 row sums per load, turns every
+ * leading stretch of published ones into carries with a wave scan and publishes them -- the serial
+ * chain advances up to 64 rows per memory round trip instead of one row per DPP reduction. */
+__device__ void summer_wave (u32 *agg, u64 *rowsum, u64 num_tiles, PairControl *ctl, int lane, u32 spin_limit, u32 first, u32 stride)
+{
+  __builtin_amdgcn_s_setprio (2);
+  const u64 rows = (num_tiles + WAVE - 1) / WAVE;
+  if (first >= rows) return;
+  const u64 mine = (rows - first + stride - 1) / stride; /* rows first, first + stride, ... */
+  u32 v[SCAN_ROWS], w[SCAN_ROWS];
+  auto load_batch = [&] (u32 (&dst)[SCAN_ROWS], u64 i0) {
+#pragma unroll
+    for (int j = 0; j < SCAN_ROWS; j++) {
+      const u64 r = first + (i0 + j) * stride, idx = r * WAVE + lane;
+      dst[j] = (i0 + j < mine && idx < num_tiles) ? peek_u32 (&agg[idx]) : AGG_READY;
+    }
+  };
+  load_batch (v, 0);
+  for (u64 i0 = 0; i0 < mine; i0 += SCAN_ROWS) {
+    const int n = mine - i0 < (u64) SCAN_ROWS ? (int) (mine - i0) : SCAN_ROWS;
+    load_batch (w, i0 + SCAN_ROWS);
+    u32 pending = n == 32 ? 0xffffffffu : ((1u << n) - 1u); /* rows of the batch not yet published (any order) */
+    u32 spins = 0;
+    for (;;) {
+#pragma unroll
+      for (int j = 0; j < SCAN_ROWS; j++) {
+        if (((pending >> j) & 1u) && __all ((v[j] & AGG_READY) != 0)) {
+          const u32 sum = dpp_wave_sum_u32 (v[j] & ~AGG_READY);
+          if (lane == 0) publish_u64 (&rowsum[first + (i0 + j) * stride], CARRY_READY | sum);
+          pending &= ~(1u << j);
+        }
+      }
+      if (!pending) break;
+      if ((spins & 63u) == 63u && peek_u32 (&ctl->error)) spins = spin_limit;
+      if (++spins > spin_limit) {
+        if (lane == 0) atomicOr (&ctl->error, 4u);
+        return;
+      }
+#pragma unroll
+      for (int j = 0; j < SCAN_ROWS; j++) {
+        const u64 idx = (first + (i0 + j) * stride) * WAVE + lane;
+        if (((pending >> j) & 1u) && !(v[j] & AGG_READY)) v[j] = peek_u32 (&agg[idx]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < SCAN_ROWS; j++) v[j] = w[j];
+  }
+}
+
+__device__ void chainer_wave (u64 *rowsum, u64 *carry_out, u64 num_tiles, PairControl *ctl, int lane, u32 spin_limit)
+{
+  __builtin_amdgcn_s_setprio (3);
+  const u64 rows = (num_tiles + WAVE - 1) / WAVE;
+  if (lane == 0) publish_u64 (&carry_out[0], CARRY_READY);
+  u64 base = 0;
+  u64 nv = lane < (int) (rows < (u64) WAVE ? rows : WAVE) ? peek_u64 (&rowsum[lane]) : CARRY_READY; /* next block, loaded ahead */
+  for (u64 b0 = 0; b0 < rows; b0 += WAVE) {
+    const u64 r = b0 + lane;
+    const bool in = r < rows;
+    u64 v = nv;
+    {
+      const u64 rn = r + WAVE;
+      nv = rn < rows ? peek_u64 (&rowsum[rn]) : CARRY_READY;
+    }
+    int done = 0;
+    u32 spins = 0;
+    for (;;) {
+      const u64 ready = __builtin_amdgcn_ballot_w64 ((v & CARRY_READY) != 0);
+      const int lead = ~ready ? (int) __builtin_ctzll (~ready) : WAVE; /* rows of the block whose sums are all in, from its start */
+      if (lead > done) {
+        const u64 inc = wave_inclusive_scan (lane < lead ? (v & ~CARRY_READY) : 0ull, lane);
+        if (lane >= done && lane < lead && in) publish_u64 (&carry_out[r + 1], CARRY_READY | (base + inc));
+        done = lead;
+        if (done >= WAVE) {
+          base += (u64) __shfl ((u32) inc, WAVE - 1, WAVE) | ((u64) __shfl ((u32) (inc >> 32), WAVE - 1, WAVE) << 32);
+          break;
+        }
+      }
+      if ((spins & 63u) == 63u && peek_u32 (&ctl->error)) spins = spin_limit;
+      if (++spins > spin_limit) {
+        if (lane == 0) atomicOr (&ctl->error, 4u);
+        return;
+      }
+      if (in && !(v & CARRY_READY)) v = peek_u64 (&rowsum[r]);
+    }
+  }
+}
+
+/* The scanner workgroup's wavefront `sub` of `n_sub` working for one output stream: alone it sums
+ * and chains (scanner_wave); with company, wavefront 0 chains and the others sum. */
+__device__ __forceinline__ void scanner_part (u32 *agg, u64 *rowsum, u64 *carry_out, u64 num_tiles, PairControl *ctl, int lane, u32 spin_limit,
+                                              u32 sub, u32 n_sub)
+{
+  if (n_sub <= 1) scanner_wave (agg, carry_out, num_tiles, ctl, lane, spin_limit);
+  else if (sub == 0) chainer_wave (rowsum, carry_out, num_tiles, ctl, lane, spin_limit);
+  else summer_wave (agg, rowsum, num_tiles, ctl, lane, spin_limit, sub - 1, n_sub - 1);
+}
+
 /* A tile's global output offset: carry of its row + counts of the tiles before it in the row.
  * `a` and `c` are the values of an earlier, speculative load of the same words (or 0). */
 __device__ __forceinline__ u64 resolve_offset (u32 *agg, u64 *carry, u64 tile, int lane, u32 a, u64 c, PairControl *ctl, u32 spin_limit)

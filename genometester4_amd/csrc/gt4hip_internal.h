@@ -79,7 +79,7 @@ hipError_t launch_extract_column (hipStream_t s, const uint32_t *rec, uint64_t n
 hipError_t launch_extract_keys (hipStream_t s, const uint32_t *rec, uint64_t n, unsigned long long *keys);
 hipError_t launch_decode_index (hipStream_t s, const unsigned long long *kmers, uint64_t n, uint64_t num_locations, uint32_t *rec);
 
-int merge_blocks_per_cu (int geom, int mode, uint32_t ops);
+int merge_blocks_per_cu (int geom, int mode, uint32_t ops, const PairParams *p = nullptr);
 
 }  // namespace gt4
 

@@ -208,7 +208,11 @@ __global__ void k_partition (const u32 *__restrict__ A, u64 nA, const u32 *__res
  */
 /* launch bound (waves per SIMD): count-only kernels of the small geometry fit 85 VGPRs and 26 KB of
  * LDS -> three workgroups per CU; everything else runs at 4 waves per SIMD */
-__host__ __device__ constexpr int merge_waves_per_simd (int nt, int mode) { return (nt == 512 && mode == MODE_COUNT) ? 6 : 4; }
+__host__ __device__ constexpr int merge_waves_per_simd (int nt, int mode, int ops = 0, int fast = 0)
+{
+  /* the small geometry's folded intersection fits 80 registers and 50 KB too: three workgroups per CU */
+  return (nt == 512 && (mode == MODE_COUNT || (ops == 2 && fast == 1))) ? 6 : 4;
+}
 
 /* records per thread: an intersection does per-record work on the A half of a tile only and
  * stages at most half a tile, so its tiles are 1.5x as long (6 positions per thread, 6080 records:
@@ -234,7 +238,7 @@ struct RankShared {
                                      : (OPS == STAGE_ANY ? 3 * (2 * CAP + 16) : (OPS == STAGE_UNION_LATE ? 3 * (CAP + 16) : 4))); /* 16-byte multiples */
   /* write-out lags this many tiles behind ranking (LAG): two slots in general; an intersection on
    * 4-position tiles has room for four half-size slots; the late-written layouts use one */
-  static constexpr int STAGE_SLOTS = (OPS == STAGE_INTRSEC && IPT <= 4) ? 4 : ((OPS == STAGE_ANY || OPS == STAGE_UNION_LATE) ? 1 : 2);
+  static constexpr int STAGE_SLOTS = (OPS == STAGE_INTRSEC && IPT <= 4 && NT > 512) ? 4 : ((OPS == STAGE_ANY || OPS == STAGE_UNION_LATE) ? 1 : 2);
   /* input view: the tile's packed records exactly as they lie in HBM (12-byte AoS), the A range
    * from dword 0, the B range from the next 16-byte boundary */
   alignas (16) u32 raw[3 * CAP];
@@ -382,8 +386,10 @@ struct TileRange {
  * intersection: MIN, first complement: SUBTRACT without -du; any-combination kernel: every
  * requested stream on its default rule), any cutoff; 2 / 3: ADD keeping every key / every sum
  * >= cutoff (intermediate and final N-way union levels). */
-template <int NT, int IPT, int MODE, int OPS, int FAST = 0>
-__global__ __launch_bounds__ (NT, merge_waves_per_simd (NT, MODE)) void
+/* OPSET != 0 (any-combination kernel only): the set of output streams fixed at compile time -- the
+ * other streams' code, registers and scalar branches disappear (glistcompare -u -d, BASELINE config 2) */
+template <int NT, int IPT, int MODE, int OPS, int FAST = 0, int OPSET = 0>
+__global__ __launch_bounds__ (NT, merge_waves_per_simd (NT, MODE, OPS, FAST)) void
 k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 nB, u64 *part, u64 num_tiles,
               PairParams p, PairOutputs outs, u64 *desc, PairControl *ctl)
 {
@@ -409,7 +415,8 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
 
   const int tid = threadIdx.x, lane = tid & (WAVE - 1);
   const int wid = __builtin_amdgcn_readfirstlane (tid / WAVE); /* wave-uniform: scalar branches on it */
-  const u32 ops = OPS ? (u32) OPS : p.ops;
+  static_assert (OPSET == 0 || OPS == 0, "a compile-time stream set belongs to the any-combination kernel");
+  const u32 ops = OPS ? (u32) OPS : (OPSET ? (u32) OPSET : p.ops);
   /* every "both" pair is evaluated at its A record, so A records always matter; B records only
    * where a B-only key can be kept (union, diff2) */
   const bool need_b = (ops & 9u) != 0;
@@ -428,7 +435,20 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
     role = sh.tick[0];
     __syncthreads ();
     if (role == 0) {
-      if (wid < 4 && ((ops >> wid) & 1u)) scanner_wave (agg + (u64) wid * n_rows * WAVE, carry + (u64) wid * (n_rows + 1), num_tiles, ctl, lane, spin_limit);
+      /* the workgroup's wavefronts are dealt to the requested streams round-robin: the first one of a
+       * stream chains its carries, the others sum its rows (scanner_part) */
+      const u32 n_str = (u32) __builtin_popcount (ops);
+      const u32 k = (u32) wid % n_str, sub = (u32) wid / n_str, n_sub = ((u32) NW - k + n_str - 1) / n_str;
+      u32 s = 0;
+      for (u32 seen = 0, b = 0; b < 4; b++)
+        if ((ops >> b) & 1u) {
+          if (seen == k) s = b;
+          seen++;
+        }
+      u64 *const rowsum = carry + 4 * (n_rows + 1);
+      if (sub < 8u)
+        scanner_part (agg + (u64) s * n_rows * WAVE, rowsum + (u64) s * n_rows, carry + (u64) s * (n_rows + 1), num_tiles, ctl, lane, spin_limit, sub,
+                      n_sub > 8u ? 8u : n_sub);
       return;
     }
   }
@@ -1094,26 +1114,41 @@ hipError_t launch_partition (hipStream_t s, const uint32_t *A, uint64_t nA, cons
  * and 2048-record tiles (two workgroups per CU overlap their phases); calls that materialise
  * records run fastest with 1024 threads and 4096-record tiles (half as many tiles on the scan
  * chain, whose hop latency is fixed, and room for the staging slots in one workgroup per CU). */
+/* the rule-folded variant a call takes (see FAST in k_pair_merge); 0: the general coefficient form */
+static int fast_variant (int ops_cls, const PairParams &p)
+{
+  int fast = 0;
+  if (p.filter == FILTER_REFERENCE) {
+    if (ops_cls == 1 && p.rule[0] == 1u) fast = 1;
+    if (ops_cls == 2 && p.rule[1] == 3u) fast = 1;
+    if (ops_cls == 4 && p.rule[2] == 2u && !p.subtract) fast = 1;
+  } else if (ops_cls == 1 && p.rule[0] == 1u) {
+    fast = p.filter == FILTER_RAW ? 2 : 3; /* N-way union levels: keep every key / keep sums >= cutoff (union_multi, :574) */
+  }
+  /* any combination of outputs with every requested stream on its default rule, any cutoff, no -du */
+  if (ops_cls == 0 && p.filter == FILTER_REFERENCE && !p.subtract && (!(p.ops & 1u) || p.rule[0] == 1u) && (!(p.ops & 2u) || p.rule[1] == 3u) &&
+      (!(p.ops & 4u) || p.rule[2] == 2u) && (!(p.ops & 8u) || p.rule[3] == 2u))
+    fast = 1;
+  return fast;
+}
+
 template <int NT, int OPS>
 static hipError_t launch_pair_merge_ops (hipStream_t s, int mode, int grid, const uint32_t *A, uint64_t nA, const uint32_t *B, uint64_t nB,
                                          const uint64_t *part, uint64_t num_tiles, const PairParams &p, const PairOutputs &o,
                                          unsigned long long *desc, PairControl *ctl)
 {
   /* the commonest single-output calls take the variant with the rule folded in (see FAST) */
-  int fast = 0;
-  if (p.filter == FILTER_REFERENCE) {
-    if (OPS == 1 && p.rule[0] == 1u) fast = 1;
-    if (OPS == 2 && p.rule[1] == 3u) fast = 1;
-    if (OPS == 4 && p.rule[2] == 2u && !p.subtract) fast = 1;
-  } else if (OPS == 1 && p.rule[0] == 1u) {
-    fast = p.filter == FILTER_RAW ? 2 : 3; /* N-way union levels: keep every key / keep sums >= cutoff (union_multi, :574) */
-  }
-  /* any combination of outputs with every requested stream on its default rule, any cutoff, no -du */
-  if (OPS == 0 && p.filter == FILTER_REFERENCE && !p.subtract && (!(p.ops & 1u) || p.rule[0] == 1u) && (!(p.ops & 2u) || p.rule[1] == 3u) &&
-      (!(p.ops & 4u) || p.rule[2] == 2u) && (!(p.ops & 8u) || p.rule[3] == 2u))
-    fast = 1;
+  const int fast = fast_variant (OPS, p);
   constexpr int F1 = 1, F2 = OPS == 1 ? 2 : 0, F3 = OPS == 1 ? 3 : 0;
 #define GT4_LAUNCH_MERGE(M, F) hipLaunchKernelGGL ((k_pair_merge<NT, merge_ipt (NT, OPS), M, OPS, F>), dim3 (grid), dim3 (NT), 0, s, A, nA, B, nB, (u64 *) part, num_tiles, p, o, desc, ctl)
+  if (OPS == 0 && fast == 1 && p.ops == 5u && (mode == MODE_COUNT ? NT == 512 : NT == 1024)) {
+    /* union + first complement (-u -d) with the default rules: the stream set is a compile-time constant */
+    constexpr int O5 = OPS == 0 ? 5 : 0;
+    if (mode == MODE_COUNT) hipLaunchKernelGGL ((k_pair_merge<NT, merge_ipt (NT, OPS), MODE_COUNT, OPS, 1, O5>), dim3 (grid), dim3 (NT), 0, s, A, nA, B, nB, (u64 *) part, num_tiles, p, o, desc, ctl);
+    else if (mode == MODE_LOOKBACK) hipLaunchKernelGGL ((k_pair_merge<NT, merge_ipt (NT, OPS), MODE_LOOKBACK, OPS, 1, O5>), dim3 (grid), dim3 (NT), 0, s, A, nA, B, nB, (u64 *) part, num_tiles, p, o, desc, ctl);
+    else hipLaunchKernelGGL ((k_pair_merge<NT, merge_ipt (NT, OPS), MODE_OFFSETS, OPS, 1, O5>), dim3 (grid), dim3 (NT), 0, s, A, nA, B, nB, (u64 *) part, num_tiles, p, o, desc, ctl);
+    return hipGetLastError ();
+  }
   if (mode == MODE_COUNT) {
     if (fast == 1 && F1) GT4_LAUNCH_MERGE (MODE_COUNT, F1);
     else if (fast == 2 && F2) GT4_LAUNCH_MERGE (MODE_COUNT, F2);
@@ -1160,8 +1195,19 @@ uint64_t merge_tile_records (int geom, uint32_t ops)
 
 /* workgroups of the merge kernel that are resident per CU (the single-pass path needs every
  * worker resident: see k_pair_merge) */
-int merge_blocks_per_cu (int geom, int mode, uint32_t ops)
+int merge_blocks_per_cu (int geom, int mode, uint32_t ops, const PairParams *p)
 {
+  /* the small geometry's folded intersection is built for three workgroups per CU (80 registers, 50 KB) */
+  if (!geom && mode != MODE_COUNT && ops == 2u && p && fast_variant (2, *p) == 1) {
+    static int c3 = 0;
+    if (!c3) {
+      int n = 0;
+      const hipError_t e = mode == MODE_LOOKBACK ? hipOccupancyMaxActiveBlocksPerMultiprocessor (&n, k_pair_merge<512, MERGE_VT, MODE_LOOKBACK, 2, 1>, 512, 0)
+                                                 : hipOccupancyMaxActiveBlocksPerMultiprocessor (&n, k_pair_merge<512, MERGE_VT, MODE_OFFSETS, 2, 1>, 512, 0);
+      c3 = (e != hipSuccess || n < 1) ? 1 : (n > 3 ? 3 : n);
+    }
+    return c3;
+  }
   static int cache[2][3][5];
   const int oi = ops_class (ops);
   int &c = cache[geom ? 1 : 0][mode][oi];

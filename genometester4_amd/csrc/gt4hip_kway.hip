@@ -157,7 +157,7 @@ k_kway_merge (KwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
     role = sh.tick[0];
     __syncthreads ();
     if (role == 0) {
-      if (wid == 0) scanner_wave (agg, carry, p.num_tiles, ctl, lane, spin_limit);
+      if (wid < 8) scanner_part (agg, carry + 4 * (n_rows + 1), carry, p.num_tiles, ctl, lane, spin_limit, (u32) wid, NW < 8 ? (u32) NW : 8u);
       return;
     }
   }
@@ -539,7 +539,7 @@ struct Level {
 size_t kway_desc_bytes (u64 tiles)
 {
   const u64 rows = (tiles + 63) / 64;
-  return (((size_t) rows * 64 * 16 + (size_t) (rows + 1) * 32) + 255) & ~(size_t) 255;
+  return (((size_t) rows * 64 * 16 + (size_t) (rows + 1) * 32 + (size_t) rows * 32) + 255) & ~(size_t) 255; /* agg, carry, rowsum */
 }
 
 int kway_grow (gt4hip_context *ctx, void **p, size_t *have, size_t need)
