@@ -51,7 +51,7 @@ SYMBOLS = [
     "gt4hip_union_multi", "gt4hip_intersect_multi", "gt4hip_union_table", "gt4hip_probe_table", "gt4hip_probe_table_ex", "gt4hip_table_download",
     "gt4hip_table_free", "gt4hip_generate", "gt4hip_generate_ex", "gt4hip_synchronize", "gt4hip_set_option",
     "gt4hip_get_counter", "gt4hip_device_memory", "gt4hip_list_upload_fd", "gt4hip_list_load_fd", "gt4hip_list_load",
-    "gt4hip_list_write_fd", "gt4hip_shard_first_key", "gt4hip_comm_unique_id", "gt4hip_comm_create", "gt4hip_comm_destroy",
+    "gt4hip_list_write_fd", "gt4hip_lists_write_fd", "gt4hip_shard_first_key", "gt4hip_comm_unique_id", "gt4hip_comm_create", "gt4hip_comm_destroy",
     "gt4hip_comm_rank", "gt4hip_comm_size", "gt4hip_comm_last_error", "gt4hip_comm_gatherv",
 ]
 
@@ -113,6 +113,7 @@ def lib():
             "gt4hip_list_load_fd": (C.c_int, [vp, vp, C.c_int, u64, u64]),
             "gt4hip_list_load": (C.c_int, [vp, vp, vp, u64]),
             "gt4hip_list_write_fd": (C.c_int, [vp, vp, u64, u64, C.c_int, u64]),
+            "gt4hip_lists_write_fd": (C.c_int, [vp, u32, C.POINTER(vp), C.POINTER(u64), C.POINTER(u64), C.POINTER(C.c_int), C.POINTER(u64)]),
             "gt4hip_shard_first_key": (u64, [u32, u32, u32]),
             "gt4hip_comm_unique_id": (C.c_int, [vp]),
             "gt4hip_comm_create": (C.c_int, [vp, vp, C.c_int, C.c_int, C.POINTER(vp)]),

@@ -261,11 +261,22 @@ static void *writer_main (void *arg)
           while (!w->sh->chunk[q].done && !stopped (w)) usleep (50);
           for (int s = 0; s < 4; s++) start[s] += w->sh->chunk[q].n[s];
         }
-        for (int s = 0; s < 4 && !stopped (w); s++) {
+        /* every output stream of the chunk in one call: the copy threads are dealt to the files */
+        const gt4hip_list *wl[4];
+        uint64_t wfirst[4], wcount[4], woff[4];
+        int wfd[4];
+        uint32_t nw = 0;
+        for (int s = 0; s < 4; s++) {
           if (!w->out[slot][s] || !w->out_n[slot][s]) continue;
-          if (gt4hip_list_write_fd (ctx, w->out[slot][s], 0, w->out_n[slot][s], w->out_fd[s], 48 + 12 * start[s]))
-            worker_fail (w, "Error: writing results failed: %s", gt4hip_last_error (ctx));
+          wl[nw] = w->out[slot][s];
+          wfirst[nw] = 0;
+          wcount[nw] = w->out_n[slot][s];
+          wfd[nw] = w->out_fd[s];
+          woff[nw] = 48 + 12 * start[s];
+          nw++;
         }
+        if (nw && !stopped (w) && gt4hip_lists_write_fd (ctx, nw, wl, wfirst, wcount, wfd, woff))
+          worker_fail (w, "Error: writing results failed: %s", gt4hip_last_error (ctx));
       }
     }
     w->t_write += now_s () - t0;

@@ -27,6 +27,8 @@ constexpr int MAX_THREADS = 16;
 
 enum JobKind { JOB_NONE = 0, JOB_FD_TO_DEV, JOB_MEM_TO_DEV, JOB_DEV_TO_FD, JOB_DEV_TO_MEM, JOB_EXIT };
 
+constexpr int MAX_SEG = 4;
+
 struct Job {
   int kind;
   int fd;
@@ -35,6 +37,14 @@ struct Job {
   char *dst_mem;
   char *dev;
   size_t bytes;
+  /* JOB_DEV_TO_FD may carry several segments (the outputs of one operation, each to its own file):
+   * the copy threads are dealt to the segments, so that different threads write different files --
+   * writers of ONE file serialise on its inode lock */
+  int n_seg;
+  int seg_fd[MAX_SEG];
+  off_t seg_off[MAX_SEG];
+  char *seg_dev[MAX_SEG];
+  size_t seg_bytes[MAX_SEG];
 };
 
 struct Worker {
@@ -94,20 +104,46 @@ int full_pwrite (int fd, const void *buf, size_t len, off_t off)
   return 0;
 }
 
-/* pieces index, index + T, ... of the job, double-buffered on this worker's stream */
+void run_pieces (Worker *w, const Job &j, size_t index, size_t T);
+
+/* pieces index, index + T, ... of the job (or, with several segments, of this thread's segment) */
 void run_job (Worker *w, const Job &j)
 {
-  const size_t n_pieces = (j.bytes + PIECE - 1) / PIECE;
-  const size_t T = (size_t) w->io->n_threads;
-  const bool to_dev = j.kind == JOB_FD_TO_DEV || j.kind == JOB_MEM_TO_DEV;
+  const int T = w->io->n_threads;
   w->err = 0;
+  if (j.n_seg <= 0) {
+    run_pieces (w, j, (size_t) w->index, (size_t) T);
+    return;
+  }
+  /* several segments: with at least as many threads as segments, thread t serves segment t mod n_seg
+   * together with the other threads dealt to it; with fewer threads each takes whole segments */
+  for (int s = w->index % j.n_seg; s < j.n_seg && !w->err; s += T) {
+    Job one = j;
+    one.n_seg = 0;
+    one.fd = j.seg_fd[s];
+    one.file_off = j.seg_off[s];
+    one.dev = j.seg_dev[s];
+    one.bytes = j.seg_bytes[s];
+    if (T >= j.n_seg) {
+      run_pieces (w, one, (size_t) (w->index / j.n_seg), (size_t) ((T - s + j.n_seg - 1) / j.n_seg));
+      break;
+    }
+    run_pieces (w, one, 0, 1);
+  }
+}
+
+/* double-buffered on this worker's stream */
+void run_pieces (Worker *w, const Job &j, size_t index, size_t T)
+{
+  const size_t n_pieces = (j.bytes + PIECE - 1) / PIECE;
+  const bool to_dev = j.kind == JOB_FD_TO_DEV || j.kind == JOB_MEM_TO_DEV;
   if (to_dev) {
     int slot = 0;
     bool busy[2] = { false, false };
     hipEvent_t ev[2];
     hipEventCreateWithFlags (&ev[0], hipEventDisableTiming);
     hipEventCreateWithFlags (&ev[1], hipEventDisableTiming);
-    for (size_t p = (size_t) w->index; p < n_pieces && !w->err; p += T) {
+    for (size_t p = index; p < n_pieces && !w->err; p += T) {
       const size_t off = p * PIECE, len = j.bytes - off < PIECE ? j.bytes - off : PIECE;
       if (busy[slot] && hipEventSynchronize (ev[slot]) != hipSuccess) w->err = 2;
       if (j.kind == JOB_FD_TO_DEV) {
@@ -125,7 +161,7 @@ void run_job (Worker *w, const Job &j)
     hipEventDestroy (ev[1]);
   } else {
     /* device -> pinned (async) -> file / memory: the copy of piece i+1 runs while piece i is written */
-    size_t p = (size_t) w->index;
+    size_t p = index;
     int slot = 0;
     size_t cur_off = 0, cur_len = 0;
     bool have = false;
@@ -194,7 +230,7 @@ int io_get (gt4hip_context *ctx, gt4hip_io **out)
   gt4hip_io *io = (gt4hip_io *) calloc (1, sizeof (gt4hip_io));
   if (!io) return gt4hip_fail (ctx, GT4HIP_ENOMEM, "host allocation failed");
   io->device = ctx->device;
-  int T = 4;
+  int T = 8;
   const char *e = getenv ("GT4HIP_IO_THREADS");
   if (e && atoi (e) > 0) T = atoi (e);
   if (T > MAX_THREADS) T = MAX_THREADS;
@@ -347,6 +383,27 @@ extern "C" int gt4hip_list_write_fd (gt4hip_context *ctx, const gt4hip_list *lis
   j.dev = (char *) list->dev + first * GT4HIP_RECORD_BYTES;
   j.bytes = (size_t) count * GT4HIP_RECORD_BYTES;
   return io_run (ctx, j, "gt4hip_list_write_fd");
+}
+
+extern "C" int gt4hip_lists_write_fd (gt4hip_context *ctx, uint32_t n, const gt4hip_list *const lists[], const uint64_t first[], const uint64_t count[],
+                                      const int fds[], const uint64_t file_offsets[])
+{
+  if (!ctx || !n || n > MAX_SEG || !lists || !first || !count || !fds || !file_offsets) return GT4HIP_EINVAL;
+  HIPCHK (ctx, hipSetDevice (ctx->device));
+  Job j;
+  memset (&j, 0, sizeof j);
+  j.kind = JOB_DEV_TO_FD;
+  for (uint32_t i = 0; i < n; i++) {
+    if (!lists[i] || first[i] > lists[i]->n_words || count[i] > lists[i]->n_words - first[i]) return GT4HIP_EINVAL;
+    if (!count[i]) continue;
+    j.seg_fd[j.n_seg] = fds[i];
+    j.seg_off[j.n_seg] = (off_t) file_offsets[i];
+    j.seg_dev[j.n_seg] = (char *) lists[i]->dev + first[i] * GT4HIP_RECORD_BYTES;
+    j.seg_bytes[j.n_seg] = (size_t) count[i] * GT4HIP_RECORD_BYTES;
+    j.n_seg++;
+  }
+  if (!j.n_seg) return GT4HIP_OK;
+  return io_run (ctx, j, "gt4hip_lists_write_fd");
 }
 
 /* used by gt4hip_list_download_range for large ranges */

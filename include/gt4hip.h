@@ -109,7 +109,7 @@ int gt4hip_list_slice (gt4hip_context *ctx, const gt4hip_list *list, uint64_t fi
 /* File <-> HBM transfers (replace gt4_mmap + scout, src/utils.c:35-99, and the
  * fwrite / write output loops, src/glistcompare.c:491-496, :579-582).  The body of a list moves in
  * 8 MiB pieces through pinned staging buffers owned by the context (set up once, on first use) on
- * GT4HIP_IO_THREADS (default 4) copy threads, each with its own HIP stream: pread -> pinned -> HBM
+ * GT4HIP_IO_THREADS (default 8) copy threads, each with its own HIP stream: pread -> pinned -> HBM
  * and HBM -> pinned -> pwrite overlap piece by piece.  `fd` needs no particular file position.
  *   _upload_fd  new list from n_words records at byte `file_offset` of `fd`
  *   _load_fd    the same into an existing list (capacity >= n_words; sets n_words)
@@ -122,6 +122,10 @@ int gt4hip_list_load_fd (gt4hip_context *ctx, gt4hip_list *list, int fd, uint64_
 int gt4hip_list_load (gt4hip_context *ctx, gt4hip_list *list, const void *host_records, uint64_t n_words);
 int gt4hip_list_write_fd (gt4hip_context *ctx, const gt4hip_list *list, uint64_t first, uint64_t count, int fd,
                           uint64_t file_offset);
+/* Up to four lists to four files in one go (the outputs of one compare_wordmaps pass): the copy threads
+ * are dealt to the files, because several writers of ONE file serialise on its inode lock. */
+int gt4hip_lists_write_fd (gt4hip_context *ctx, uint32_t n, const gt4hip_list *const lists[], const uint64_t first[],
+                           const uint64_t count[], const int fds[], const uint64_t file_offsets[]);
 /* Copies the records back to host memory (n_words * 12 bytes). */
 int gt4hip_list_download (gt4hip_context *ctx, const gt4hip_list *list, void *host_records);
 /* Copies records [first, first+count) back to host memory. */
