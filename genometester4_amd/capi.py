@@ -52,7 +52,7 @@ SYMBOLS = [
     "gt4hip_table_free", "gt4hip_generate", "gt4hip_generate_ex", "gt4hip_synchronize", "gt4hip_set_option",
     "gt4hip_get_counter", "gt4hip_device_memory", "gt4hip_list_upload_fd", "gt4hip_list_load_fd", "gt4hip_list_load",
     "gt4hip_list_write_fd", "gt4hip_lists_write_fd", "gt4hip_shard_first_key", "gt4hip_comm_unique_id", "gt4hip_comm_create", "gt4hip_comm_destroy",
-    "gt4hip_comm_rank", "gt4hip_comm_size", "gt4hip_comm_last_error", "gt4hip_comm_gatherv",
+    "gt4hip_comm_rank", "gt4hip_comm_size", "gt4hip_comm_last_error", "gt4hip_comm_gatherv", "gt4hip_sort_words", "gt4hip_words_to_list",
 ]
 
 _lib = None
@@ -122,6 +122,8 @@ def lib():
             "gt4hip_comm_size": (C.c_int, [vp]),
             "gt4hip_comm_last_error": (C.c_char_p, []),
             "gt4hip_comm_gatherv": (C.c_int, [vp, vp, C.POINTER(u64), C.c_int, vp]),
+            "gt4hip_sort_words": (C.c_int, [vp, vp, u64, u32]),
+            "gt4hip_words_to_list": (C.c_int, [vp, vp, u64, u32, C.POINTER(vp)]),
         }
         for name, (res, args) in sig.items():
             f = getattr(L, name)
@@ -246,6 +248,13 @@ class Context:
 
     def synchronize(self):
         self._chk(lib().gt4hip_synchronize(self.h))
+
+    def words_to_list(self, words, word_length) -> "DeviceList":
+        """Packed k-mer words (any order, repeats) -> sorted (word, occurrences) list on the device."""
+        w = np.ascontiguousarray(words, dtype=np.uint64)
+        h = C.c_void_p()
+        self._chk(lib().gt4hip_words_to_list(self.h, w.ctypes.data if len(w) else None, len(w), word_length, C.byref(h)))
+        return DeviceList(self, h)
 
     def device_memory(self):
         f, t = C.c_uint64(), C.c_uint64()

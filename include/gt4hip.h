@@ -258,6 +258,18 @@ const char *gt4hip_comm_last_error (void);
 int gt4hip_comm_gatherv (gt4hip_comm *comm, const gt4hip_list *local, const uint64_t counts[], int root,
                          gt4hip_list *gathered);
 
+/* ---------------------------------------------------------------- glistmaker's table step */
+
+/* Sorts n_words packed 64-bit k-mer words (device memory) ascending, in place: the reference's
+ * wordtable_sort (src/word-table.c:217-231; hybridInPlaceRadixSort256, src/utils.c:127-198) as an LSD
+ * radix sort over the 2 * word_length significant bits.  At most 2^32 - 1 words per call. */
+int gt4hip_sort_words (gt4hip_context *ctx, void *device_words, uint64_t n_words, uint32_t word_length);
+/* Sort + wordtable_find_frequencies (src/word-table.c:233-260): host words (any order, repeats
+ * allowed) -> a new list of (word, number of occurrences) records, ascending -- what glistmaker writes
+ * to its temporary lists before gt4_write_union collates them (src/glistmaker.c:914-924, :333, :814). */
+int gt4hip_words_to_list (gt4hip_context *ctx, const uint64_t *host_words, uint64_t n_words, uint32_t word_length,
+                          gt4hip_list **out);
+
 /* ---------------------------------------------------------------- synthetic lists (bench) */
 
 /* Fills `list` (capacity >= n) with n strictly ascending keys < 4^word_length and counts in
