@@ -4,6 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from genometester4_amd import capi
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 500_000_000
 ctx = capi.Context(0)
+ctx.set_option("kway", int(os.environ.get("KWAY", "1")))
 lists = []
 for j in range(8):
     l = ctx.alloc(n, 25)
