@@ -27,6 +27,9 @@
 #ifndef GT4_IPT_INTERSECT
 #define GT4_IPT_INTERSECT 6
 #endif
+#ifndef GT4_IPT_INTERSECT_SMALL
+#define GT4_IPT_INTERSECT_SMALL 4 /* positions per thread of the 512-thread intersection (experiments: 6) */
+#endif
 
 namespace gt4 {
 
@@ -211,7 +214,7 @@ __global__ void k_partition (const u32 *__restrict__ A, u64 nA, const u32 *__res
 __host__ __device__ constexpr int merge_waves_per_simd (int nt, int mode, int ops = 0, int fast = 0)
 {
   /* the small geometry's folded intersection fits 80 registers and 50 KB too: three workgroups per CU */
-  return (nt == 512 && (mode == MODE_COUNT || (ops == 2 && fast == 1))) ? 6 : 4;
+  return (nt == 512 && (mode == MODE_COUNT || (ops == 2 && fast == 1 && GT4_IPT_INTERSECT_SMALL <= 4))) ? 6 : 4;
 }
 
 /* records per thread: an intersection does per-record work on the A half of a tile only and
@@ -219,7 +222,8 @@ __host__ __device__ constexpr int merge_waves_per_simd (int nt, int mode, int op
  * the per-tile costs -- barriers, ring, scan, fetch set-up -- are paid two thirds as often) */
 __host__ __device__ constexpr int merge_ipt (int nt, int ops_class)
 {
-  return (nt == 1024 && ops_class == 2) ? GT4_IPT_INTERSECT : ((nt == 1024 && ops_class == 1) ? GT4_IPT_UNION : MERGE_VT); /* 0 (any) and 4 (complement): MERGE_VT */
+  return (nt == 1024 && ops_class == 2) ? GT4_IPT_INTERSECT
+         : ((nt == 1024 && ops_class == 1) ? GT4_IPT_UNION : ((nt == 512 && ops_class == 2) ? GT4_IPT_INTERSECT_SMALL : MERGE_VT)); /* 0 (any) and 4 (complement): MERGE_VT */
 }
 
 /* staging layout of a kernel's LDS (third parameter of RankShared) */
@@ -1202,8 +1206,8 @@ int merge_blocks_per_cu (int geom, int mode, uint32_t ops, const PairParams *p)
     static int c3 = 0;
     if (!c3) {
       int n = 0;
-      const hipError_t e = mode == MODE_LOOKBACK ? hipOccupancyMaxActiveBlocksPerMultiprocessor (&n, k_pair_merge<512, MERGE_VT, MODE_LOOKBACK, 2, 1>, 512, 0)
-                                                 : hipOccupancyMaxActiveBlocksPerMultiprocessor (&n, k_pair_merge<512, MERGE_VT, MODE_OFFSETS, 2, 1>, 512, 0);
+      const hipError_t e = mode == MODE_LOOKBACK ? hipOccupancyMaxActiveBlocksPerMultiprocessor (&n, k_pair_merge<512, merge_ipt (512, 2), MODE_LOOKBACK, 2, 1>, 512, 0)
+                                                 : hipOccupancyMaxActiveBlocksPerMultiprocessor (&n, k_pair_merge<512, merge_ipt (512, 2), MODE_OFFSETS, 2, 1>, 512, 0);
       c3 = (e != hipSuccess || n < 1) ? 1 : (n > 3 ? 3 : n);
     }
     return c3;
