@@ -157,6 +157,7 @@ extern "C" int gt4hip_set_option (gt4hip_context *ctx, const char *name, int64_t
     if (ctx->pool_bytes > ctx->pool_cap) pool_flush (ctx);
   }
   else if (!strcmp (name, "grid")) ctx->grid_override = value;
+  else if (!strcmp (name, "scan_group")) ctx->scan_group = (int) value;
   else if (!strcmp (name, "kway")) ctx->kway_enabled = value != 0;
   else if (!strcmp (name, "kway_g")) ctx->kway_g = value;
   else if (!strcmp (name, "kway_vt")) ctx->kway_vt = value;
@@ -545,6 +546,10 @@ static int run_pair (gt4hip_context *ctx, const uint32_t *A, uint64_t nA, const 
   const uint64_t tiles = (total + tile_records - 1) / tile_records;
   if (tiles >= 0xffffffffull) return gt4hip_fail (ctx, GT4HIP_EINVAL, "lists too long: %llu merge tiles", (unsigned long long) tiles);
   run->tiles = tiles;
+  /* the scanner as a group of wavefronts pays off where one wavefront cannot keep up (more than ~2e4
+   * rows of 64 tiles per launch: the small geometry on billions of records); below that the single
+   * wavefront's shorter path to the carry is worth more (option "scan_group": -1 never, 1 always) */
+  p.scan_group = ctx->scan_group > 0 ? 1u : (ctx->scan_group < 0 ? 0u : (tiles > (20000ull << 6) ? 1u : 0u));
   int rc;
   if ((rc = grow (ctx, (void **) &ctx->part, &ctx->part_bytes, (size_t) (tiles + 1) * 16 + (size_t) (tiles / 64 + 3) * 8))) return rc; /* tile ranges + coarse co-ranks */
   const bool two_pass = (ctx->two_pass || force_two_pass) && !count_only;

@@ -27,6 +27,7 @@ struct PairParams {
   uint32_t count_override;
   uint32_t filter;
   uint32_t spin_limit;     /* bound of every inter-workgroup wait (0: the default, ~seconds); tests set it low */
+  uint32_t scan_group;     /* 0: one scanner wavefront per stream; 1: summers + chainer (launches with many rows) */
 };
 
 struct PairOutputs {

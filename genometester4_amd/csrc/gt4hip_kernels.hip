@@ -450,9 +450,9 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
           seen++;
         }
       u64 *const rowsum = carry + 4 * (n_rows + 1);
-      if (sub < 8u)
+      if (sub < 8u && (p.scan_group || sub == 0))
         scanner_part (agg + (u64) s * n_rows * WAVE, rowsum + (u64) s * n_rows, carry + (u64) s * (n_rows + 1), num_tiles, ctl, lane, spin_limit, sub,
-                      n_sub > 8u ? 8u : n_sub);
+                      p.scan_group ? (n_sub > 8u ? 8u : n_sub) : 1u);
       return;
     }
   }
