@@ -89,10 +89,15 @@ def workdir():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["plain", "chunks", "gpus2"])
 @pytest.mark.parametrize("case", CASES, ids=lambda c: c["id"])
-def test_cli_reproduces_reference_on_index_inputs(case, workdir):
+def test_cli_reproduces_reference_on_index_inputs(case, workdir, mode):
+    """plain: whole tables in HBM; chunks / gpus2: key-range slices of the index tables (the count of
+    a slice's last entry reaches to the NEXT entry's first location) through the chunk pipeline /
+    two worker processes."""
+    env = dict(os.environ, **{"plain": {}, "chunks": {"GT4HIP_HBM_LIMIT": "2K"}, "gpus2": {"GT4HIP_GPUS": "2", "GT4HIP_HBM_LIMIT": "8K"}}[mode])
     before = set(os.listdir(workdir))
-    p = subprocess.run([CLI] + case["argv"], cwd=workdir, capture_output=True, timeout=300)
+    p = subprocess.run([CLI] + case["argv"], cwd=workdir, capture_output=True, timeout=300, env=env)
     created = sorted(set(os.listdir(workdir)) - before)
     try:
         assert p.returncode == case["exit"], p.stderr.decode("latin-1")
