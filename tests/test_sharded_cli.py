@@ -171,3 +171,25 @@ def test_io_primitives_round_trip(big_files):
         os.remove(out)
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("mode", ["plain", "chunks", "gpus2", "rccl1"])
+def test_unwritable_output_is_an_error_in_every_mode(workdir, mode):
+    """The reference writes through a NULL FILE* here (src/glistcompare.c:814-834) and crashes; the
+    tool reports the file it cannot create, exits 1, leaves no temporary behind -- and, with several
+    worker processes, nobody is left waiting at a barrier."""
+    env = {"plain": {}}
+    env.update(MODES)
+    before = set(os.listdir(workdir))
+    rc, out, err, files = _run_env(["A8.list", "B8.list", "-u", "-i", "-o", "no_such_dir/x"], workdir, env[mode])
+    assert rc == 1, (rc, err)
+    assert "Cannot create output file no_such_dir/x_8_union.list.tmp" in err
+    assert not files and set(os.listdir(workdir)) == before
+
+
+def test_three_workers_and_more_workers_than_records(workdir):
+    case = next(c for c in GPU_CASES if c["id"] == "edge_ragged")
+    for gpus in ("3", "7"):
+        _check(case, workdir, {"GT4HIP_GPUS": gpus})
+    tiny = next(c for c in GPU_CASES if c["id"] == "edge_empty_nonempty")
+    _check(tiny, workdir, {"GT4HIP_GPUS": "5"})
