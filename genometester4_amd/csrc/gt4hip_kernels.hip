@@ -1145,12 +1145,21 @@ static hipError_t launch_pair_merge_ops (hipStream_t s, int mode, int grid, cons
   const int fast = fast_variant (OPS, p);
   constexpr int F1 = 1, F2 = OPS == 1 ? 2 : 0, F3 = OPS == 1 ? 3 : 0;
 #define GT4_LAUNCH_MERGE(M, F) hipLaunchKernelGGL ((k_pair_merge<NT, merge_ipt (NT, OPS), M, OPS, F>), dim3 (grid), dim3 (NT), 0, s, A, nA, B, nB, (u64 *) part, num_tiles, p, o, desc, ctl)
-  if (OPS == 0 && fast == 1 && p.ops == 5u && (mode == MODE_COUNT ? NT == 512 : NT == 1024)) {
-    /* union + first complement (-u -d) with the default rules: the stream set is a compile-time constant */
-    constexpr int O5 = OPS == 0 ? 5 : 0;
-    if (mode == MODE_COUNT) hipLaunchKernelGGL ((k_pair_merge<NT, merge_ipt (NT, OPS), MODE_COUNT, OPS, 1, O5>), dim3 (grid), dim3 (NT), 0, s, A, nA, B, nB, (u64 *) part, num_tiles, p, o, desc, ctl);
-    else if (mode == MODE_LOOKBACK) hipLaunchKernelGGL ((k_pair_merge<NT, merge_ipt (NT, OPS), MODE_LOOKBACK, OPS, 1, O5>), dim3 (grid), dim3 (NT), 0, s, A, nA, B, nB, (u64 *) part, num_tiles, p, o, desc, ctl);
-    else hipLaunchKernelGGL ((k_pair_merge<NT, merge_ipt (NT, OPS), MODE_OFFSETS, OPS, 1, O5>), dim3 (grid), dim3 (NT), 0, s, A, nA, B, nB, (u64 *) part, num_tiles, p, o, desc, ctl);
+  if (OPS == 0 && fast == 1 && (p.ops == 3u || p.ops == 5u || p.ops == 15u) && (mode == MODE_COUNT ? NT == 512 : NT == 1024)) {
+    /* the commonest output sets with the default rules (-u -i, -u -d, all four): the stream set is a
+     * compile-time constant */
+#define GT4_LAUNCH_SET(M, SET) hipLaunchKernelGGL ((k_pair_merge<NT, merge_ipt (NT, OPS), M, OPS, 1, (OPS == 0 ? SET : 0)>), dim3 (grid), dim3 (NT), 0, s, A, nA, B, nB, (u64 *) part, num_tiles, p, o, desc, ctl)
+#define GT4_LAUNCH_SET_MODE(SET)                          \
+    do {                                                  \
+      if (mode == MODE_COUNT) GT4_LAUNCH_SET (MODE_COUNT, SET);          \
+      else if (mode == MODE_LOOKBACK) GT4_LAUNCH_SET (MODE_LOOKBACK, SET); \
+      else GT4_LAUNCH_SET (MODE_OFFSETS, SET);            \
+    } while (0)
+    if (p.ops == 3u) GT4_LAUNCH_SET_MODE (3);
+    else if (p.ops == 5u) GT4_LAUNCH_SET_MODE (5);
+    else GT4_LAUNCH_SET_MODE (15);
+#undef GT4_LAUNCH_SET_MODE
+#undef GT4_LAUNCH_SET
     return hipGetLastError ();
   }
   if (mode == MODE_COUNT) {
