@@ -35,6 +35,13 @@ gt4hip_context *gt4_hip_default_context (void)
   return g_ctx;
 }
 
+gt4hip_context *gt4_hip_set_default_context (gt4hip_context *ctx)
+{
+  gt4hip_context *const old = g_ctx;
+  g_ctx = ctx;
+  return old;
+}
+
 static GT4HipWordList *wrap_uploaded (gt4hip_context *ctx, gt4hip_list *dev, uint64_t n, unsigned int wl, uint64_t sum, int have_sum)
 {
   GT4HipWordList *l = (GT4HipWordList *) calloc (1, sizeof *l);

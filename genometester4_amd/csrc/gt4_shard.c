@@ -369,6 +369,7 @@ static int worker_main (const GT4ShardJob *job, Shared *sh, int rank)
   Worker *w = (Worker *) calloc (1, sizeof (Worker));
   if (!w) return 1;
   FILE *errf = stderr;
+  const double t_begin = now_s ();
   w->job = job;
   w->sh = sh;
   w->rank = rank;
@@ -432,6 +433,7 @@ static int worker_main (const GT4ShardJob *job, Shared *sh, int rank)
   }
 
   /* ---- the pipeline */
+  const double t_setup = now_s ();
   for (int slot = 0; slot < SLOTS; slot++) {
     sem_init (&w->slot_free[slot], 0, 1);
     sem_init (&w->slot_loaded[slot], 0, 0);
@@ -468,9 +470,10 @@ static int worker_main (const GT4ShardJob *job, Shared *sh, int rank)
     if (outs_pending[slot])
       for (int s = 0; s < 4; s++)
         if (w->out[slot][s]) gt4hip_list_free (w->out[slot][s]);
+  const double t_pipe = now_s ();
   if (job->debug)
-    fprintf (errf, "Worker %d: %u of %u chunks, load %.3f s, merge %.3f s, write %.3f s (threads overlap)\n", rank, w->n_mine, plan.n_chunks,
-             w->t_load, w->t_merge, w->t_write);
+    fprintf (errf, "Worker %d: %u of %u chunks, load %.3f s, merge %.3f s, write %.3f s (threads overlap); set-up %.3f s, pipeline %.3f s\n", rank,
+             w->n_mine, plan.n_chunks, w->t_load, w->t_merge, w->t_write, t_setup - t_begin, t_pipe - t_setup);
   if (w->comm) gt4hip_comm_destroy (w->comm);
   /* a worker that stopped early still marks its chunks so that nobody waits for them */
   if (stopped (w))
@@ -509,7 +512,9 @@ static int worker_main (const GT4ShardJob *job, Shared *sh, int rank)
       }
     }
   }
+  const double t_fin = now_s ();
   if (ctx) gt4hip_destroy (ctx);
+  if (job->debug) fprintf (errf, "Worker %d: headers and renames %.3f s, context teardown %.3f s\n", rank, t_fin - t_pipe, now_s () - t_fin);
   free (plan.cut);
   free (w);
   if (errf != stderr) fflush (errf);

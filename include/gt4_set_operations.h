@@ -26,6 +26,10 @@ typedef struct _GT4HipWordList GT4HipWordList;
 /* The device context every GT4HipWordList of this process lives in (created on first use on
  * device $GT4HIP_DEVICE, default 0).  NULL (and a message on stderr) when there is no GPU. */
 gt4hip_context *gt4_hip_default_context (void);
+/* Hosts that manage their own contexts (several GPUs, several threads) install the one the
+ * GT4HipWordList functions of the calling process shall use from now on; NULL forgets it (the
+ * previous one is not destroyed: whoever created it does that).  Returns the previous one. */
+gt4hip_context *gt4_hip_set_default_context (gt4hip_context *ctx);
 
 /* gt4_word_map_new (src/word-map.c:165-241) for the GPU path: map, validate, upload.  A GT4I index
  * file is accepted as the sorted k-mer list it contains (gt4_index_map_new, src/index-map.c:317-373).
