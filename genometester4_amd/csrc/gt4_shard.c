@@ -530,9 +530,8 @@ int gt4_shard_run (const GT4ShardJob *job, GT4ShardResult *res)
     fprintf (stderr, "Error: between 1 and %d GPUs can be used\n", MAX_RANKS);
     return 1;
   }
-  /* the number of chunks must be known before the shared block is sized: plan once here with the
-   * caller's limit when it is given; with the automatic limit worker 0 decides it, so reserve the
-   * largest plan the budget rule can produce */
+  /* the shared block: one record of totals per chunk, reserved for the largest plan the budget rule
+   * can produce (address space only: untouched pages cost nothing) */
   const size_t max_chunks = (size_t) 1 << 22;
   const size_t bytes = sizeof (Shared) + max_chunks * sizeof (ChunkTotals);
   Shared *sh = (Shared *) mmap (NULL, bytes, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
@@ -548,37 +547,29 @@ int gt4_shard_run (const GT4ShardJob *job, GT4ShardResult *res)
   }
   int rc = 0;
   if (G == 1 && !job->gather_rccl) {
-    /* the plan needs the budget, which needs the device: worker_main checks n_chunks against its own
-     * plan, so tell it to accept whatever it computes */
-    sh->n_chunks = 0;
-    /* single worker: plan inside, in this process */
+    /* one worker, in this process.  Every worker makes the plan itself from the same inputs and the
+     * same budget; the budget is the caller's, or 70 % of what the device has free right now. */
     GT4ShardJob j1 = *job;
-    /* (n_chunks is filled by a first planning pass below) */
-    {
-      /* budget without a device query when the caller gave one; else worker_main queries */
-      if (j1.hbm_limit) {
-        Plan p;
-        if (make_plan (&j1, j1.hbm_limit, &p)) return 1;
-        sh->n_chunks = p.n_chunks;
-        free (p.cut);
-      } else {
-        gt4hip_context *probe = NULL;
-        if (gt4hip_create (getenv ("GT4HIP_DEVICE") ? atoi (getenv ("GT4HIP_DEVICE")) : 0, &probe)) {
-          fprintf (stderr, "Error: %s\n", gt4hip_last_error (NULL));
-          munmap (sh, bytes);
-          return 1;
-        }
-        uint64_t free_b = 0, total_b = 0;
-        gt4hip_device_memory (probe, &free_b, &total_b);
-        gt4hip_destroy (probe);
-        j1.hbm_limit = free_b / 10 * 7;
-        if (!j1.hbm_limit) j1.hbm_limit = 1ull << 30;
-        Plan p;
-        if (make_plan (&j1, j1.hbm_limit, &p)) return 1;
-        sh->n_chunks = p.n_chunks;
-        free (p.cut);
+    if (!j1.hbm_limit) {
+      gt4hip_context *probe = NULL;
+      if (gt4hip_create (getenv ("GT4HIP_DEVICE") ? atoi (getenv ("GT4HIP_DEVICE")) : 0, &probe)) {
+        fprintf (stderr, "Error: %s\n", gt4hip_last_error (NULL));
+        munmap (sh, bytes);
+        return 1;
       }
+      uint64_t free_b = 0, total_b = 0;
+      gt4hip_device_memory (probe, &free_b, &total_b);
+      gt4hip_destroy (probe);
+      j1.hbm_limit = free_b / 10 * 7;
+      if (!j1.hbm_limit) j1.hbm_limit = 1ull << 30;
     }
+    Plan p;
+    if (make_plan (&j1, j1.hbm_limit, &p)) {
+      munmap (sh, bytes);
+      return 1;
+    }
+    sh->n_chunks = p.n_chunks;
+    free (p.cut);
     rc = worker_main (&j1, sh, 0);
   } else {
     /* several GPUs (or the RCCL path, whose library is kept out of the calling process): the budget
@@ -586,7 +577,10 @@ int gt4_shard_run (const GT4ShardJob *job, GT4ShardResult *res)
     GT4ShardJob jn = *job;
     if (!jn.hbm_limit) jn.hbm_limit = 128ull << 30; /* per worker; GT4HIP_HBM_LIMIT overrides */
     Plan p;
-    if (make_plan (&jn, jn.hbm_limit, &p)) return 1;
+    if (make_plan (&jn, jn.hbm_limit, &p)) {
+      munmap (sh, bytes);
+      return 1;
+    }
     sh->n_chunks = p.n_chunks;
     free (p.cut);
     fflush (stdout);
