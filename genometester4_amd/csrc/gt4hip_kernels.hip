@@ -612,8 +612,12 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
     const bool w_have = it >= LAG;
     const bool n_have = LAG > 1 && it >= LAG - 1;        /* written out next iteration */
     const u32 n_tile = tile_of_iter (it - (LAG - 1));
-    if (DEFER && w_have) {
-      write_out_tile<NT> (outs.rec[S0], uniform64 (sh.excl[S0]), w_tot, sh.stage[it % LAG], tid);
+#ifndef GT4_STAGGER_WRITEOUT
+#define GT4_STAGGER_WRITEOUT 0 /* experiment: the younger half of the wavefronts writes the old tile out BEHIND its ranking */
+#endif
+    const u64 w_excl = DEFER && w_have ? uniform64 (sh.excl[S0]) : 0;
+    if (DEFER && w_have && (!GT4_STAGGER_WRITEOUT || wid < NW / 2)) {
+      write_out_tile<NT> (outs.rec[S0], w_excl, w_tot, sh.stage[it % LAG], tid);
     }
     /* wave 4 asks now for the words the next write-out needs (row counts and row carry of the
      * tile in the next slot, published LAG - 1 iterations ago) and resolves them in phase 2 */
@@ -814,6 +818,7 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
       else x = desc[4 * (u64) pt + s];
       if (lane == 0) sh.excl[s] = x;
     }
+    if (GT4_STAGGER_WRITEOUT && DEFER && w_have && wid >= NW / 2) write_out_tile<NT> (outs.rec[S0], w_excl, w_tot, sh.stage[it % LAG], tid);
     PHASE_STAMP (3); /* phase 1 */
     __syncthreads (); /* B1: all input reads done */
     PHASE_STAMP (4); /* barrier B1 */
