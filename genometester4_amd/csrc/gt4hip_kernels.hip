@@ -409,6 +409,13 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
    * out during the NEXT tile (after its ranking), when their global offsets have long been published */
   constexpr bool GDEFER = (OPS == 0 || LATE1) && MODE != MODE_COUNT;
   constexpr int G = IPT % 3 == 0 ? 3 : 2; /* chunks searched together (four at a time is no faster for the union and spills the 85-register count kernels) */
+  /* staggered fetch: the first F_TOP of the NLOAD4 + 1 parts are issued at the top of the iteration,
+   * F_MID between the search groups, the rest behind the ranking.  Measured per kernel class (2 x 2e9
+   * records): union and intersection are fastest with one part at the top and one in the middle; the
+   * first complement with all whole parts at the top (16.1 -> 14.3 ms); the any-combination kernel,
+   * which also resolves its offsets behind the ranking, with everything at the top (29.8 -> 28.7 ms). */
+  constexpr int F_TOP = GDEFER ? NLOAD4 + 1 : (OPS == 4 ? NLOAD4 : 1);
+  constexpr int F_MID = (GDEFER || OPS == 4) ? 0 : 1;
   constexpr bool STAGGER = NT >= 1024;           /* spread the fetch over the iteration (measured: helps 16-wave workgroups only) */
   static_assert (NW >= 4, "one wavefront per output stream in phase 2");
   static_assert (NCH <= 2 * WAVE, "chunk scan is a single wavefront pass");
@@ -554,6 +561,10 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
   auto tile_of_iter = [&] (int j) -> u32 { return wk + (u32) j * n_workers; };
   u32 g_tot[4] = { 0, 0, 0, 0 }, g_off[4] = { 0, 0, 0, 0 }; /* GDEFER: the staged tile's records per stream and their staging offsets (records) */
   int it = 0;
+  /* DEFER: wavefront 4's look at the chain words of the tile the NEXT iteration writes out (its row's
+   * counts and row carry; two-pass path: its offset), carried over the back edge */
+  u32 dagg = 0;
+  u64 dcarry = 0;
 
   while (cur < ntl) {
     /* position space of the tile: A records at [0, na), B records from the next multiple of 64 on, so
@@ -578,6 +589,17 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
           *reinterpret_cast<u32x4 *> (lds32 + 4 * q) = straddle ? (pre[j] | pre_x) : pre[j];
         }
       }
+    }
+    if (DEFER && it >= LAG && wid == 4) {
+      /* global offset of the tile written out below, from the words asked for during the previous
+       * iteration: they came back with the prefetched records this wavefront has just waited for (the
+       * memory counter retires in order -- consuming them any earlier would have made this wavefront
+       * wait for its share of the prefetch in the middle of the iteration, and everybody else for it
+       * at the next barrier).  The previous write-out read sh.excl a whole iteration ago. */
+      u64 x = dcarry;
+      if (MODE == MODE_LOOKBACK)
+        x = resolve_offset (agg + (u64) S0 * n_rows * WAVE, carry + (u64) S0 * (n_rows + 1), tile_of_iter (it - LAG), lane, dagg, dcarry, ctl, spin_limit);
+      if (lane == 0) sh.excl[S0] = x;
     }
     PHASE_STAMP (0); /* phase 0: wait for the prefetched records, LDS writes */
     __syncthreads (); /* B0 */
@@ -619,15 +641,8 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
     if (DEFER && w_have && (!GT4_STAGGER_WRITEOUT || wid < NW / 2)) {
       write_out_tile<NT> (outs.rec[S0], w_excl, w_tot, sh.stage[it % LAG], tid);
     }
-    /* wave 4 asks now for the words the next write-out needs (row counts and row carry of the
-     * tile in the next slot, published LAG - 1 iterations ago) and resolves them in phase 2 */
     u32 xagg = 0;
     u64 xcarry = 0;
-    if (DEFER && MODE == MODE_LOOKBACK && n_have && wid == 4) {
-      const u64 prow = n_tile / WAVE;
-      if ((u32) lane < n_tile % WAVE) xagg = peek_u32 (&agg[(u64) S0 * n_rows * WAVE + prow * WAVE + lane]);
-      xcarry = peek_u64 (&carry[(u64) S0 * (n_rows + 1) + prow]);
-    }
     if (GDEFER && MODE == MODE_LOOKBACK && it >= 1 && wid >= 4 && wid < 8 && ((ops >> (wid - 4)) & 1u)) {
       /* wavefront 4 + s asks for the words stream s of the previous tile needs (published during
        * the previous iteration) and resolves them behind its own ranking, before B1 */
@@ -639,8 +654,10 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
     }
     /* in flight until the next iteration's phase 0; the large geometry staggers the parts */
     if (nxt < ntl) {
-      if (STAGGER) fetch_part (tn, 0);
-      else fetch (tn);
+      if (STAGGER) {
+#pragma unroll
+        for (int j = 0; j < F_TOP; j++) fetch_part (tn, j);
+      } else fetch (tn);
     }
 
     PHASE_STAMP (2); /* ring read, housekeeping issue, fetch issue */
@@ -653,7 +670,10 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
       static_assert (IPT % G == 0, "chunks are searched in groups");
 #pragma unroll
       for (int kk = 0; kk < IPT; kk += G) {
-        if (STAGGER && kk == G && nxt < ntl) fetch_part (tn, 1); /* staggered fetch: see fetch_part */
+        if (STAGGER && kk == G && nxt < ntl) {
+#pragma unroll
+          for (int j = F_TOP; j < F_TOP + F_MID; j++) fetch_part (tn, j);
+        } /* staggered fetch: see fetch_part */
         bool live[G], valid[G], any_live = false;
         u32 is_a[G], own[G], lim[G], lo[G]; /* is_a: wave-uniform (chunks never mix the lists); lim, lo: bytes (12 per record) */
         u32 sbase[G], sn[G];                /* wave-uniform: dword base and length of the run this chunk is ranked in */
@@ -797,19 +817,9 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
       else if (OPS == 1) asm volatile ("" : "+v"(fa[k]), "+v"(meta[k]));
       else asm volatile ("" : "+v"(fa[k]));
     }
-    if (STAGGER && nxt < ntl) {
-      if (G == IPT) fetch_part (tn, 1); /* a single search group: no second group to issue it under */
-#pragma unroll
-      for (int j = 2; j <= NLOAD4; j++) fetch_part (tn, j);
-    }
-    if (DEFER && MODE == MODE_LOOKBACK && n_have && wid == 4) {
-      /* second look, behind the ranking, at the words that were not yet published at the top of
-       * the iteration: they arrive during phase 2 and the staging, so the resolve below rarely
-       * has to wait for a round trip */
-      const u64 prow = n_tile / WAVE;
-      if ((u32) lane < n_tile % WAVE && !(xagg & AGG_READY)) xagg = peek_u32 (&agg[(u64) S0 * n_rows * WAVE + prow * WAVE + lane]);
-      if (!(xcarry & CARRY_READY)) xcarry = peek_u64 (&carry[(u64) S0 * (n_rows + 1) + prow]);
-    }
+    /* any-combination kernel: resolved BEFORE the rest of the fetch is issued -- the memory counter
+     * retires in order, so looking at the words asked for at the top of the iteration waits for every
+     * load issued before this point: only the two parts issued at the top with them */
     if (GDEFER && it >= 1 && wid >= 4 && wid < 8 && ((ops >> (wid - 4)) & 1u)) {
       const int s = wid - 4;
       const u32 pt = tile_of_iter (it - 1);
@@ -817,6 +827,23 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
       if (MODE == MODE_LOOKBACK) x = resolve_offset (agg + (u64) s * n_rows * WAVE, carry + (u64) s * (n_rows + 1), pt, lane, xagg, xcarry, ctl, spin_limit);
       else x = desc[4 * (u64) pt + s];
       if (lane == 0) sh.excl[s] = x;
+    }
+    if (STAGGER && nxt < ntl) {
+#pragma unroll
+      for (int j = (G == IPT ? F_TOP : F_TOP + F_MID); j <= NLOAD4; j++) fetch_part (tn, j); /* (a single search group has no middle) */
+    }
+    if (DEFER && n_have && wid == 4) {
+      /* wavefront 4 asks for the words the next iteration's write-out needs (row counts and row carry
+       * of the tile staged LAG - 1 iterations ago, published then) and does NOT look at them before
+       * the next phase 0: issued behind the fetch, they cost no wait of their own */
+      if (MODE == MODE_LOOKBACK) {
+        const u64 prow = n_tile / WAVE;
+        dagg = 0;
+        if ((u32) lane < n_tile % WAVE) dagg = peek_u32 (&agg[(u64) S0 * n_rows * WAVE + prow * WAVE + lane]);
+        dcarry = peek_u64 (&carry[(u64) S0 * (n_rows + 1) + prow]);
+      } else {
+        dcarry = __hip_atomic_load (&desc[4 * (u64) n_tile + S0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
     if (GT4_STAGGER_WRITEOUT && DEFER && w_have && wid >= NW / 2) write_out_tile<NT> (outs.rec[S0], w_excl, w_tot, sh.stage[it % LAG], tid);
     PHASE_STAMP (3); /* phase 1 */
@@ -884,14 +911,6 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
 #pragma unroll
       for (int q = 0; q + 1 < LAG; q++) pend_tot[q] = pend_tot[q + 1];
       pend_tot[LAG - 1] = my_tot;
-      if (n_have && wid == 4) {
-        /* global offset of the tile the next iteration writes out (this iteration's write-out,
-         * which read sh.excl, finished before B1) */
-        u64 x;
-        if (MODE == MODE_LOOKBACK) x = resolve_offset (agg + (u64) S0 * n_rows * WAVE, carry + (u64) S0 * (n_rows + 1), n_tile, lane, xagg, xcarry, ctl, spin_limit);
-        else x = desc[4 * (u64) n_tile + S0];
-        if (lane == 0) sh.excl[S0] = x;
-      }
     }
     PHASE_STAMP (6); /* (any-combination kernel: previous tile's write-out, B2) staging scatter */
     if (tid == 0) {
