@@ -91,6 +91,15 @@ if fetch and write:
                   "correction of MI355X_MICROARCH.md (HBM section); WRITE_SIZE as is",
         "source": ["profiles/%s/" % ROUND + os.path.basename(fpath), "profiles/%s/" % ROUND + os.path.basename(wpath)],
     }
+    if workload == "union8":
+        # 7 pair merges per union: count the unions of the pass from the launches themselves
+        launches = sum(len(fetch[k]) for k in cand)
+        unions = max(1, launches // 7)
+        tj["unions_per_pmc_pass"] = unions
+        tj["merge_kernels_hbm_bytes_per_union"] = (all_f + all_w) / unions
+        tj["note"] = ("7 pair merges per 8-way union (4 + 2 raw levels, 1 final); hbm_bytes_per_launch is the average launch of "
+                      "the dominant instantiation only; the bench runs every step twice (with and without the gather), so a "
+                      "PMC pass of --steps 2 --warmup 1 holds more unions than steps")
     with open(os.path.join(dst, "traffic_%s.json" % workload), "w") as f:
         json.dump(tj, f, indent=1)
     print(json.dumps(tj))
