@@ -626,8 +626,8 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
         for (int i = 0; i < 4; i++) hk_rng[i] = __hip_atomic_load (&part[2 * (u64) tnn + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
-    /* DEFER: write out the tile staged LAG iterations ago (its offset was resolved during phase 2
-     * of the previous iteration) BEFORE the next fetch is issued: the memory counter retires in
+    /* DEFER: write out the tile staged LAG iterations ago (its offset was resolved in phase 0,
+     * just above) BEFORE the next fetch is issued: the memory counter retires in
      * order, so the wait for the fetched records at the next phase 0 then only ever waits on
      * stores that are a whole iteration old */
     const u32 w_tot = pend_tot[0];                       /* written out now */
@@ -645,7 +645,7 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
     u64 xcarry = 0;
     if (GDEFER && MODE == MODE_LOOKBACK && it >= 1 && wid >= 4 && wid < 8 && ((ops >> (wid - 4)) & 1u)) {
       /* wavefront 4 + s asks for the words stream s of the previous tile needs (published during
-       * the previous iteration) and resolves them behind its own ranking, before B1 */
+       * the previous iteration) and resolves them behind its own ranking, before the late fetch parts and B1 */
       const int s = wid - 4;
       const u32 pt = tile_of_iter (it - 1);
       const u64 prow = pt / WAVE;
