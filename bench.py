@@ -293,9 +293,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if os.environ.get("GT4_BENCH_ONE_DEVICE"):
+        # test hook: run the N-rank control flow with every rank on device 0 (RCCL refuses two ranks
+        # on one device, so the barrier / reductions go over gloo); never set by the driver
+        local_rank = 0
+        torch.cuda.set_device(0)
+        if world > 1:
+            dist.init_process_group("gloo")
+    else:
+        torch.cuda.set_device(local_rank)
+        if world > 1:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from genometester4_amd import capi
     ctx = capi.Context(local_rank)
@@ -367,11 +375,11 @@ def main():
         names = {1: "union", 2: "intrsec", 4: "diff1"}
         if args.workload == "intersect":
             metric = "k-mers merged/sec, 2-list k=%d intersection (glistcompare -i), lists resident in HBM" % args.k
-            wl = "single-GPU intersection, two %d-entry k=%d lists (%.1f GB each) per GPU, |A n B| = n/2" % (n, args.k, 12 * n / 1e9)
+            wl = ("single-GPU" if world == 1 else "%d independent key-range shards, one per GPU:" % world) + " intersection, two %d-entry k=%d lists (%.1f GB each) per GPU, |A n B| = n/2" % (n, args.k, 12 * n / 1e9)
             kernel = "k_pair_merge<1024, 6, MODE_LOOKBACK, intersection, folded MIN>"
         else:
             metric = "k-mers merged/sec, 2-list k=%d union + first complement, cutoff %d (glistcompare -u -d -c %d), lists resident in HBM" % (args.k, cutoff, cutoff)
-            wl = "single-GPU union + difference_first with --cutoff %d, two %d-entry k=%d lists (%.1f GB each) per GPU, |A n B| = n/2" % (cutoff, n, args.k, 12 * n / 1e9)
+            wl = ("single-GPU" if world == 1 else "%d independent key-range shards, one per GPU:" % world) + " union + difference_first with --cutoff %d, two %d-entry k=%d lists (%.1f GB each) per GPU, |A n B| = n/2" % (cutoff, n, args.k, 12 * n / 1e9)
             kernel = "k_pair_merge<1024, 4, MODE_LOOKBACK, any combination of outputs, default rules>"
         res = {
             "metric": metric,
