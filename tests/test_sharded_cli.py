@@ -193,3 +193,24 @@ def test_three_workers_and_more_workers_than_records(workdir):
         _check(case, workdir, {"GT4HIP_GPUS": gpus})
     tiny = next(c for c in GPU_CASES if c["id"] == "edge_empty_nonempty")
     _check(tiny, workdir, {"GT4HIP_GPUS": "5"})
+
+
+def test_two_rccl_ranks_on_one_device_fail_cleanly(workdir):
+    """RCCL refuses two ranks on one device.  On a one-GPU box that makes `--gpus 2` with the RCCL gather
+    the one multi-rank communicator set-up that can be driven here: both worker processes get the
+    unique id through the shared block and reach ncclCommInitRank, which reports the duplicate device --
+    the tool must say so, exit 1 within seconds (nobody left waiting for the other) and leave no
+    temporary behind.  (With two or more GPUs the same command succeeds and is covered by _check.)"""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    n = ctypes.c_int(0)
+    assert hip.hipGetDeviceCount(ctypes.byref(n)) == 0
+    env = {"GT4HIP_GPUS": "2", "GT4HIP_GATHER": "rccl", "GT4HIP_HBM_LIMIT": "64K", "NCCL_DEBUG": "NONE"}
+    if n.value >= 2:
+        _check(next(c for c in GPU_CASES if c["id"] == "edge_ragged"), workdir, env)
+        return
+    before = set(os.listdir(workdir))
+    rc, out, err, files = _run_env(["A8.list", "B8.list", "-u", "-o", "dup"], workdir, env)
+    assert rc == 1, (rc, err)
+    assert "ncclCommInitRank" in err
+    assert not files and set(os.listdir(workdir)) == before
