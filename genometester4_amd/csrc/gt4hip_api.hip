@@ -85,6 +85,10 @@ extern "C" int gt4hip_create (int device, gt4hip_context **out)
   }
   ctx->n_cus = prop.multiProcessorCount;
   ctx->pool_cap = prop.totalGlobalMem / 2;
+  {
+    const char *e = getenv ("GT4HIP_DYNAMIC"); /* diagnostic: the whole test-suite through the other dealing */
+    ctx->dynamic = e ? atoi (e) : 0; /* 0: automatic */
+  }
   ctx->kway_enabled = 0; /* measured slower than the pairwise tree (DESIGN.md, N-way): option "kway" = 1 selects it */
   snprintf (ctx->info, sizeof ctx->info, "%s|%s|%d|%zu", prop.name, prop.gcnArchName, prop.multiProcessorCount, prop.totalGlobalMem);
   if ((e = hipStreamCreateWithFlags (&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
@@ -158,6 +162,7 @@ extern "C" int gt4hip_set_option (gt4hip_context *ctx, const char *name, int64_t
   }
   else if (!strcmp (name, "grid")) ctx->grid_override = value;
   else if (!strcmp (name, "scan_group")) ctx->scan_group = (int) value;
+  else if (!strcmp (name, "dynamic")) ctx->dynamic = (int) value;
   else if (!strcmp (name, "kway")) ctx->kway_enabled = value != 0;
   else if (!strcmp (name, "kway_g")) ctx->kway_g = value;
   else if (!strcmp (name, "kway_vt")) ctx->kway_vt = value;
@@ -549,6 +554,13 @@ static int run_pair (gt4hip_context *ctx, const uint32_t *A, uint64_t nA, const 
   /* the scanner as a group of wavefronts pays off where one wavefront cannot keep up (more than ~2e4
    * rows of 64 tiles per launch: the small geometry on billions of records); below that the single
    * wavefront's shorter path to the carry is worth more (option "scan_group": -1 never, 1 always) */
+  /* tiles by ticket (dynamic dealing) for the record-writing single-pass kernels of the large
+   * geometry: their ~40 tiles per microsecond are well below the ~88 returning atomics per microsecond
+   * one counter sustains (the count-only geometry's 200+ are not: 8.7 -> 23.8 ms), and arrival order
+   * spares the fast workers the wait for the slow ones in the chained scan (measured at 2 x 2e9:
+   * intersection 12.75 -> 12.55 ms, union 21.7 -> 21.45, union + intersection 27.05 -> 26.25; the first
+   * complement alone is 2 % SLOWER and stays round-robin).  Option "dynamic": 1 always, -1 never. */
+  p.dynamic = ctx->dynamic > 0 ? 1u : (ctx->dynamic < 0 ? 0u : ((geom == 1 && !count_only && p.ops != 4u && p.ops != 8u) ? 1u : 0u));
   p.scan_group = ctx->scan_group > 0 ? 1u : (ctx->scan_group < 0 ? 0u : (tiles > (20000ull << 6) ? 1u : 0u));
   int rc;
   if ((rc = grow (ctx, (void **) &ctx->part, &ctx->part_bytes, (size_t) (tiles + 1) * 16 + (size_t) (tiles / 64 + 3) * 8))) return rc; /* tile ranges + coarse co-ranks */

@@ -20,6 +20,7 @@ struct gt4hip_context {
   int two_pass;
   int64_t grid_override;
   uint32_t spin_limit;       /* option "spin_limit": bound of the single-pass kernel's waits (0 = default) */
+  int dynamic;     /* option "dynamic": tiles of the single-pass kernels dealt by a ticket counter: 0 automatic, 1 always, -1 never (round-robin) */
   int scan_group;  /* option "scan_group": 0 automatic, 1 always the scanner group, -1 always one wavefront per stream */
   int force_geom; /* options "geom1" / "geom0": force the large / small geometry for every call (experiments); 0 = automatic */
   uint64_t single_pass_fallbacks; /* calls that had to be rerun on the two-pass path */

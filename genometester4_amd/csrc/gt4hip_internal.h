@@ -28,6 +28,7 @@ struct PairParams {
   uint32_t filter;
   uint32_t spin_limit;     /* bound of every inter-workgroup wait (0: the default, ~seconds); tests set it low */
   uint32_t scan_group;     /* 0: one scanner wavefront per stream; 1: summers + chainer (launches with many rows) */
+  uint32_t dynamic;        /* 0: tiles dealt round-robin; 1: by a ticket counter (ctl->ticket), three tiles ahead */
 };
 
 struct PairOutputs {
@@ -38,7 +39,7 @@ struct PairOutputs {
 struct PairControl {
   unsigned long long n_words[4];
   unsigned long long total_count[4];
-  unsigned int pad0;
+  unsigned int ticket;     /* dynamic dealing: next tile */
   unsigned int error;      /* non-zero: a bounded spin gave up / consistency check tripped */
   unsigned int role;       /* first workgroup to arrive becomes the scanner */
   unsigned int pad;

@@ -253,6 +253,7 @@ struct RankShared {
   u32 tot[4];             /* records the current tile keeps, per stream                                */
   u32 tick[3];            /* [0]: role election scratch (tile ids themselves are arithmetic: static dealing)      */
   u64 rng[3][4];          /* their record ranges {a0, b0, a1, b1} (part[] entries), fetched ahead        */
+  u32 tile_id[3];         /* and their tile numbers (0xffffffff: none)                                    */
 };
 
 /* number of kept records among the concatenated tile positions [0, z) */
@@ -467,16 +468,20 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
   u64 acc_sum0 = 0, acc_sum1 = 0, acc_sum2 = 0, acc_sum3 = 0; /* per-thread sums of kept counts */
   u64 blk_cnt = 0;                                              /* lane 0 of wave s: records kept in stream s */
 
-  /* Tiles are dealt round-robin: worker w processes tiles w, w + W, w + 2W, ...  (A shared ticket
-   * counter saturates near 88 returning atomics per microsecond -- MI355X_MICROARCH.md, row
-   * dequeue -- which capped the whole kernel; counters sharded by worker class drift apart;
-   * claiming tiles in groups puts a group's last tile behind the next group's write-out.)  With
-   * the scanner this needs every worker resident, which the host guarantees by sizing the grid
-   * from the kernel's occupancy; worker ids come from arrival order, and every spin is bounded,
-   * so a non-resident worker shows up as an error flag (the host then reruns the call on the
-   * two-pass path), never as a hang.
-   * A three-deep ring keeps every dependent global round trip off the critical path: while tile i
-   * is processed, the records of tile i+1 are in flight and the range of tile i+2 is being read. */
+  /* Two ways of dealing tiles, chosen by the host per launch (p.dynamic).
+   * Round-robin: worker w processes tiles w, w + W, w + 2W, ...  With the scanner this needs every
+   * worker resident, which the host guarantees by sizing the grid from the kernel's occupancy;
+   * worker ids come from arrival order, and every spin is bounded, so a non-resident worker shows up
+   * as an error flag (the host then reruns the call on the two-pass path), never as a hang.
+   * By ticket: one returning atomic per tile on a shared counter.  It saturates near 88 atomics per
+   * microsecond (MI355X_MICROARCH.md, row dequeue), which caps the small geometry's 200+ tiles per
+   * microsecond but not the ~40 of the kernels that write records; there arrival order means that
+   * no worker ever waits for a tile of a slower one that it could have taken itself.  (Counters
+   * sharded by worker class drift apart; claiming tiles in groups puts a group's last tile behind
+   * the next group's write-out.)
+   * Either way a three-deep ring keeps every dependent global round trip off the critical path:
+   * while tile i is processed, the records of tile i+1 are in flight, the range of tile i+2 is
+   * being read, and (by ticket) the number of tile i+3 is being drawn. */
   const u32 n_workers = MODE == MODE_LOOKBACK ? gridDim.x - 1 : gridDim.x;
   const u32 wk = MODE == MODE_LOOKBACK ? role - 1 : blockIdx.x;
   const u32 ntl = (u32) num_tiles; /* the host refuses calls with 2^32 - 1 tiles or more */
@@ -485,15 +490,28 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
     const u64 t = (u64) wk + (u64) j * n_workers;
     return t < num_tiles ? (u32) t : 0xffffffffu;
   };
+  /* dynamic dealing (p.dynamic): tiles are handed out by one returning atomic per tile, taken three
+   * iterations ahead of the tile's processing (its round trip is never waited for); tile order then
+   * follows arrival order, so a worker that is slow -- for a moment or for the whole launch -- takes
+   * fewer tiles instead of making everybody behind it in the chained scan wait */
+  auto deal = [&] (int j) -> u32 {
+    if (MODE != MODE_LOOKBACK || !p.dynamic) return tile_at (j); /* the two-pass path's kernels stay round-robin */
+    const u32 t = atomicAdd (&ctl->ticket, 1u);
+    return t < ntl ? t : 0xffffffffu;
+  };
+  u32 tk_next = 0xffffffffu; /* thread 0: the tile of iteration it + 2 */
   if (tid == 0) {
+    u32 t3[3];
+    for (int q = 0; q < 3; q++) t3[q] = deal (q);
     for (int q = 0; q < 2; q++) {
-      const u32 t = tile_at (q);
-      if (t < ntl)
-        for (int i = 0; i < 4; i++) sh.rng[q][i] = part[2 * (u64) t + i];
+      sh.tile_id[q] = t3[q];
+      if (t3[q] < ntl)
+        for (int i = 0; i < 4; i++) sh.rng[q][i] = part[2 * (u64) t3[q] + i];
     }
+    tk_next = t3[2];
   }
   __syncthreads ();
-  u32 cur = tile_at (0);
+  u32 cur = uniform32 (sh.tile_id[0]);
   TileRange tr = { 0, 0, 0, 0 };
   if (cur < ntl) {
     tr.a0 = uniform64 (sh.rng[0][0]);
@@ -549,16 +567,17 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
   u64 t_last;
   asm volatile ("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_last) :: "memory");
 #endif
-  /* DEFER: the LAG tiles whose output is staged in LDS but not yet written.  Tiles are dealt
-   * statically, so the tile staged j iterations ago is known (tile_of_iter); only its record count
-   * has to be remembered: a queue shifted once per iteration with static indices only (entry 0 =
+  /* DEFER: the LAG tiles whose output is staged in LDS but not yet written: their numbers (past[])
+   * and record counts are remembered: a queue shifted once per iteration with static indices only (entry 0 =
    * oldest = staged LAG iterations ago, in slot it % LAG) -- indexing it by it % LAG instead turns
    * the array into scratch memory, which cost a second copy of the output in HBM traffic. */
   constexpr int LAG = Shared::STAGE_SLOTS;
   u32 pend_tot[LAG];
 #pragma unroll
   for (int q = 0; q < LAG; q++) pend_tot[q] = 0;
-  auto tile_of_iter = [&] (int j) -> u32 { return wk + (u32) j * n_workers; };
+  u32 past[LAG]; /* the tiles of the last LAG iterations, oldest first (wave-uniform) */
+#pragma unroll
+  for (int q = 0; q < LAG; q++) past[q] = 0;
   u32 g_tot[4] = { 0, 0, 0, 0 }, g_off[4] = { 0, 0, 0, 0 }; /* GDEFER: the staged tile's records per stream and their staging offsets (records) */
   int it = 0;
   /* DEFER: wavefront 4's look at the chain words of the tile the NEXT iteration writes out (its row's
@@ -602,14 +621,14 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
        * at the next barrier).  The previous write-out read sh.excl a whole iteration ago. */
       u64 x = dcarry;
       if (MODE == MODE_LOOKBACK)
-        x = resolve_offset (agg + (u64) S0 * n_rows * WAVE, carry + (u64) S0 * (n_rows + 1), tile_of_iter (it - LAG), lane, dagg, dcarry, ctl, spin_limit);
+        x = resolve_offset (agg + (u64) S0 * n_rows * WAVE, carry + (u64) S0 * (n_rows + 1), past[0], lane, dagg, dcarry, ctl, spin_limit);
       if (lane == 0) sh.excl[S0] = x;
     }
     PHASE_STAMP (0); /* phase 0: wait for the prefetched records, LDS writes */
     __syncthreads (); /* B0 */
     PHASE_STAMP (1); /* barrier B0 */
     const int s_nxt = (it + 1) % 3, s_nn = (it + 2) % 3;
-    const u32 nxt = tile_at (it + 1);
+    const u32 nxt = uniform32 (sh.tile_id[s_nxt]);
     TileRange tn = { 0, 0, 0, 0 };
     if (nxt < ntl) {
       tn.a0 = uniform64 (sh.rng[s_nxt][0]);
@@ -620,8 +639,11 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
     /* housekeeping by thread 0, results consumed at the end of this iteration */
     u64 hk_rng[4] = { 0, 0, 0, 0 };
     bool hk_have_rng = false;
+    u32 hk_tile = 0xffffffffu;
     if (tid == 0) {
-      const u32 tnn = tile_at (it + 2);
+      hk_tile = tk_next;
+      tk_next = deal (it + 3);
+      const u32 tnn = hk_tile;
       if (tnn < ntl) {
         hk_have_rng = true;
 #pragma unroll
@@ -637,7 +659,7 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
     const u32 w_tot = pend_tot[0];                       /* written out now */
     const bool w_have = it >= LAG;
     const bool n_have = LAG > 1 && it >= LAG - 1;        /* written out next iteration */
-    const u32 n_tile = tile_of_iter (it - (LAG - 1));
+    const u32 n_tile = past[LAG > 1 ? 1 : 0];
 #ifndef GT4_STAGGER_WRITEOUT
 #define GT4_STAGGER_WRITEOUT 0 /* experiment: the younger half of the wavefronts writes the old tile out BEHIND its ranking */
 #endif
@@ -651,7 +673,7 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
       /* wavefront 4 + s asks for the words stream s of the previous tile needs (published during
        * the previous iteration) and resolves them behind its own ranking, before the late fetch parts and B1 */
       const int s = wid - 4;
-      const u32 pt = tile_of_iter (it - 1);
+      const u32 pt = past[LAG - 1];
       const u64 prow = pt / WAVE;
       if ((u32) lane < pt % WAVE) xagg = peek_u32 (&agg[(u64) s * n_rows * WAVE + prow * WAVE + lane]);
       xcarry = peek_u64 (&carry[(u64) s * (n_rows + 1) + prow]);
@@ -826,7 +848,7 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
      * load issued before this point: only the two parts issued at the top with them */
     if (GDEFER && it >= 1 && wid >= 4 && wid < 8 && ((ops >> (wid - 4)) & 1u)) {
       const int s = wid - 4;
-      const u32 pt = tile_of_iter (it - 1);
+      const u32 pt = past[LAG - 1];
       u64 x;
       if (MODE == MODE_LOOKBACK) x = resolve_offset (agg + (u64) s * n_rows * WAVE, carry + (u64) s * (n_rows + 1), pt, lane, xagg, xcarry, ctl, spin_limit);
       else x = desc[4 * (u64) pt + s];
@@ -918,11 +940,15 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
     }
     PHASE_STAMP (6); /* (any-combination kernel: previous tile's write-out, B2) staging scatter */
     if (tid == 0) {
+      sh.tile_id[s_nn] = hk_tile;
       if (hk_have_rng) {
 #pragma unroll
         for (int i = 0; i < 4; i++) sh.rng[s_nn][i] = hk_rng[i];
       }
     }
+#pragma unroll
+    for (int q = 0; q + 1 < LAG; q++) past[q] = past[q + 1];
+    past[LAG - 1] = cur;
     PHASE_STAMP (7); /* housekeeping results */
     cur = nxt;
     tr = tn;
@@ -935,7 +961,7 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
 
   if (GDEFER && it >= 1) {
     /* drain: the last tile's streams are still staged */
-    const u32 pt = tile_of_iter (it - 1);
+    const u32 pt = past[LAG - 1];
     __syncthreads ();
     if (wid < 4 && ((ops >> wid) & 1u)) {
       const int s = wid;
@@ -954,7 +980,7 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
 #pragma unroll
     for (int q = 0; q < LAG; q++) {
       if (it - LAG + q < 0) continue;
-      const u32 tile = tile_of_iter (it - LAG + q);
+      const u32 tile = past[q];
       const u32 tot = pend_tot[q];
       __syncthreads ();
       if (wid == 0) {

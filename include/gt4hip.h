@@ -297,6 +297,9 @@ int gt4hip_synchronize (gt4hip_context *ctx);
  *   "kway" = 1         N-way unions by the one-pass tile kernel (gt4hip_kway.hip) instead of the
  *                      pairwise tree; "kway_g" / "kway_vt": its samples per tile / positions per thread
  *   "spin_limit" = n   bound of the single-pass kernel's inter-workgroup waits (0: default, ~seconds)
+ *   "dynamic" = 1 / -1 tiles of the single-pass kernel always / never dealt by a ticket counter
+ *                      (0: automatic -- the record-writing kernels except a complement alone)
+ *   "scan_group" = 1 / -1  the scanner as a group of wavefronts always / never (0: by launch size)
  *   "geom0" / "geom1"  force the 512- / 1024-thread geometry (experiments). */
 int gt4hip_set_option (gt4hip_context *ctx, const char *name, int64_t value);
 /* Diagnostic counters of a context.  "single_pass_fallbacks": calls whose single-pass merge gave up a

@@ -295,6 +295,7 @@ def test_single_pass_gives_up_and_falls_back(ctx):
     before = ctx.get_counter("single_pass_fallbacks")
     ctx.set_option("grid", 2048)
     ctx.set_option("spin_limit", 3)
+    ctx.set_option("dynamic", -1)  # round-robin dealing: tiles of workgroups that are not resident
     try:
         for ops in (2, 1, 15):
             st, out, _ = ctx.compare(da, db, ops)
@@ -305,6 +306,7 @@ def test_single_pass_gives_up_and_falls_back(ctx):
     finally:
         ctx.set_option("grid", 0)
         ctx.set_option("spin_limit", 0)
+        ctx.set_option("dynamic", 0)
     assert ctx.get_counter("single_pass_fallbacks") > before
 
 
@@ -319,17 +321,50 @@ def test_fallback_with_default_spin_limit_is_fast(ctx):
     da, db = ctx.upload(a, 24), ctx.upload(b, 24)
     before = ctx.get_counter("single_pass_fallbacks")
     ctx.set_option("grid", 1024)
+    ctx.set_option("dynamic", -1)
     try:
         t0 = time.perf_counter()
         st, out, _ = ctx.compare(da, db, 3)
         elapsed = time.perf_counter() - t0
     finally:
         ctx.set_option("grid", 0)
+        ctx.set_option("dynamic", 0)
     assert ctx.get_counter("single_pass_fallbacks") > before
     assert elapsed < 60.0, "fallback took %.1f s" % elapsed
     for bit in (1, 2):
         assert st[bit] == exp[bit][:2]
         assert out[bit].download().tobytes() == exp[bit][2].tobytes()
+
+
+@pytest.mark.parametrize("ops", [1, 2, 3, 5, 15])
+def test_tiles_by_ticket_need_no_resident_grid(ctx, ops):
+    """Dynamic dealing: tiles go to the workgroups that are running, in arrival order, so four times
+    the resident grid finishes on the single-pass path (no fallback) with the oracle's bytes; the
+    same sizes round-robin and by ticket give identical outputs."""
+    a, b = U.random_pair(21 + ops, 2_500_000, 0.55, 0.45, k=23)
+    exp = O.compare(a, b, ops, cutoff=2)
+    da, db = ctx.upload(a, 23), ctx.upload(b, 23)
+    before = ctx.get_counter("single_pass_fallbacks")
+    ctx.set_option("grid", 1024)
+    ctx.set_option("dynamic", 1)
+    try:
+        st, out, _ = ctx.compare(da, db, ops, cutoff=2)
+    finally:
+        ctx.set_option("grid", 0)
+        ctx.set_option("dynamic", 0)
+    assert ctx.get_counter("single_pass_fallbacks") == before
+    for bit, (n, total, recs) in exp.items():
+        assert st[bit] == (n, total)
+        assert out[bit].download().tobytes() == recs.tobytes()
+    for dyn in (-1, 1):
+        ctx.set_option("dynamic", dyn)
+        try:
+            st2, out2, _ = ctx.compare(da, db, ops, cutoff=2)
+        finally:
+            ctx.set_option("dynamic", 0)
+        assert st2 == st
+        for bit in exp:
+            assert out2[bit].download().tobytes() == exp[bit][2].tobytes()
 
 
 @pytest.mark.parametrize("rule", range(8))

@@ -9,7 +9,7 @@ from bench import build_lists
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 500_000_000
 ctx = capi.Context(0)
-for opt in ("geom0", "geom1", "grid", "scan_group"):
+for opt in ("geom0", "geom1", "grid", "scan_group", "dynamic"):
     if os.environ.get("GT4_" + opt.upper()):
         ctx.set_option(opt, int(os.environ["GT4_" + opt.upper()]))
 a, b = build_lists(ctx, capi, n, 25, 0)
