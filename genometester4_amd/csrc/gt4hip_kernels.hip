@@ -313,60 +313,73 @@ __device__ __forceinline__ void rank_group (const u32 *lds32, const u32 (&sbase)
     const u32 *const q = reinterpret_cast<const u32 *> (reinterpret_cast<const char *> (lds32) + byte_off);
     return (u64) q[0] | ((u64) q[1] << 32);
   };
-  u32 q4[G], at[G];
-#pragma unroll
-  for (int u = 0; u < G; u++) {
-    const u32 n = sn[u];
-    const u32 half = n ? 1u << (31 - __builtin_clz (n)) : 0u; /* P/2 = the largest power of two <= n */
-    q4[u] = half >> 1;
-    const u32 i0 = n - half;
-    const u32 inc = n ? 12u * (i0 + 1u) : 0u;
-    const u64 pv = key_at (4u * sbase[u] + 12u * i0);
-    at[u] = 4u * sbase[u] + (pv < ky[u] ? inc : 0u);
-  }
   constexpr u32 HTOP = (CAP & (CAP - 1)) ? (1u << (31 - __builtin_clz ((unsigned) CAP))) / 2 : CAP / 4; /* P/4 of the longest run */
-#pragma unroll
-  for (u32 h = HTOP; h > 64; h >>= 1) {
-    bool any = false; /* wave-uniform */
-#pragma unroll
-    for (int u = 0; u < G; u++) any |= h <= q4[u];
-    if (!any) continue;
+  u32 at[G];
+  /* one probe step of all G searches with the compile-time stride h */
+  auto step = [&] (u32 h) {
     u64 pv[G];
 #pragma unroll
     for (int u = 0; u < G; u++) pv[u] = key_at (at[u] + 12u * (h - 1u));
 #pragma unroll
     for (int u = 0; u < G; u++) {
-      const u32 hs = h <= q4[u] ? 12u * h : 0u; /* scalar */
-      u32 cand = at[u] + hs;                   /* independent of the probe: issued under its latency */
-      asm volatile ("" : "+v"(cand));          /* keep add + select (the folded form needs a move of hs per step) */
+      u32 cand = at[u] + 12u * h;     /* independent of the probe: issued under its latency */
+      asm volatile ("" : "+v"(cand)); /* keep add + select */
       at[u] = pv[u] < ky[u] ? cand : at[u];
     }
-  }
-  bool all_long = true; /* every run holds >= 256 records (the usual tile): every remaining step is live */
+  };
+  bool same = true; /* wave-uniform: every chunk of the group is ranked in the same run (the usual group) */
 #pragma unroll
-  for (int u = 0; u < G; u++) all_long &= q4[u] >= 64;
-  if (all_long) {
+  for (int u = 1; u < G; u++) same &= sn[u] == sn[0] && sbase[u] == sbase[0];
+  if (same) {
+    /* ONE plan for the group: the scalar unit is shared by the CU's sixteen wavefronts and is this
+     * kernel's scarcest resource, so the per-search selects of the general form below
+     * are worth avoiding: a step is either skipped by one scalar branch or runs on constants */
+    const u32 n = sn[0], base = 4u * sbase[0];
+    const u32 half = n ? 1u << (31 - __builtin_clz (n)) : 0u; /* P/2 = the largest power of two <= n */
+    const u32 q4 = half >> 1, i0 = n - half, inc = n ? 12u * (i0 + 1u) : 0u;
+    const u64 pv0 = key_at (base + 12u * i0); /* the same record for every lane and search */
 #pragma unroll
-    for (u32 h = 64; h >= 1; h >>= 1) {
-      u64 pv[G];
+    for (int u = 0; u < G; u++) at[u] = base + (pv0 < ky[u] ? inc : 0u);
 #pragma unroll
-      for (int u = 0; u < G; u++) pv[u] = key_at (at[u] + 12u * (h - 1u));
+    for (u32 h = HTOP; h > 64; h >>= 1) {
+      if (h > q4) continue;
+      step (h);
+    }
+    if (q4 >= 64) { /* a run of >= 256 records: every remaining step is live */
 #pragma unroll
-      for (int u = 0; u < G; u++) {
-        u32 cand = at[u] + 12u * h;
-        asm volatile ("" : "+v"(cand));
-        at[u] = pv[u] < ky[u] ? cand : at[u];
+      for (u32 h = 64; h >= 1; h >>= 1) step (h);
+    } else {
+#pragma unroll
+      for (u32 h = 64; h >= 1; h >>= 1) {
+        if (h > q4) continue;
+        step (h);
       }
     }
   } else {
+    /* general form: every search has its own plan; steps a short run does not need add 0 */
+    u32 q4[G];
 #pragma unroll
-    for (u32 h = 64; h >= 1; h >>= 1) {
+    for (int u = 0; u < G; u++) {
+      const u32 n = sn[u];
+      const u32 half = n ? 1u << (31 - __builtin_clz (n)) : 0u;
+      q4[u] = half >> 1;
+      const u32 i0 = n - half;
+      const u32 inc = n ? 12u * (i0 + 1u) : 0u;
+      const u64 pv = key_at (4u * sbase[u] + 12u * i0);
+      at[u] = 4u * sbase[u] + (pv < ky[u] ? inc : 0u);
+    }
+#pragma unroll
+    for (u32 h = HTOP; h >= 1; h >>= 1) {
+      bool any = false; /* wave-uniform */
+#pragma unroll
+      for (int u = 0; u < G; u++) any |= h <= q4[u];
+      if (!any) continue;
       u64 pv[G];
 #pragma unroll
       for (int u = 0; u < G; u++) pv[u] = key_at (at[u] + 12u * (h - 1u));
 #pragma unroll
       for (int u = 0; u < G; u++) {
-        const u32 hs = h <= q4[u] ? 12u * h : 0u;
+        const u32 hs = h <= q4[u] ? 12u * h : 0u; /* scalar */
         u32 cand = at[u] + hs;
         asm volatile ("" : "+v"(cand));
         at[u] = pv[u] < ky[u] ? cand : at[u];
