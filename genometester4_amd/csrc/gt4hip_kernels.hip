@@ -597,6 +597,7 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
    * counts and row carry; two-pass path: its offset), carried over the back edge */
   u32 dagg = 0;
   u64 dcarry = 0;
+  int r_nxt = 1, r_nn = 2; /* ring slots of the next two tiles */
   /* count-only kernels: the wavefronts that share a SIMD with the housekeeping wavefront win the CU's
    * arbitration -- measured 3 - 5 % on every count-only call (9.34 -> 8.91 ms at 2 x 2e9), nothing on
    * the kernels that write records */
@@ -619,11 +620,15 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
 #pragma unroll
       for (int j = 0; j < NLOAD4; j++) {
         const u32 q = (u32) j * NT + (u32) tid;
-        if (q < cA + cB) {
-          const u32 q0 = (u32) j * NT + (u32) wid * WAVE;
-          const bool straddle = q0 < cA && q0 + WAVE > cA; /* wave-uniform */
-          *reinterpret_cast<u32x4 *> (lds32 + 4 * q) = straddle ? (pre[j] | pre_x) : pre[j];
-        }
+        if (q < cA + cB) *reinterpret_cast<u32x4 *> (lds32 + 4 * q) = pre[j];
+      }
+      /* the one wave-instruction per tile that straddles the two ranges: its B half arrived in
+       * pre_x (fetch_part) and goes over the zeros the A descriptor returned for those lanes -- one
+       * uniform test per tile instead of a select in every part */
+      const u32 qs = cA & ~(u32) (WAVE - 1);
+      if ((cA & (WAVE - 1)) && (qs / WAVE) % NW == (u32) wid) {
+        const u32 q = qs + (u32) lane;
+        if (q >= cA && q < cA + cB) *reinterpret_cast<u32x4 *> (lds32 + 4 * q) = pre_x;
       }
     }
     if (DEFER && it >= LAG && wid == 4) {
@@ -640,7 +645,7 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
     PHASE_STAMP (0); /* phase 0: wait for the prefetched records, LDS writes */
     __syncthreads (); /* B0 */
     PHASE_STAMP (1); /* barrier B0 */
-    const int s_nxt = (it + 1) % 3, s_nn = (it + 2) % 3;
+    const int s_nxt = r_nxt, s_nn = r_nn; /* (it + 1) % 3, (it + 2) % 3 without the division */
     const u32 nxt = uniform32 (sh.tile_id[s_nxt]);
     TileRange tn = { 0, 0, 0, 0 };
     if (nxt < ntl) {
@@ -783,7 +788,7 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
             fb[k] = 0;
             meta[k] = 0;
             const u64 m = __builtin_amdgcn_ballot_w64 (keep);
-            if (lane == 0) sh.kmask[OPS == 2 ? 1 : 2][chunk] = m;
+            if (lane == 0) sh.kmask[OPS == 2 ? 1 : 2][chunk] = m; /* (written by every lane, as the other kernels do, this kernel loses 8 %) */
             if (OPS == 2) acc_sum1 += keep ? f : 0u;
             else acc_sum2 += keep ? f : 0u;
             continue;
@@ -800,7 +805,7 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
             fb[k] = 0;
             meta[k] = r | (is_a[u] << 18);
             const u64 m = __builtin_amdgcn_ballot_w64 (keep);
-            if (lane == 0) sh.kmask[0][chunk] = m;
+            sh.kmask[0][chunk] = m;
             acc_sum0 += keep ? f : 0u;
             continue;
           }
@@ -823,25 +828,25 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
           if (ops & 1u) {
             const bool keep = (FAST && OPS == 0) ? eval_default<0> (kind, xa, xb, p.cutoff, f) : eval_stream<0> (kind, xa, xb, c0, f);
             const u64 m = __builtin_amdgcn_ballot_w64 (keep);
-            if (lane == 0) sh.kmask[0][chunk] = m;
+            sh.kmask[0][chunk] = m;
             acc_sum0 += keep ? f : 0u;
           }
           if ((!FAST || OPS == 0) && (ops & 2u)) {
             const bool keep = (FAST && OPS == 0) ? eval_default<1> (kind, xa, xb, p.cutoff, f) : eval_stream<1> (kind, xa, xb, c1, f);
             const u64 m = __builtin_amdgcn_ballot_w64 (keep);
-            if (lane == 0) sh.kmask[1][chunk] = m;
+            sh.kmask[1][chunk] = m;
             acc_sum1 += keep ? f : 0u;
           }
           if ((!FAST || OPS == 0) && (ops & 4u)) {
             const bool keep = (FAST && OPS == 0) ? eval_default<2> (kind, xa, xb, p.cutoff, f) : eval_stream<2> (kind, xa, xb, c2, f);
             const u64 m = __builtin_amdgcn_ballot_w64 (keep);
-            if (lane == 0) sh.kmask[2][chunk] = m;
+            sh.kmask[2][chunk] = m;
             acc_sum2 += keep ? f : 0u;
           }
           if ((!FAST || OPS == 0) && (ops & 8u)) {
             const bool keep = (FAST && OPS == 0) ? eval_default<3> (kind, xa, xb, p.cutoff, f) : eval_stream<3> (kind, xa, xb, c3, f);
             const u64 m = __builtin_amdgcn_ballot_w64 (keep);
-            if (lane == 0) sh.kmask[3][chunk] = m;
+            sh.kmask[3][chunk] = m;
             acc_sum3 += keep ? f : 0u;
           }
           if (OPS != 0) fa[k] = f; /* the one stream's count: staging does not evaluate the rule again */
@@ -966,6 +971,11 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
     cur = nxt;
     tr = tn;
     it++;
+    {
+      const int r_cur = r_nxt;
+      r_nxt = r_nn;
+      r_nn = r_cur == 0 ? 2 : r_cur - 1; /* 0 1 2 -> the slot before r_nxt */
+    }
   }
 #ifdef GT4_PROFILE_PHASES
   if (tid == GT4_STAMP_TID)
