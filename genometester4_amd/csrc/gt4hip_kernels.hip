@@ -721,12 +721,14 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
         bool live[G], valid[G], any_live = false;
         u32 is_a[G], own[G], lim[G], lo[G]; /* is_a: wave-uniform (chunks never mix the lists); lim, lo: bytes (12 per record) */
         u32 sbase[G], sn[G];                /* wave-uniform: dword base and length of the run this chunk is ranked in */
+        u32 plim[G];                        /* wave-uniform: positions below it hold a record this call looks at */
         u64 ky[G];
 #pragma unroll
         for (int u = 0; u < G; u++) {
           const u32 cbeg = ((u32) (kk + u) * NW + (u32) wid) * WAVE; /* wave-uniform */
           is_a[u] = cbeg < nbs ? 1u : 0u;
-          live[u] = is_a[u] ? cbeg < na : (need_b && cbeg < npos);
+          plim[u] = is_a[u] ? na : (need_b ? npos : 0u);
+          live[u] = cbeg < plim[u];
           any_live |= live[u];
         }
         if (!any_live) {
@@ -749,9 +751,18 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
         }
 #pragma unroll
         for (int u = 0; u < G; u++) {
+          /* one per-lane compare against a scalar limit; everything uniform stays a scalar select
+           * (mixing uniform and per-lane conditions costs the shared scalar unit a mask operation each) */
           const u32 e = (u32) (kk + u) * NT + (u32) tid;
-          valid[u] = live[u] && (is_a[u] ? e < na : e < npos);
-          const u32 at = valid[u] ? (is_a[u] ? 3 * e : OB + 3 * (e - nbs)) : 0u;
+          u32 at;
+          if (OPS == 2) { /* (the intersection alone measures 4 % FASTER with the condition spelled out) */
+            valid[u] = live[u] && (is_a[u] ? e < na : e < npos);
+            at = valid[u] ? (is_a[u] ? 3 * e : OB + 3 * (e - nbs)) : 0u;
+          } else {
+            valid[u] = e < plim[u]; /* (a chunk that is not live has no position below its limit) */
+            const u32 off = is_a[u] ? 0u : OB - 3 * nbs;
+            at = valid[u] ? 3 * e + off : 0u;
+          }
           ky[u] = (u64) lds32[at] | ((u64) lds32[at + 1] << 32);
           own[u] = lds32[at + 2];
           sbase[u] = is_a[u] ? OB : 0u;
