@@ -620,7 +620,9 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
 #pragma unroll
       for (int j = 0; j < NLOAD4; j++) {
         const u32 q = (u32) j * NT + (u32) tid;
-        if (q < cA + cB) *reinterpret_cast<u32x4 *> (lds32 + 4 * q) = pre[j];
+        /* chunks past the tile's last one hold zeros (range-checked loads): writing them is harmless
+         * wherever the part still lies inside the input view -- no per-part test, no exec juggling */
+        if ((j + 1) * NT * 4 <= 3 * CAP || q < cA + cB) *reinterpret_cast<u32x4 *> (lds32 + 4 * q) = pre[j];
       }
       /* the one wave-instruction per tile that straddles the two ranges: its B half arrived in
        * pre_x (fetch_part) and goes over the zeros the A descriptor returned for those lanes -- one
