@@ -362,6 +362,26 @@ __device__ __forceinline__ void write_out_tile (u32 *out_rec, u64 excl, u32 tot,
 }
 
 
+/* The same with the offset in BYTES (the one wavefront that resolves it multiplies, not all sixteen)
+ * and without a single per-lane branch: K guarded-by-a-scalar steps, the range-checked descriptor
+ * drops what lies past the last record, the LDS read is clamped into the staged records.  The
+ * scalar unit is shared by the CU's wavefronts: every scalar instruction here is paid sixteen times. */
+template <int NT, int K>
+__device__ __forceinline__ void write_out_fixed (u32 *out_rec, u64 excl_bytes, u32 tot, const u32 *slot, int tid)
+{
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc ((void *) (reinterpret_cast<char *> (out_rec) + excl_bytes), 0, (int) (12 * tot), 0x00020000);
+  const u32 chunks = (3 * tot + 3) >> 2;
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    if ((u32) k * NT >= chunks) break; /* wave-uniform */
+    const u32 c = (u32) k * NT + (u32) tid;
+    const u32 cr = c < chunks ? c : chunks - 1u;
+    const u32x4 w = *reinterpret_cast<const u32x4 *> (slot + 4 * cr);
+    __builtin_amdgcn_raw_buffer_store_b128 (w, r, 16 * c, 0, 0);
+  }
+}
+
+
 /* values read back from LDS are the same in every lane; say so, so that addresses, descriptors and
  * loop bounds derived from them live in SGPRs (no waterfall loops around the buffer loads) */
 __device__ __forceinline__ u32 uniform32 (u32 v) { return __builtin_amdgcn_readfirstlane (v); }

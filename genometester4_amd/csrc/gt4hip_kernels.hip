@@ -642,7 +642,7 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
       u64 x = dcarry;
       if (MODE == MODE_LOOKBACK)
         x = resolve_offset (agg + (u64) S0 * n_rows * WAVE, carry + (u64) S0 * (n_rows + 1), past[0], lane, dagg, dcarry, ctl, spin_limit);
-      if (lane == 0) sh.excl[S0] = x;
+      if (lane == 0) sh.excl[S0] = 12 * x; /* bytes */
     }
     PHASE_STAMP (0); /* phase 0: wait for the prefetched records, LDS writes */
     __syncthreads (); /* B0 */
@@ -680,12 +680,9 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
     const bool w_have = it >= LAG;
     const bool n_have = LAG > 1 && it >= LAG - 1;        /* written out next iteration */
     const u32 n_tile = past[LAG > 1 ? 1 : 0];
-#ifndef GT4_STAGGER_WRITEOUT
-#define GT4_STAGGER_WRITEOUT 0 /* experiment: the younger half of the wavefronts writes the old tile out BEHIND its ranking */
-#endif
-    const u64 w_excl = DEFER && w_have ? uniform64 (sh.excl[S0]) : 0;
-    if (DEFER && w_have && (!GT4_STAGGER_WRITEOUT || wid < NW / 2)) {
-      write_out_tile<NT> (outs.rec[S0], w_excl, w_tot, sh.stage[it % LAG], tid);
+    if (DEFER && w_have) {
+      constexpr int WK = (Shared::STAGE_DW / 4 + NT - 1) / NT;
+      write_out_fixed<NT, WK> (outs.rec[S0], uniform64 (sh.excl[S0]), w_tot, sh.stage[it % LAG], tid);
     }
     u32 xagg = 0;
     u64 xcarry = 0;
@@ -883,7 +880,7 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
       u64 x;
       if (MODE == MODE_LOOKBACK) x = resolve_offset (agg + (u64) s * n_rows * WAVE, carry + (u64) s * (n_rows + 1), pt, lane, xagg, xcarry, ctl, spin_limit);
       else x = desc[4 * (u64) pt + s];
-      if (lane == 0) sh.excl[s] = x;
+      if (lane == 0) sh.excl[s] = 12 * x; /* bytes */
     }
     if (STAGGER && nxt < ntl) {
 #pragma unroll
@@ -902,7 +899,6 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
         dcarry = __hip_atomic_load (&desc[4 * (u64) n_tile + S0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
-    if (GT4_STAGGER_WRITEOUT && DEFER && w_have && wid >= NW / 2) write_out_tile<NT> (outs.rec[S0], w_excl, w_tot, sh.stage[it % LAG], tid);
     PHASE_STAMP (3); /* phase 1 */
     __syncthreads (); /* B1: all input reads done */
     PHASE_STAMP (4); /* barrier B1 */
@@ -939,7 +935,7 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
       if (it >= 1) {
 #pragma unroll
         for (int s = 0; s < 4; s++)
-          if ((ops >> s) & 1u) write_out_tile<NT> (outs.rec[s], uniform64 (sh.excl[s]), g_tot[s], sh.stage[0] + 3 * g_off[s], tid);
+          if ((ops >> s) & 1u) write_out_fixed<NT, (3 * CAP / 4 + NT - 1) / NT> (outs.rec[s], uniform64 (sh.excl[s]), g_tot[s], sh.stage[0] + 3 * g_off[s], tid);
       }
       __syncthreads (); /* B2: staging area free, this tile's totals and prefix tables complete */
       u32 run = 0;
