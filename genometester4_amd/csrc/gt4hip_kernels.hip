@@ -340,17 +340,15 @@ __device__ __forceinline__ void rank_group (const u32 *lds32, const u32 (&sbase)
     const u64 pv0 = key_at (base + 12u * i0); /* the same record for every lane and search */
 #pragma unroll
     for (int u = 0; u < G; u++) at[u] = base + (pv0 < ky[u] ? inc : 0u);
+    if (q4 >= HTOP / 2) {
+      /* the usual tile (two lists of similar density: every run holds at least a quarter of the tile's
+       * capacity): one test for the top step, the others run unconditionally */
+      if (q4 >= HTOP) step (HTOP);
 #pragma unroll
-    for (u32 h = HTOP; h > 64; h >>= 1) {
-      if (h > q4) continue;
-      step (h);
-    }
-    if (q4 >= 64) { /* a run of >= 256 records: every remaining step is live */
-#pragma unroll
-      for (u32 h = 64; h >= 1; h >>= 1) step (h);
+      for (u32 h = HTOP / 2; h >= 1; h >>= 1) step (h);
     } else {
 #pragma unroll
-      for (u32 h = 64; h >= 1; h >>= 1) {
+      for (u32 h = HTOP / 4; h >= 1; h >>= 1) {
         if (h > q4) continue;
         step (h);
       }
