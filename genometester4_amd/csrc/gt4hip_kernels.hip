@@ -389,7 +389,7 @@ __device__ __forceinline__ void rank_group (const u32 *lds32, const u32 (&sbase)
 }
 
 struct TileRange {
-  u64 a0, b0;
+  u64 a0, b0; /* BYTE offsets of the tile's first records in the two lists */
   u32 na, nb;
 };
 
@@ -516,8 +516,15 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
     for (int q = 0; q < 3; q++) t3[q] = deal (q);
     for (int q = 0; q < 2; q++) {
       sh.tile_id[q] = t3[q];
-      if (t3[q] < ntl)
-        for (int i = 0; i < 4; i++) sh.rng[q][i] = part[2 * (u64) t3[q] + i];
+      if (t3[q] < ntl) {
+        {
+          const u64 e0 = part[2 * (u64) t3[q]], e1 = part[2 * (u64) t3[q] + 1], e2 = part[2 * (u64) t3[q] + 2], e3 = part[2 * (u64) t3[q] + 3];
+          sh.rng[q][0] = 12 * e0; /* byte offsets and record counts, ready for the descriptors: */
+          sh.rng[q][1] = 12 * e1; /* computed once here, not by sixteen wavefronts' scalar code */
+          sh.rng[q][2] = e2 - e0;
+          sh.rng[q][3] = e3 - e1;
+        }
+      }
     }
     tk_next = t3[2];
   }
@@ -527,8 +534,8 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
   if (cur < ntl) {
     tr.a0 = uniform64 (sh.rng[0][0]);
     tr.b0 = uniform64 (sh.rng[0][1]);
-    tr.na = uniform32 ((u32) (sh.rng[0][2] - sh.rng[0][0]));
-    tr.nb = uniform32 ((u32) (sh.rng[0][3] - sh.rng[0][1]));
+    tr.na = uniform32 ((u32) sh.rng[0][2]);
+    tr.nb = uniform32 ((u32) sh.rng[0][3]);
   }
   u32x4 pre[NLOAD4];
   u32x4 pre_x = { 0, 0, 0, 0 }; /* B half of the one wave-instruction per tile that straddles the two ranges */
@@ -544,8 +551,8 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
    * up in front of the CU's one address unit. */
   auto fetch_part = [&] (const TileRange &t, int j) {
     const u32 da = 3 * t.na, db = 3 * t.nb, cA = (da + 3) >> 2;
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc ((void *) (A + 3 * t.a0), 0, (int) (4 * da), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc ((void *) (B + 3 * t.b0), 0, (int) (4 * db), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc ((void *) (reinterpret_cast<const char *> (A) + t.a0), 0, (int) (4 * da), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc ((void *) (reinterpret_cast<const char *> (B) + t.b0), 0, (int) (4 * db), 0x00020000);
 #pragma unroll
     for (int jj = 0; jj < NLOAD4; jj++) {
       if (jj != j) continue;
@@ -651,8 +658,8 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
     if (nxt < ntl) {
       tn.a0 = uniform64 (sh.rng[s_nxt][0]);
       tn.b0 = uniform64 (sh.rng[s_nxt][1]);
-      tn.na = uniform32 ((u32) (sh.rng[s_nxt][2] - sh.rng[s_nxt][0]));
-      tn.nb = uniform32 ((u32) (sh.rng[s_nxt][3] - sh.rng[s_nxt][1]));
+      tn.na = uniform32 ((u32) sh.rng[s_nxt][2]);
+      tn.nb = uniform32 ((u32) sh.rng[s_nxt][3]);
     }
     /* housekeeping by thread 0, results consumed at the end of this iteration */
     u64 hk_rng[4] = { 0, 0, 0, 0 };
@@ -967,8 +974,12 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
     if (tid == 0) {
       sh.tile_id[s_nn] = hk_tile;
       if (hk_have_rng) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) sh.rng[s_nn][i] = hk_rng[i];
+        {
+          sh.rng[s_nn][0] = 12 * hk_rng[0];
+          sh.rng[s_nn][1] = 12 * hk_rng[1];
+          sh.rng[s_nn][2] = hk_rng[2] - hk_rng[0];
+          sh.rng[s_nn][3] = hk_rng[3] - hk_rng[1];
+        }
       }
     }
 #pragma unroll
