@@ -18,7 +18,10 @@ for n, (i, nm) in enumerate(zip(starts, names)):
         continue
     end = starts[n + 1] if n + 1 < len(starts) else len(L)
     B = L[i:end]
-    hd = [j for j, l in enumerate(B) if "This Loop Header: Depth=1" in l][0]
+    hds = [j for j, l in enumerate(B) if "Loop Header: Depth=1" in l]
+    if not hds:
+        continue
+    hd = hds[0]
     nxt = [j for j, l in enumerate(B) if "Loop Header: Depth=1" in l and j > hd]
     body = B[hd:nxt[0]] if nxt else B[hd:]
     c = collections.Counter()
