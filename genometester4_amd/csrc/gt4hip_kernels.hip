@@ -423,11 +423,12 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
   constexpr int G = IPT % 3 == 0 ? 3 : 2; /* chunks searched together (four at a time is no faster for the union and spills the 85-register count kernels) */
   /* staggered fetch: the first F_TOP of the NLOAD4 + 1 parts are issued at the top of the iteration,
    * F_MID between the search groups, the rest behind the ranking.  Measured per kernel class (2 x 2e9
-   * records): union and intersection are fastest with one part at the top and one in the middle; the
+   * records): the union is fastest with one part at the top and one in the middle, the intersection
+   * (after the scalar diet) with two at the top and none in the middle (11.6 -> 11.4 ms); the
    * first complement with all whole parts at the top (16.1 -> 14.3 ms); the any-combination kernel,
    * which also resolves its offsets behind the ranking, with everything at the top (29.8 -> 28.7 ms). */
-  constexpr int F_TOP = GDEFER ? NLOAD4 + 1 : (OPS == 4 ? NLOAD4 : 1);
-  constexpr int F_MID = (GDEFER || OPS == 4) ? 0 : 1;
+  constexpr int F_TOP = GDEFER ? NLOAD4 + 1 : (OPS == 4 ? NLOAD4 : (OPS == 2 ? 2 : 1));
+  constexpr int F_MID = (GDEFER || OPS == 4 || OPS == 2) ? 0 : 1;
   constexpr bool STAGGER = NT >= 1024;           /* spread the fetch over the iteration (measured: helps 16-wave workgroups only) */
   static_assert (NW >= 4, "one wavefront per output stream in phase 2");
   static_assert (NCH <= 2 * WAVE, "chunk scan is a single wavefront pass");
