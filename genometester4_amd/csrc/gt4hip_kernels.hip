@@ -757,11 +757,11 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
             key[k] = 0;
             fa[k] = fb[k] = 0;
             meta[k] = KIND_SKIP << 16;
-            if (lane == 0) {
+            {
               const u32 chunk = (u32) k * NW + (u32) wid;
 #pragma unroll
               for (int s = 0; s < 4; s++)
-                if ((ops >> s) & 1u) sh.kmask[s][chunk] = 0;
+                if ((ops >> s) & 1u) store_lane0 (&sh.kmask[s][chunk], sh.trash, 0ull, lane);
             }
           }
           continue;
