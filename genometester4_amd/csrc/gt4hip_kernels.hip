@@ -927,9 +927,9 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
     u32 my_total = 0;
     if (DEFER) {
       my_total = chunk_scan<NCH> (sh.kmask[S0], sh.cpre[S0], lane);
-      if (lane == 0) {
-        if (wid == S0) blk_cnt += my_total; /* the kernel-total reduction reads it from lane 0 of wave S0 */
-        if (wid == 0 && MODE == MODE_LOOKBACK) publish_u32 (&agg[(u64) S0 * n_rows * WAVE + cur], AGG_READY | my_total);
+      blk_cnt += my_total; /* every lane of every wavefront holds the same sum; the kernel-total reduction reads lane 0 of wave S0 */
+      if (wid == 0 && MODE == MODE_LOOKBACK) { /* a uniform branch first: fifteen wavefronts skip the exec bookkeeping */
+        if (lane == 0) publish_u32 (&agg[(u64) S0 * n_rows * WAVE + cur], AGG_READY | my_total);
       }
     }
     /* any-combination kernel: wavefront s owns stream s: chunk scan, tile total, publish */
