@@ -21,6 +21,9 @@
  */
 #include "gt4hip_device.h"
 
+#ifndef GT4_NARROW
+#define GT4_NARROW 1
+#endif
 #ifndef GT4_IPT_UNION
 #define GT4_IPT_UNION 4 /* 6 (one staging slot written out late) measured 3 % slower than 4 with two slots */
 #endif
@@ -319,7 +322,7 @@ __device__ __forceinline__ void scatter_stream (Shared &sh, u32 *dst32, const Pa
  * step.  Steps a short run does not need add 0 (their probes read this workgroup's LDS beyond
  * the run, and the value is ignored).  The G searches are interleaved: G LDS reads in flight per lane. */
 template <int CAP, int G>
-__device__ __forceinline__ void rank_group (const u32 *lds32, const u32 (&sbase)[G], const u32 (&sn)[G], const u64 (&ky)[G], u32 (&lo)[G])
+__device__ __forceinline__ void rank_group (const u32 *lds32, const u32 (&sbase)[G], const u32 (&sn)[G], const u64 (&ky)[G], u32 (&lo)[G], bool narrow, u32 base_lo)
 {
   auto key_at = [&] (u32 byte_off) -> u64 {
     const u32 *const q = reinterpret_cast<const u32 *> (reinterpret_cast<const char *> (lds32) + byte_off);
@@ -352,7 +355,32 @@ __device__ __forceinline__ void rank_group (const u32 *lds32, const u32 (&sbase)
     const u64 pv0 = key_at (base + 12u * i0); /* the same record for every lane and search */
 #pragma unroll
     for (int u = 0; u < G; u++) at[u] = base + (pv0 < ky[u] ? inc : 0u);
-    if (q4 >= HTOP / 2) {
+    if (q4 >= HTOP / 2 && narrow) {
+      /* the usual tile whose keys all lie within 2^32 of its smallest one (wave-uniform, tested once per
+       * tile by the caller): keys compare as (low dword - base_lo) mod 2^32, so a probe reads 4 bytes
+       * instead of 8 -- the ranking phase is bound by LDS cycles (50 extra LDS reads per wavefront and
+       * tile cost this kernel 30 %), and the probes are most of them */
+      u32 k32[G];
+#pragma unroll
+      for (int u = 0; u < G; u++) k32[u] = (u32) ky[u] - base_lo;
+      auto key32_at = [&] (u32 byte_off) -> u32 {
+        return *reinterpret_cast<const u32 *> (reinterpret_cast<const char *> (lds32) + byte_off) - base_lo;
+      };
+      auto step32 = [&] (u32 h) {
+        u32 pv[G];
+#pragma unroll
+        for (int u = 0; u < G; u++) pv[u] = key32_at (at[u] + 12u * (h - 1u));
+#pragma unroll
+        for (int u = 0; u < G; u++) {
+          u32 cand = at[u] + 12u * h;
+          asm volatile ("" : "+v"(cand));
+          at[u] = pv[u] < k32[u] ? cand : at[u];
+        }
+      };
+      if (q4 >= HTOP) step32 (HTOP);
+#pragma unroll
+      for (u32 h = HTOP / 2; h >= 1; h >>= 1) step32 (h);
+    } else if (q4 >= HTOP / 2) {
       /* the usual tile (two lists of similar density: every run holds at least a quarter of the tile's
        * capacity): one test for the top step, the others run unconditionally */
       if (q4 >= HTOP) step (HTOP);
@@ -721,6 +749,19 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
       } else fetch (tn);
     }
 
+    /* do all keys of the tile lie within 2^32 of its smallest one?  Both runs ascend: four reads of
+     * uniform addresses (broadcast), computed on the vector side (the same in every lane) so that
+     * only the final test reaches the scalar unit */
+    bool narrow = false;
+    u32 base_lo = 0;
+    if (GT4_NARROW && OPS == 2 && MODE != MODE_COUNT && na && nb) { /* (the intersection: 11.30 -> 11.11 ms; the scalar-bound kernels lose 2-3 % to the test itself) */
+      const u32 la = 3 * (na - 1), lb = OB + 3 * (nb - 1);
+      const u64 a_min = (u64) lds32[0] | ((u64) lds32[1] << 32), a_max = (u64) lds32[la] | ((u64) lds32[la + 1] << 32);
+      const u64 b_min = (u64) lds32[OB] | ((u64) lds32[OB + 1] << 32), b_max = (u64) lds32[lb] | ((u64) lds32[lb + 1] << 32);
+      const u64 t_min = a_min < b_min ? a_min : b_min, t_max = a_max > b_max ? a_max : b_max;
+      narrow = __builtin_amdgcn_ballot_w64 (((t_max - t_min) >> 32) == 0) != 0;
+      base_lo = (u32) t_min;
+    }
     PHASE_STAMP (2); /* ring read, housekeeping issue, fetch issue */
     /* ---- phase 1: rank, classify, predicates.  Chunks are handled two at a time so that every
      * step of the search has two independent LDS reads in flight per lane. */
@@ -787,7 +828,7 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
           lim[u] = valid[u] ? 12 * sn[u] : 0u;
           lo[u] = 0;
         }
-        rank_group<CAP, G> (lds32, sbase, sn, ky, lo);
+        rank_group<CAP, G> (lds32, sbase, sn, ky, lo, narrow, base_lo);
 #pragma unroll
         for (int u = 0; u < G; u++) {
           const int k = kk + u;

@@ -399,3 +399,36 @@ def test_intersect_multi_long_first_list(ctx, rule):
         assert rc_g == rc_o == 0
         assert (n_g, t_g) == (n_o, t_o)
         assert out.download().tobytes() == r_o.tobytes()
+
+
+@pytest.mark.parametrize("ops", [2, 4, 8, 1, 15])
+@pytest.mark.parametrize("shape", ["wrap", "wide", "mixed"])
+def test_key_spans_around_the_32_bit_search(ctx, ops, shape):
+    """The intersection / complement kernels compare low dwords relative to the tile's smallest key when
+    the tile spans less than 2^32 (rank_group, 32-bit probes).  `wrap`: dense keys around multiples of
+    2^32, so the low dwords of one tile wrap; `wide`: every tile spans far more than 2^32 (64-bit
+    probes); `mixed`: dense stretches separated by gaps of 2^40, so tiles of both kinds alternate and
+    some tiles span just under / just over 2^32."""
+    rng = np.random.default_rng(77 + ops)
+    if shape == "wrap":
+        keys = np.concatenate([(np.uint64(j) << np.uint64(32)) + rng.integers(-(1 << 21), 1 << 21, size=9000).astype(np.int64).astype(np.uint64)
+                               for j in (2, 3, 1 << 20)])
+    elif shape == "wide":
+        keys = rng.integers(0, 1 << 62, size=30000, dtype=np.uint64)
+    else:
+        parts = []
+        for j in range(12):
+            base = np.uint64(j + 1) << np.uint64(40)
+            width = (1 << 31) + (j - 6) * (1 << 28)  # a stretch of about one tile: spans from 2^31 - 1.5 * 2^30 to 2^31 + 1.25 * 2^30 ... and 2x that with the neighbour
+            parts.append(base + rng.integers(0, max(width, 1 << 20), size=2500, dtype=np.uint64))
+            parts.append(base + (np.uint64(1) << np.uint64(32)) + rng.integers(0, 1 << 20, size=700, dtype=np.uint64))
+        keys = np.concatenate(parts)
+    keys = np.unique(keys)
+    in_a, in_b = rng.random(len(keys)) < 0.6, rng.random(len(keys)) < 0.6
+    a = U.make_records(keys[in_a], rng.integers(1, 9, size=int(in_a.sum()), dtype=np.uint32))
+    b = U.make_records(keys[in_b], rng.integers(1, 9, size=int(in_b.sum()), dtype=np.uint32))
+    exp = O.compare(a, b, ops, cutoff=2)
+    st, out, _ = ctx.compare(ctx.upload(a, 31), ctx.upload(b, 31), ops, cutoff=2)
+    for bit, (n, total, recs) in exp.items():
+        assert st[bit] == (n, total)
+        assert out[bit].download().tobytes() == recs.tobytes()
