@@ -179,6 +179,8 @@ extern "C" int gt4hip_get_counter (gt4hip_context *ctx, const char *name, uint64
   if (!strcmp (name, "single_pass_fallbacks")) *value = ctx->single_pass_fallbacks;
   else if (!strcmp (name, "kway_calls")) *value = ctx->kway_calls;
   else if (!strcmp (name, "kway_overflows")) *value = ctx->kway_overflows;
+  else if (!strcmp (name, "nway_kernel_us")) *value = (uint64_t) (ctx->nway_kernel_ms * 1000.0);
+  else if (!strcmp (name, "nway_tiles")) *value = ctx->nway_tiles;
   else return gt4hip_fail (ctx, GT4HIP_EINVAL, "unknown counter %s", name);
   return GT4HIP_OK;
 }
@@ -767,7 +769,7 @@ static int empty_result (gt4hip_context *ctx, uint32_t word_length, bool count_o
   return gt4hip_list_new (ctx, 0, word_length, &res->out);
 }
 
-/* N-way union by the one-pass tile kernel (gt4hip_kway.hip): groups of up to eight lists per launch;
+/* N-way union by the one-pass tile kernel (gt4hip_nway.hip): groups of up to eight lists per launch;
  * more than eight lists take levels of eight-way merges that keep every key (ADD / MAX are
  * associative, NUMBER ignores the counts), the cutoff is applied once, at the last level (:574).
  * *done = 0: nothing was produced, the caller takes the pairwise tree. */
@@ -802,7 +804,7 @@ static int union_multi_kway (gt4hip_context *ctx, const std::vector<const gt4hip
       uint64_t n = 0, t = 0;
       double ms = 0;
       int used = 0;
-      rc = gt4hip_kway_union (ctx, &cur[i], (uint32_t) g, rule, cutoff, ovr, FILTER_RAW, false, o, &n, &t, &ms, &used);
+      rc = gt4hip_nway_union (ctx, &cur[i], (uint32_t) g, rule, cutoff, ovr, FILTER_RAW, false, o, &n, &t, &ms, &used);
       if (rc || !used) {
         gt4hip_list_free (o);
         for (gt4hip_list *l : next_owned) gt4hip_list_free (l);
@@ -868,7 +870,7 @@ static int union_multi_kway (gt4hip_context *ctx, const std::vector<const gt4hip
   uint64_t n = 0, t = 0;
   double ms = 0;
   int used = 0;
-  rc = gt4hip_kway_union (ctx, cur.data (), (uint32_t) cur.size (), rule, cutoff, ovr, FILTER_RESULT, count_only, o, &n, &t, &ms, &used);
+  rc = gt4hip_nway_union (ctx, cur.data (), (uint32_t) cur.size (), rule, cutoff, ovr, FILTER_RESULT, count_only, o, &n, &t, &ms, &used);
   drop ();
   if (rc || !used) {
     if (made) gt4hip_list_free (made);

@@ -1,5 +1,5 @@
 /* gt4hip_host.h -- host-side internals shared by the C-ABI implementation files
- * (gt4hip_api.hip, gt4hip_io.hip, gt4hip_comm.hip, gt4hip_kway.hip). */
+ * (gt4hip_api.hip, gt4hip_io.hip, gt4hip_comm.hip, gt4hip_nway.hip). */
 #ifndef GT4HIP_HOST_H
 #define GT4HIP_HOST_H
 
@@ -41,7 +41,7 @@ struct gt4hip_context {
   gt4::PairControl *ctl_host;     /* pinned */
   unsigned long long *scratch;      /* device, 4 x u64 */
   unsigned long long *scratch_host; /* pinned */
-  /* N-way tile merge (gt4hip_kway.hip) */
+  /* N-way tile kernel (gt4hip_nway.hip) */
   uint64_t *kway_part;       /* tile boundaries, [tiles + 1][8] */
   size_t kway_part_bytes;
   int kway_enabled;          /* option "kway": 0 = always the pairwise tree */
@@ -49,6 +49,8 @@ struct gt4hip_context {
   int64_t kway_vt;           /* option "kway_vt": positions per thread in a merge pass, at least (0 = default) */
   uint64_t kway_overflows;   /* calls that fell back to the tree because a tile would not fit LDS */
   uint64_t kway_calls;       /* N-way unions done by the one-pass kernel */
+  double nway_kernel_ms;     /* the last one-pass launch's kernel time (HIP events on the library's stream) and tiles */
+  uint64_t nway_tiles;
   gt4hip_io *io;            /* file <-> HBM staging (gt4hip_io.hip), NULL until first used */
   char err[512];
   char info[256];
@@ -70,7 +72,7 @@ int gt4hip_fail (gt4hip_context *ctx, int code, const char *fmt, ...);
 hipError_t gt4hip_dev_alloc (gt4hip_context *ctx, void **p, size_t bytes);
 int gt4hip_list_new (gt4hip_context *ctx, uint64_t capacity, uint32_t word_length, gt4hip_list **out);
 void gt4hip_io_destroy (gt4hip_context *ctx);
-int gt4hip_kway_union (gt4hip_context *ctx, const gt4hip_list *const lists[], uint32_t k, uint32_t rule, uint32_t cutoff, uint32_t ovr,
+int gt4hip_nway_union (gt4hip_context *ctx, const gt4hip_list *const lists[], uint32_t k, uint32_t rule, uint32_t cutoff, uint32_t ovr,
                        uint32_t filter, bool count_only, gt4hip_list *out, uint64_t *n_words, uint64_t *total_count, double *device_ms,
                        int *used);
 int gt4hip_io_download (gt4hip_context *ctx, const void *dev, void *host, size_t bytes);

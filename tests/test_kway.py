@@ -1,8 +1,9 @@
-"""The one-pass N-way union (k_kway_merge, genometester4_amd/csrc/gt4hip_kway.hip) against the CPU
+"""The one-pass N-way union (k_nway_merge, genometester4_amd/csrc/gt4hip_nway.hip) against the CPU
 oracle's union_multi (reference src/glistcompare.c:500-603): rules ADD / MAX / NUMBER, cutoff on the
 resulting count, zero counts, u32 wrap, empty members, more than eight lists (levels of eight-way
-merges), tiles that hold one list only, identical lists (every key eight times), the fallback to the
-pairwise tree when a tile would not fit LDS, and the count-only form."""
+merges), tiles that hold one list only, identical lists (every key eight times), clustered keys (the
+tiles' search path), the retry with fewer samples per tile when a tile would not fit LDS, and the
+count-only form."""
 import numpy as np
 import pytest
 
@@ -16,7 +17,7 @@ pytestmark = pytest.mark.gpu
 def ctx():
     from genometester4_amd import capi
     c = capi.Context(0)
-    c.set_option("kway", 1)  # the one-pass kernel is not the default (the pairwise tree measures faster)
+    c.set_option("kway", 1)
     yield c
     c.close()
 
@@ -113,9 +114,43 @@ def test_more_than_eight_lists(ctx, n_lists):
     _check(ctx, lists, rule=4, cutoff=0)
 
 
-def test_tile_overflow_falls_back_to_the_pairwise_tree(ctx):
-    """64 samples per tile = 16384 records expected per tile > the LDS capacity: the partition check
-    refuses, the call takes the pairwise tree and still gives the reference's bytes."""
+def test_every_tile_through_the_search_path(ctx):
+    """Option kway_vt = 99 sends every tile through the path clustered keys take (records back to LDS as
+    sorted runs, positions by lower bounds in all the runs)."""
+    ctx.set_option("kway_vt", 99)
+    try:
+        for n_lists, rule, cutoff in ((3, 0, 1), (8, 4, 2), (5, 7, 3)):
+            rng = np.random.default_rng(4242 + n_lists)
+            _check(ctx, _random_lists(rng, n_lists, 50000), rule=rule, cutoff=cutoff)
+    finally:
+        ctx.set_option("kway_vt", 0)
+
+
+def test_clustered_keys(ctx):
+    """Clusters of adjacent keys 2^40 apart: the interpolation puts a whole cluster into one bucket, the
+    tiles take the search path on their own."""
+    rng = np.random.default_rng(31)
+    centres = np.sort(rng.choice(1 << 22, size=900, replace=False).astype(np.uint64)) << np.uint64(40)
+    keys = np.unique((centres[:, None] + rng.integers(0, 400, size=(900, 150), dtype=np.uint64)).ravel())
+    lists = []
+    for j in range(6):
+        m = rng.random(len(keys)) < 0.5
+        lists.append(U.make_records(keys[m], rng.integers(0, 7, size=int(m.sum()), dtype=np.uint32)))
+    _check(ctx, lists, k=32)
+    _check(ctx, lists, k=32, rule=4, cutoff=3)
+    # one dense cluster inside an otherwise uniform list: only the tiles around it search
+    uni = np.unique(rng.integers(0, 1 << 50, size=200000, dtype=np.uint64))
+    dense = np.arange(1 << 49, (1 << 49) + 30000, dtype=np.uint64)
+    lists = []
+    for j in range(4):
+        k = np.unique(np.concatenate([uni[rng.random(len(uni)) < 0.6], dense[rng.random(len(dense)) < 0.7]]))
+        lists.append(U.make_records(k, rng.integers(1, 9, size=len(k), dtype=np.uint32)))
+    _check(ctx, lists, k=25)
+
+
+def test_tile_overflow_is_retried_with_fewer_samples_per_tile(ctx):
+    """64 samples per tile = 8192 records expected per tile > the LDS capacity: the partition check
+    refuses, the cut is redone with fewer samples per tile; still the reference's bytes."""
     rng = np.random.default_rng(11)
     lists = _random_lists(rng, 5, 300000)
     before = ctx.get_counter("kway_overflows")
