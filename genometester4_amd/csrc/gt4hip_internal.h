@@ -43,7 +43,7 @@ struct PairControl {
   unsigned int error;      /* non-zero: a bounded spin gave up / consistency check tripped */
   unsigned int role;       /* first workgroup to arrive becomes the scanner */
   unsigned int pad;
-  unsigned long long phase_cycles[8];
+  unsigned long long phase_cycles[24];
   unsigned long long resolve_stats[8]; /* diagnostic builds: sampled resolve calls, spins, -, agg/carry not ready at first look; scanner rounds, rows retired on the first look, rows */ /* diagnostic builds (-DGT4_PROFILE_PHASES): shader cycles per phase, summed over workgroups */
 };
 

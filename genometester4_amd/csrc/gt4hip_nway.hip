@@ -179,6 +179,18 @@ __global__ void k_nway_check (const u64 *__restrict__ part, u32 num_tiles, u32 c
 
 /* ------------------------------------------------------------------ K7: the tile kernel */
 
+#ifndef GT4_NWAY_SVPRIO
+#define GT4_NWAY_SVPRIO 3
+#endif
+#ifndef GT4_NWAY_NT
+#define GT4_NWAY_NT 1024
+#endif
+#ifndef GT4_NWAY_RPT
+#define GT4_NWAY_RPT 4
+#endif
+#ifndef GT4_NWAY_NBF
+#define GT4_NWAY_NBF 1
+#endif
 typedef u32 u32x3 __attribute__ ((ext_vector_type (3)));
 
 __device__ __forceinline__ u32 dpp_wave_max_u32 (u32 v)
@@ -201,33 +213,86 @@ struct NwayShared {
   static constexpr int NW = NT / WAVE;
   /* the tile in key order: key and folded count per position -- or, in the fallback, the records
    * as sorted runs (packed 12 bytes at their positions) */
+  /* Records of one list in consecutive lanes lie about as many positions apart in the ordered tile as
+   * there are lists: a power-of-two stride puts 32 lanes on 4 LDS banks.  Grouped keys and ordered tile
+   * are therefore SKEWED: index i lives at i + i / 32 (nway_skew), which spreads every power-of-two
+   * stride over all banks (measured before: 60 % of all LDS cycles were bank conflicts). */
+  static constexpr int CAPS = CAP + CAP / 32;                 /* skewed positions */
+  static constexpr int GSZ = (CAPS + NWAY_LIMIT + 3) & ~1;    /* grouped keys: + the longest bucket walk behind the last key */
   union {
     struct {
-      u64 skey[CAP];
-      u32 scnt[CAP];
+      u64 skey[CAPS];
+      u32 scnt[CAPS];
     } s;
     u32 raw[3 * CAP];
   };
-  u64 g[CAP + NWAY_LIMIT];                 /* keys grouped by bucket (+ all-ones behind the last) */
+  alignas (16) u64 g[GSZ];                 /* keys grouped by bucket; all-ones wherever no key is */
   alignas (16) u32 cnt[NB / 2 + 4];        /* 16-bit bucket counters, then bucket starts, in pairs (+ the total) */
-  alignas (16) u32 live[CAP / 4];          /* one byte per position: a key was stored there */
+  alignas (16) u32 live[(CAPS + 3) / 4];   /* one byte per position: a key was stored there */
   alignas (16) u32 stage[MODE == NWAY_COUNT ? 4 : 3 * CAP + 4]; /* the kept records, packed, written out during the NEXT tile */
   u32 wtot[NW], wmax[NW], wkept[NW];
-  /* the tile being fetched / processed, two deep: one 64-record wave slot per wave-instruction */
-  u64 slot_addr[2][NCH];
-  u32 slot_cnt[2][NCH];
-  u32 tab_pbase[2][NWAY_MAX];              /* first position of each run */
-  u32 tab_len[2][NWAY_MAX];
-  u32 tab_n[2], tab_bk[2][2];              /* records; shift | direct << 8, multiplier */
-  u64 tab_lo[2], tab_base[2];              /* smallest possible key; NWAY_DUPS: where the tile's output starts */
-  u64 rng[3][2 * NWAY_PSTRIDE];            /* partition entries of the next tiles, three deep */
-  u32 tile_id[3];
-  u64 listbase[NWAY_MAX];
+  /* the tiles of this iteration, the next one (being fetched) and the one after (being described),
+   * three deep: one 64-record wave slot per wave-instruction */
+  u64 slot_addr[3][NCH];
+  u32 slot_cnt[3][NCH];
+  u32 tab_pbase[3][NWAY_MAX];              /* first position of each run */
+  u32 tab_len[3][NWAY_MAX];
+  /* tile number (0xffffffff: none), records, wave slots, shift | direct << 8, multiplier, smallest
+   * possible key (2), NWAY_DUPS: where the tile's output starts (2) */
+  alignas (16) u32 hdr[3][12];
   u64 excl;
   u32 tick;
 };
 
 __host__ __device__ constexpr int nway_waves_per_simd (int nt) { return nt >= 1024 ? 4 : (nt >= 512 ? 4 : 4); }
+
+__device__ __forceinline__ u32 nway_skew (u32 i) { return i + (i >> 5); }
+
+/* LDS accesses by byte offset through address-space-3 pointers: the compiler keeps generic pointers for
+ * loop-invariant per-thread addresses otherwise (flat loads, two registers per address) */
+typedef __attribute__ ((address_space (3))) u32 lds_u32;
+typedef __attribute__ ((address_space (3))) u64 lds_u64;
+typedef __attribute__ ((address_space (3))) unsigned char lds_u8;
+template <class T> __device__ __forceinline__ u32 lds_offset (T *p) { return (u32) (uintptr_t) p; }
+
+/* Two steps of four bucket walks: eight INDEPENDENT 8-byte reads, one wait, eight compares.  Inline
+ * assembly because the compiler merges two reads of one walk into a ds_read2_b64 (twice the LDS cycles
+ * of two ds_read_b64: MI355X_MICROARCH.md, LDS table) or, told not to (volatile), waits for every
+ * single read.  The wait is part of the statement: the outputs are valid behind it. */
+template <int J>
+__device__ __forceinline__ void nway_rank_pair (u32 a0, u32 a1, u32 a2, u32 a3, const u64 (&key)[4], u32 (&lt)[4])
+{
+  u64 r0, r1, r2, r3, r4, r5, r6, r7;
+  asm volatile ("ds_read_b64 %0, %8 offset:%12\n\t"
+                "ds_read_b64 %1, %9 offset:%12\n\t"
+                "ds_read_b64 %2, %10 offset:%12\n\t"
+                "ds_read_b64 %3, %11 offset:%12\n\t"
+                "ds_read_b64 %4, %8 offset:%13\n\t"
+                "ds_read_b64 %5, %9 offset:%13\n\t"
+                "ds_read_b64 %6, %10 offset:%13\n\t"
+                "ds_read_b64 %7, %11 offset:%13\n\t"
+                "s_waitcnt lgkmcnt(0)"
+                : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7)
+                : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "n"(8 * J), "n"(8 * J + 8)
+                : "memory");
+  lt[0] += (r0 < key[0] ? 1u : 0u) + (r4 < key[0] ? 1u : 0u);
+  lt[1] += (r1 < key[1] ? 1u : 0u) + (r5 < key[1] ? 1u : 0u);
+  lt[2] += (r2 < key[2] ? 1u : 0u) + (r6 < key[2] ? 1u : 0u);
+  lt[3] += (r3 < key[3] ? 1u : 0u) + (r7 < key[3] ? 1u : 0u);
+}
+
+template <int J>
+__device__ __forceinline__ void nway_rank_steps (u32 mx, u32 a0, u32 a1, u32 a2, u32 a3, const u64 (&key)[4], u32 (&lt)[4])
+{
+  if ((u32) J >= mx) return; /* uniform */
+  nway_rank_pair<J> (a0, a1, a2, a3, key, lt);
+  if constexpr (J + 2 < NWAY_LIMIT) nway_rank_steps<J + 2> (mx, a0, a1, a2, a3, key, lt);
+}
+
+__device__ __forceinline__ u64 readlane_u64 (u64 v, int l)
+{
+  return (u64) (u32) __builtin_amdgcn_readlane ((int) (u32) v, l) | ((u64) (u32) __builtin_amdgcn_readlane ((int) (u32) (v >> 32), l) << 32);
+}
 
 template <int NT, int RPT, int NBF, int MODE>
 __global__ __launch_bounds__ (NT, nway_waves_per_simd (NT)) void
@@ -236,10 +301,13 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
   typedef NwayShared<NT, RPT, NBF, MODE> Shared;
   constexpr int CAP = Shared::CAP, NW = Shared::NW, NCH = Shared::NCH, NB = Shared::NB;
   constexpr int NWORDS = NB / 2, WPT = NWORDS / NT;
+  constexpr int CAPS = Shared::CAPS, GSZ = Shared::GSZ;
   static_assert (NCH <= WAVE, "one lane per wave slot builds the slot table");
   static_assert (WPT * NT == NWORDS && WPT >= 1, "every thread scans the same number of counter words");
   static_assert (NW <= 16 && NW >= 2, "wave totals are reduced by one DPP row");
-  static_assert (CAP <= 65535, "16-bit bucket counters and starts");
+  static_assert (NWAY_LIMIT % 2 == 0, "bucket walks go two steps at a time");
+  static_assert (CAP <= 32767 && NB <= 65536, "16-bit bucket counters and starts; bucket, arrival number and a flag share a dword");
+  static_assert (2 * NWAY_PSTRIDE <= WAVE, "one lane per partition entry of a tile");
   __shared__ Shared sh;
   const int tid = threadIdx.x, lane = tid & (WAVE - 1);
   const int wid = __builtin_amdgcn_readfirstlane (tid / WAVE);
@@ -262,7 +330,17 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
   const u32 n_workers = MODE == NWAY_UNION ? gridDim.x - 1 : gridDim.x;
   const u32 wk = MODE == NWAY_UNION ? role - 1 : blockIdx.x;
   const u32 ntl = p.num_tiles;
-  auto deal = [&] (int j) -> u32 {
+  /* The LAST wavefront is the service wavefront.  Wave slots are dealt to the wavefronts in order (RPT
+   * consecutive slots each), a tile fills 85 % of them on average, so the last wavefront usually has
+   * no records and does what must not sit in front of everybody's barrier: tile numbers (by ticket or
+   * round-robin), partition entries, the slot table two tiles ahead (from registers: no LDS round
+   * trips), the chain words of the tile being written out, the publication of the tile total. */
+  const bool service = wid == NW - 1;
+  /* the SIMD issues oldest-first and the last wavefront is the youngest of its SIMD: without a raised
+   * priority its few instructions crawl behind three ranking wavefronts (measured: 5.7 k cycles for the
+   * slot table alone) and everybody waits for it at the next barrier */
+  if (service) __builtin_amdgcn_s_setprio (GT4_NWAY_SVPRIO);
+  auto deal = [&] (int j) -> u32 { /* lane 0 of the service wavefront */
     if (p.dynamic) {
       const u32 t = atomicAdd (&ctl->ticket, 1u);
       return t < ntl ? t : 0xffffffffu;
@@ -270,48 +348,63 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
     const u64 t = (u64) wk + (u64) j * n_workers;
     return t < (u64) ntl ? (u32) t : 0xffffffffu;
   };
-
-  /* wave 0, one lane per wave slot: where the slot's 64 records lie (ring slot r -> table tb) */
-  auto build_table = [&] (int r, int tb) {
-    u32 len[NWAY_MAX];
-    u32 n = 0;
-    u64 base = 0;
-#pragma unroll
-    for (int q = 0; q < NWAY_MAX; q++) {
-      const u64 s = sh.rng[r][q], e = sh.rng[r][NWAY_PSTRIDE + q];
-      len[q] = (u32) q < p.k ? uniform32 ((u32) (e - s)) : 0u;
-      n += len[q];
-      base += (u32) q < p.k ? uniform64 (s) : 0ull;
+  auto load_row = [&] (u32 tile) -> u64 { /* lane i: entry i of the tile's two partition rows (its start and its end) */
+    u64 v = 0;
+    if (tile < ntl && lane < 2 * NWAY_PSTRIDE)
+      v = __hip_atomic_load (&part[(u64) tile * NWAY_PSTRIDE + (u64) lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return v;
+  };
+  /* the slot table of `tile` (partition entries in `row`, one per lane) into table tb: branch-free
+   * vector code -- run lengths by a lane shift, their prefix by a DPP scan, the run of a slot by
+   * eight compares against broadcast prefixes, the run's data by lane permutes */
+  auto build_table = [&] (u64 row, u32 tile, int tb) {
+    if (tile >= ntl) {
+      if (lane == 0) sh.hdr[tb][0] = 0xffffffffu;
+      return;
     }
-    u32 acc_w = 0, run = 0, first = 0, rl = 0;
-    bool in_any = false;
+    u64 lbv = 0; /* lane q: base address of list q (rebuilt here: two registers less in every wavefront's loop) */
 #pragma unroll
-    for (int q = 0; q < NWAY_MAX; q++) {
-      const u32 nw = (len[q] + WAVE - 1) / WAVE;
-      const bool in = (u32) lane >= acc_w && (u32) lane < acc_w + nw;
-      run = in ? (u32) q : run;
-      first = in ? ((u32) lane - acc_w) * WAVE : first;
-      rl = in ? len[q] : rl;
-      in_any |= in;
-      if (lane == q) {
-        sh.tab_pbase[tb][q] = acc_w * WAVE;
-        sh.tab_len[tb][q] = len[q];
-      }
-      acc_w += nw;
+    for (int m = 0; m < NWAY_MAX; m++) lbv = lane == m ? (u64) p.list[m] : lbv;
+    const u32 rlo = (u32) row, rhi = (u32) (row >> 32);
+    const u32 elo = __shfl_down (rlo, NWAY_PSTRIDE, WAVE);
+    const u32 len = (u32) lane < p.k ? elo - rlo : 0u; /* (p.k <= 8; a run is shorter than 2^32 records) */
+    const u32 nw = (len + WAVE - 1) / WAVE;
+    const u32 incl = dpp_inclusive_scan_u32 (nw), excl = incl - nw;
+    const u32 total = (u32) __builtin_amdgcn_readlane ((int) incl, WAVE - 1);
+    const u32 n = dpp_wave_sum_u32 (len);
+    if (lane < NWAY_MAX) {
+      sh.tab_pbase[tb][lane] = excl * WAVE;
+      sh.tab_len[tb][lane] = len;
     }
+    u32 run = 0;
+#pragma unroll
+    for (int q = 0; q < NWAY_MAX - 1; q++) run += (u32) lane >= (u32) __builtin_amdgcn_readlane ((int) incl, q) ? 1u : 0u;
+    const u32 len_r = __shfl (len, run, WAVE), excl_r = __shfl (excl, run, WAVE);
+    const u64 s_r = (u64) __shfl (rlo, run, WAVE) | ((u64) __shfl (rhi, run, WAVE) << 32);
+    const u64 lb_r = (u64) __shfl ((u32) lbv, run, WAVE) | ((u64) __shfl ((u32) (lbv >> 32), run, WAVE) << 32);
+    const bool in = (u32) lane < total;
+    const u32 first = in ? ((u32) lane - excl_r) * WAVE : 0u;
     if (lane < NCH) {
-      const u32 c = in_any ? (rl - first < (u32) WAVE ? rl - first : (u32) WAVE) : 0u;
-      sh.slot_cnt[tb][lane] = c;
-      sh.slot_addr[tb][lane] = sh.listbase[run] + 12ull * (sh.rng[r][run] + first);
+      sh.slot_cnt[tb][lane] = in ? (len_r - first < (u32) WAVE ? len_r - first : (u32) WAVE) : 0u;
+      sh.slot_addr[tb][lane] = lb_r + 12ull * (s_r + first);
     }
-    if (lane == 0) {
-      sh.tab_n[tb] = acc_w <= (u32) NCH ? n : 0xffffffffu; /* more wave slots than the workgroup has: refused below */
-      sh.tab_lo[tb] = sh.rng[r][NWAY_MAX];
-      const u64 bk = sh.rng[r][NWAY_MAX + 1];
-      sh.tab_bk[tb][0] = (u32) bk;
-      sh.tab_bk[tb][1] = (u32) (bk >> 32);
-      sh.tab_base[tb] = base;
+    u64 base = 0;
+    if (MODE == NWAY_DUPS) {
+#pragma unroll
+      for (int q = 0; q < NWAY_MAX; q++) base += (u32) q < p.k ? readlane_u64 (row, q) : 0ull;
     }
+    const u32 lo_lo = (u32) __builtin_amdgcn_readlane ((int) rlo, NWAY_MAX), lo_hi = (u32) __builtin_amdgcn_readlane ((int) rhi, NWAY_MAX);
+    const u32 bk_lo = (u32) __builtin_amdgcn_readlane ((int) rlo, NWAY_MAX + 1), bk_hi = (u32) __builtin_amdgcn_readlane ((int) rhi, NWAY_MAX + 1);
+    u32 h = tile;
+    h = lane == 1 ? n : h;
+    h = lane == 2 ? total : h;
+    h = lane == 3 ? bk_lo : h;
+    h = lane == 4 ? bk_hi : h;
+    h = lane == 5 ? lo_lo : h;
+    h = lane == 6 ? lo_hi : h;
+    h = lane == 7 ? (u32) base : h;
+    h = lane == 8 ? (u32) (base >> 32) : h;
+    if (lane < 9) sh.hdr[tb][lane] = h;
   };
 
   /* The tile's records, fetched one tile ahead into registers.  A wavefront fetches 64 consecutive
@@ -321,46 +414,34 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
   auto fetch = [&] (int tb) {
 #pragma unroll
     for (int k = 0; k < RPT; k++) {
-      const int chunk = k * NW + wid;
+      const int chunk = wid * RPT + k;
       const u64 addr = uniform64 (sh.slot_addr[tb][chunk]);
       const u32 c = uniform32 (sh.slot_cnt[tb][chunk]);
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc ((void *) addr, 0, (int) (12 * c), 0x00020000);
       pre[k] = __builtin_amdgcn_raw_buffer_load_b96 (rs, 12 * lane, 0, 0);
     }
   };
-  auto load_ring = [&] (u32 tile, int lane_) -> u64 {
-    return __hip_atomic_load (&part[((u64) tile + (u64) (lane_ / NWAY_PSTRIDE)) * NWAY_PSTRIDE + (u64) (lane_ % NWAY_PSTRIDE)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  };
 
-  /* ---- prologue */
-  if (tid < NWAY_MAX) {
-    u64 lb = (u64) p.list[0];
-#pragma unroll
-    for (int m = 1; m < NWAY_MAX; m++) lb = tid == m ? (u64) p.list[m] : lb; /* selects: no dynamic indexing of the kernel arguments */
-    sh.listbase[tid] = lb;
-  }
-  u32 tk_next = 0xffffffffu; /* thread 0: the tile of iteration it + 2 */
-  if (tid == 0) {
-    u32 t3[3];
-    for (int q = 0; q < 3; q++) t3[q] = deal (q);
-    sh.tile_id[0] = t3[0];
-    sh.tile_id[1] = t3[1];
-    tk_next = t3[2];
+  /* ---- prologue: tiles of iterations 0 .. 3, tables of the first two, entries of the third */
+  u32 sv_t2 = 0xffffffffu; /* service wavefront: tile of iteration it + 2 (uniform) */
+  u32 sv_tk = 0xffffffffu; /* ... of iteration it + 3, in lane 0 (a ticket drawn one iteration ago) */
+  u64 sv_row = 0;          /* partition entries of tile sv_t2, asked for one iteration ago */
+  if (service) {
+    u32 d[4] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu };
+    if (lane == 0)
+      for (int q = 0; q < 4; q++) d[q] = deal (q);
+    const u32 d0 = uniform32 (d[0]), d1 = uniform32 (d[1]);
+    sv_t2 = uniform32 (d[2]);
+    sv_tk = d[3];
+    const u64 r0 = load_row (d0), r1 = load_row (d1);
+    sv_row = load_row (sv_t2);
+    build_table (r0, d0, 0);
+    build_table (r1, d1, 1);
   }
 #pragma unroll
   for (int i = 0; i < WPT; i++) sh.cnt[tid * WPT + i] = 0;
   __syncthreads ();
-  if (wid == 0 && lane < 2 * NWAY_PSTRIDE) {
-    for (int q = 0; q < 2; q++) {
-      const u32 t = sh.tile_id[q];
-      if (t < ntl) sh.rng[q][lane] = load_ring (t, lane);
-    }
-  }
-  __syncthreads ();
-  u32 cur = uniform32 (sh.tile_id[0]);
-  if (wid == 0 && cur < ntl) build_table (0, 0);
-  __syncthreads ();
-  if (cur < ntl) fetch (0);
+  if (uniform32 (sh.hdr[0][0]) < ntl && (u32) (wid * RPT) < uniform32 (sh.hdr[0][2])) fetch (0);
 
   u64 acc_sum = 0; /* per-thread sum of kept counts */
   u64 blk_cnt = 0; /* records kept (the same in every thread) */
@@ -368,69 +449,81 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
   u64 pend_base = 0;
   bool pend = false;
   int it = 0;
-  int r_nxt = 1, r_nn = 2;
+  int tb = 0, tb1 = 1, tb2 = 2; /* tables of this tile, the next, the one after */
 #ifdef GT4_PROFILE_PHASES
-  u64 ph[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+  u64 ph[24];
+  for (int i = 0; i < 24; i++) ph[i] = 0;
   u64 t_last;
   asm volatile ("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_last) :: "memory");
 #endif
 
-  while (cur < ntl) {
-    const int tb = it & 1;
-    const u32 n = uniform32 (sh.tab_n[tb]);
-    if (n > (u32) CAP) {
+  for (;;) {
+    u32 cur, n, slots, bk0, bk_mul;
+    u64 key_lo, out_base;
+    {
+      const u32x4 h0 = *reinterpret_cast<const u32x4 *> (&sh.hdr[tb][0]), h1 = *reinterpret_cast<const u32x4 *> (&sh.hdr[tb][4]);
+      const u32 h8 = sh.hdr[tb][8];
+      cur = uniform32 (h0.x);
+      n = uniform32 (h0.y);
+      slots = uniform32 (h0.z);
+      bk0 = uniform32 (h0.w);
+      bk_mul = uniform32 (h1.x);
+      key_lo = (u64) uniform32 (h1.y) | ((u64) uniform32 (h1.z) << 32);
+      out_base = (u64) uniform32 (h1.w) | ((u64) uniform32 (h8) << 32);
+    }
+    if (cur >= ntl) break;
+    if (n > (u32) CAP || slots > (u32) NCH) {
       if (tid == 0) atomicOr (&ctl->error, 2u);
       break;
     }
-    const u64 key_lo = uniform64 (sh.tab_lo[tb]);
-    const u32 bk0 = uniform32 (sh.tab_bk[tb][0]), bk_mul = uniform32 (sh.tab_bk[tb][1]);
     const u32 bk_sh = bk0 & 0xffu;
     const bool bk_direct = (bk0 >> 8) & 1u;
-    const u64 out_base = uniform64 (sh.tab_base[tb]);
+    const bool has_rec = (u32) (wid * RPT) < slots;          /* this wavefront holds records of the tile */
+    const bool has_pos = (u32) (wid * RPT * WAVE) < n;       /* ... positions of the ordered tile */
 
     /* ---- phase 0: the prefetched records: bucket number, arrival number (one LDS atomic) */
     u64 key[RPT];
-    u32 cnt[RPT], bkt[RPT], arr[RPT];
-    bool valid[RPT];
+    u32 cnt[RPT], ba[RPT]; /* ba: bucket | arrival number << 16 | valid << 31 */
 #pragma unroll
     for (int k = 0; k < RPT; k++) {
-      const int chunk = k * NW + wid;
-      const u32 c = uniform32 (sh.slot_cnt[tb][chunk]);
-      valid[k] = (u32) lane < c;
-      key[k] = (u64) pre[k].x | ((u64) pre[k].y << 32);
-      cnt[k] = pre[k].z;
-      const u32 v = (u32) ((key[k] - key_lo) >> bk_sh);
-      u32 b = bk_direct ? v : __umulhi (v, bk_mul);
-      b = b < (u32) NB ? b : (u32) NB - 1u;
-      bkt[k] = b;
-      arr[k] = 0;
-      if (valid[k]) {
-        const u32 s16 = (b & 1u) * 16u;
-        const u32 old = atomicAdd (&sh.cnt[b >> 1], 1u << s16);
-        arr[k] = (old >> s16) & 0xffffu;
+      key[k] = 0;
+      cnt[k] = ba[k] = 0;
+    }
+    if (has_rec) {
+#pragma unroll
+      for (int k = 0; k < RPT; k++) {
+        const int chunk = wid * RPT + k;
+        const u32 c = uniform32 (sh.slot_cnt[tb][chunk]);
+        key[k] = (u64) pre[k].x | ((u64) pre[k].y << 32);
+        cnt[k] = pre[k].z;
+        const u32 v = (u32) ((key[k] - key_lo) >> bk_sh);
+        u32 b = bk_direct ? v : __umulhi (v, bk_mul);
+        b = b < (u32) NB ? b : (u32) NB - 1u;
+        if ((u32) lane < c) {
+          const u32 s16 = (b & 1u) * 16u;
+          const u32 old = atomicAdd (&sh.cnt[b >> 1], 1u << s16);
+          ba[k] = b | (((old >> s16) & 0x7fffu) << 16) | 0x80000000u;
+        }
       }
     }
-    /* own positions (RPT consecutive ones per thread) of the ordered tile: counts 0, nothing live */
-#pragma unroll
-    for (int i = 0; i < RPT; i++) sh.s.scnt[tid * RPT + i] = 0;
-    if (RPT == 4) sh.live[tid] = 0;
-    else
-      for (int i = tid; i < CAP / 4; i += NT) sh.live[i] = 0;
-    /* housekeeping by wavefront 0: the tile of iteration it + 2 (its partition entries are consumed at
-     * the end of this iteration), the slot table of the next tile */
-    u32 hk_tile = 0xffffffffu;
-    u64 hk = 0;
-    u32 nxt = 0xffffffffu;
-    if (wid == 0) {
-      hk_tile = uniform32 (tk_next);
-      if (tid == 0) tk_next = deal (it + 3);
-      if (hk_tile < ntl && lane < 2 * NWAY_PSTRIDE) hk = load_ring (hk_tile, lane);
-      nxt = uniform32 (sh.tile_id[r_nxt]);
-      if (nxt < ntl) build_table (r_nxt, tb ^ 1);
+    /* the ordered tile: counts 0, nothing live; the grouped keys: all-ones (what a bucket walk meets
+     * behind its bucket must not be smaller than any key) */
+    for (int i = 4 * tid; i < CAPS; i += 4 * NT) *reinterpret_cast<u32x4 *> (&sh.s.scnt[i]) = u32x4 { 0, 0, 0, 0 };
+    for (int i = tid; i < (CAPS + 3) / 4; i += NT) sh.live[i] = 0;
+    for (int i = 2 * tid; i < GSZ; i += 2 * NT) *reinterpret_cast<u32x4 *> (&sh.g[i]) = u32x4 { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu };
+    /* service: the chain words of the tile staged one iteration ago are asked for; they are looked at
+     * behind B4 at the earliest (the memory counter retires in order: a look waits for every older
+     * operation of this wavefront, the previous write-out's stores included) */
+    u32 xagg = 0;
+    u64 xcarry = 0;
+    if (service && MODE == NWAY_UNION && pend) {
+      const u64 prow = pend_tile / WAVE;
+      if ((u32) lane < pend_tile % WAVE) xagg = peek_u32 (&agg[prow * WAVE + lane]);
+      xcarry = peek_u64 (&carry[prow]);
     }
     PHASE_STAMP (0);
     __syncthreads (); /* B1: every record is counted */
-    nxt = uniform32 (sh.tile_id[r_nxt]);
+    PHASE_STAMP (1);
 
     /* ---- scan of the bucket counters: WPT words (two 16-bit counters each) per thread */
     u32 ex[2 * WPT];
@@ -456,8 +549,9 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
       sh.wtot[wid] = incl;
       sh.wmax[wid] = wmx;
     }
-    PHASE_STAMP (1);
+    PHASE_STAMP (2);
     __syncthreads (); /* B2: wave totals */
+    PHASE_STAMP (3);
     u32 mx;
     {
       const u32 x = lane < NW ? sh.wtot[lane] : 0u;
@@ -469,61 +563,70 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
       for (int i = 0; i < WPT; i++) sh.cnt[tid * WPT + i] = (tbase + ex[2 * i]) | ((tbase + ex[2 * i + 1]) << 16);
       if (tid == NT - 1) sh.cnt[NWORDS] = tbase + tsum; /* start of the bucket behind the last = the tile's records */
     }
-    /* the chain words of the tile written out below, asked for ahead of the next tile's records (the
-     * memory counter retires in order) and looked at behind the rank loop */
-    u32 xagg = 0;
-    u64 xcarry = 0;
-    if (MODE == NWAY_UNION && pend && wid == NW - 1) {
-      const u64 prow = pend_tile / WAVE;
-      if ((u32) lane < pend_tile % WAVE) xagg = peek_u32 (&agg[prow * WAVE + lane]);
-      xcarry = peek_u64 (&carry[prow]);
-    }
-    if (nxt < ntl) fetch (tb ^ 1);
-    PHASE_STAMP (2);
+    /* the next tile's records */
+    const u32 nxt = uniform32 (sh.hdr[tb1][0]);
+    if (nxt < ntl && (u32) (wid * RPT) < uniform32 (sh.hdr[tb1][2])) fetch (tb1);
+    PHASE_STAMP (4);
     __syncthreads (); /* B3: bucket starts */
+    PHASE_STAMP (5);
 
     /* ---- the keys grouped by bucket */
     u32 st[RPT];
 #pragma unroll
-    for (int k = 0; k < RPT; k++) {
-      const u32 w0 = sh.cnt[bkt[k] >> 1];
-      const u32 s = (bkt[k] & 1u) ? w0 >> 16 : w0; /* start of the bucket */
-      st[k] = valid[k] ? (s & 0xffffu) : 0u;
-      if (valid[k]) sh.g[st[k] + arr[k]] = key[k];
+    for (int k = 0; k < RPT; k++) st[k] = 0;
+    if (has_rec) {
+#pragma unroll
+      for (int k = 0; k < RPT; k++) {
+        const u32 b = ba[k] & 0xffffu;
+        const u32 w0 = sh.cnt[b >> 1];
+        const u32 s = (b & 1u) ? w0 >> 16 : w0; /* start of the bucket */
+        st[k] = (ba[k] >> 31) ? (s & 0xffffu) : 0u;
+        if (ba[k] >> 31) sh.g[nway_skew (st[k]) + ((ba[k] >> 16) & 0x7fffu)] = key[k]; /* a bucket's keys stay together */
+      }
     }
-    if (tid < NWAY_LIMIT) sh.g[n + tid] = ~0ull;
-    PHASE_STAMP (3);
+    PHASE_STAMP (6);
     __syncthreads (); /* B4: keys grouped */
+    PHASE_STAMP (7);
 #pragma unroll
     for (int i = 0; i < WPT; i++) sh.cnt[tid * WPT + i] = 0; /* the next tile's counters */
 
     /* ---- position of every record = number of smaller keys in the tile */
     u32 pos[RPT];
+#pragma unroll
+    for (int k = 0; k < RPT; k++) pos[k] = 0;
     if (mx <= (u32) NWAY_LIMIT && !p.force_fallback) {
-      u32 lt[RPT];
+      if (has_rec) {
+        u32 lt[RPT], ga[RPT];
+        const u32 g0 = lds_offset (&sh.g[0]);
 #pragma unroll
-      for (int k = 0; k < RPT; k++) lt[k] = 0;
-      /* every lane runs the longest bucket's length: behind its own bucket a lane meets larger keys */
+        for (int k = 0; k < RPT; k++) {
+          lt[k] = 0;
+          ga[k] = g0 + 8u * nway_skew (st[k]);
+        }
+        /* every lane runs the longest bucket's length (rounded up to even): behind its own bucket a lane
+         * meets larger keys or all-ones */
+        if constexpr (RPT == 4) {
+          nway_rank_steps<0> (mx, ga[0], ga[1], ga[2], ga[3], key, lt);
+        } else {
+          for (u32 j = 0; j < mx; j++) {
 #pragma unroll
-      for (int j = 0; j < NWAY_LIMIT; j++) {
-        if ((u32) j >= mx) break; /* uniform */
+            for (int k = 0; k < RPT; k++) lt[k] += *(lds_u64 *) (ga[k] + 8u * j) < key[k] ? 1u : 0u;
+          }
+        }
 #pragma unroll
-        for (int k = 0; k < RPT; k++) lt[k] += sh.g[st[k] + j] < key[k] ? 1u : 0u;
+        for (int k = 0; k < RPT; k++) pos[k] = st[k] + lt[k];
       }
-#pragma unroll
-      for (int k = 0; k < RPT; k++) pos[k] = st[k] + lt[k];
     } else {
       /* clustered keys: the records back to LDS as the sorted runs they came as, and every record adds
        * up its lower bounds in all the runs */
 #pragma unroll
       for (int k = 0; k < RPT; k++) {
-        const u32 q = (u32) (k * NW + wid) * WAVE + (u32) lane;
-        if (valid[k]) {
+        const u32 q = (u32) (wid * RPT + k) * WAVE + (u32) lane;
+        if (ba[k] >> 31) {
           sh.raw[3 * q] = (u32) key[k];
           sh.raw[3 * q + 1] = (u32) (key[k] >> 32);
           sh.raw[3 * q + 2] = cnt[k];
         }
-        pos[k] = 0;
       }
       __syncthreads ();
       for (u32 q = 0; q < p.k; q++) {
@@ -551,60 +654,109 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
         for (int k = 0; k < RPT; k++) pos[k] += lo[k];
       }
       __syncthreads ();
-#pragma unroll
-      for (int i = 0; i < RPT; i++) sh.s.scnt[tid * RPT + i] = 0; /* (the runs lay over the counts) */
+      for (int i = 4 * tid; i < CAPS; i += 4 * NT) *reinterpret_cast<u32x4 *> (&sh.s.scnt[i]) = u32x4 { 0, 0, 0, 0 }; /* (the runs lay over the counts) */
       __syncthreads ();
     }
+    PHASE_STAMP (8);
 
     /* ---- the key once per position, the counts folded by LDS atomics */
+    if (has_rec) {
 #pragma unroll
-    for (int k = 0; k < RPT; k++) {
-      if (!valid[k]) continue;
-      u32 q = pos[k];
-      if (MODE == NWAY_DUPS) q += atomicAdd (&sh.s.scnt[q], 1u); /* equal sample keys: one position each */
-      else if (p.rule == 1u) atomicAdd (&sh.s.scnt[q], cnt[k]);
-      else if (p.rule == 4u) atomicMax (&sh.s.scnt[q], cnt[k]);
-      sh.s.skey[q] = key[k];
-      reinterpret_cast<unsigned char *> (sh.live)[q] = 1;
+      for (int k = 0; k < RPT; k++) {
+        if (!(ba[k] >> 31)) continue;
+        u32 q = nway_skew (pos[k]);
+        if (MODE == NWAY_DUPS) q = nway_skew (pos[k] + atomicAdd (&sh.s.scnt[q], 1u)); /* equal sample keys: one position each */
+        else if (p.rule == 1u) atomicAdd (&sh.s.scnt[q], cnt[k]);
+        else if (p.rule == 4u) atomicMax (&sh.s.scnt[q], cnt[k]);
+        sh.s.skey[q] = key[k];
+        reinterpret_cast<unsigned char *> (sh.live)[q] = 1;
+      }
     }
-    if (MODE == NWAY_UNION && pend && wid == NW - 1) {
-      const u64 x = resolve_offset (agg, carry, pend_tile, lane, xagg, xcarry, ctl, spin_limit);
-      if (lane == 0) sh.excl = 12 * x; /* bytes */
+    PHASE_STAMP (9);
+    /* ---- service window (the other wavefronts are ranking): the table of the tile two iterations
+     * ahead from the entries asked for one iteration ago, the ticket drawn then, new requests -- and
+     * the previous tile leaves its staging area as soon as the chain has its offset: only this
+     * wavefront ever waits for the chain, and not before everybody else stands at B6 */
+    bool wo_done = !(MODE != NWAY_COUNT && pend);
+    auto write_out = [&] (u64 excl_bytes) {
+      const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc ((void *) (reinterpret_cast<char *> (out) + excl_bytes), 0, (int) (12 * pend_tot), 0x00020000);
+      const u32 chunks = (3 * pend_tot + 3) >> 2;
+      for (u32 c0 = 0; c0 < chunks; c0 += 4 * WAVE) {
+        u32x4 w[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const u32 c = c0 + (u32) u * WAVE + (u32) lane;
+          w[u] = *reinterpret_cast<const u32x4 *> (sh.stage + 4 * (c < chunks ? c : chunks - 1u));
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) __builtin_amdgcn_raw_buffer_store_b128 (w[u], r, 16 * (c0 + (u32) u * WAVE + (u32) lane), 0, 0);
+      }
+      wo_done = true;
+    };
+    if (service) {
+      PHASE_STAMP (16);
+      build_table (sv_row, sv_t2, tb2);
+      PHASE_STAMP (17);
+      const u32 t3 = uniform32 (sv_tk);
+      sv_t2 = t3;
+      sv_row = load_row (t3);
+      if (lane == 0) sv_tk = deal (it + 4);
+      PHASE_STAMP (18);
+      if (!wo_done) {
+        if (MODE == NWAY_UNION) {
+          const bool mine = (u32) lane < pend_tile % WAVE;
+          if (__all (!mine || (xagg & AGG_READY) != 0) && (xcarry & CARRY_READY)) {
+            write_out (12 * ((xcarry & ~CARRY_READY) + dpp_wave_sum_u32 (mine ? (xagg & ~AGG_READY) : 0u)));
+          } else {
+            /* not yet: ask again, look again behind B5 */
+            const u64 prow = pend_tile / WAVE;
+            if (mine && !(xagg & AGG_READY)) xagg = peek_u32 (&agg[prow * WAVE + lane]);
+            if (!(xcarry & CARRY_READY)) xcarry = peek_u64 (&carry[prow]);
+          }
+        } else {
+          write_out (12 * pend_base);
+        }
+      }
+      PHASE_STAMP (19);
     }
-    PHASE_STAMP (4);
+    PHASE_STAMP (10);
     __syncthreads (); /* B5: the tile in key order */
+    PHASE_STAMP (11);
+    if (service && !wo_done) write_out (12 * resolve_offset (agg, carry, pend_tile, lane, xagg, xcarry, ctl, spin_limit));
+    PHASE_STAMP (12);
 
-    /* the previous tile leaves its staging area */
-    if (MODE != NWAY_COUNT && pend) {
-      constexpr int WK = (3 * CAP / 4 + NT - 1) / NT;
-      write_out_fixed<NT, WK> (out, MODE == NWAY_UNION ? uniform64 (sh.excl) : 12 * pend_base, pend_tot, sh.stage, tid);
-    }
-
-    /* ---- positions in order (RPT consecutive ones per thread): keep test, compaction */
+    /* ---- positions in order, one per lane (a wavefront walks its RPT chunks of 64): keep test, ballots */
     u64 okey[RPT];
     u32 ocnt[RPT];
-    u32 keep_bits = 0;
-    {
-      const u32 lv = RPT == 4 ? sh.live[tid] : 0u;
+    u32 keep_bits = 0, wave_kept = 0;
+    u32 kpre[RPT]; /* kept in the wavefront's earlier chunks (uniform) */
+#pragma unroll
+    for (int i = 0; i < RPT; i++) {
+      okey[i] = 0;
+      ocnt[i] = 0;
+      kpre[i] = 0;
+    }
+    if (has_pos) {
 #pragma unroll
       for (int i = 0; i < RPT; i++) {
-        const u32 q = (u32) tid * RPT + (u32) i;
-        const bool on = RPT == 4 ? ((lv >> (8 * i)) & 0xffu) != 0 : reinterpret_cast<const unsigned char *> (sh.live)[q] != 0;
-        okey[i] = sh.s.skey[q];
-        u32 f = sh.s.scnt[q];
+        const u32 q = nway_skew ((u32) (wid * RPT + i) * WAVE + (u32) lane);
+        const bool on = *(lds_u8 *) (lds_offset (&sh.live[0]) + q) != 0;
+        okey[i] = *(lds_u64 *) (lds_offset (&sh.s.skey[0]) + 8u * q);
+        u32 f = *(lds_u32 *) (lds_offset (&sh.s.scnt[0]) + 4u * q);
         if (MODE == NWAY_DUPS) f = 0;
         else if (p.rule == 7u) f = p.count_override;
         ocnt[i] = f;
-        const bool keep = on && (MODE == NWAY_DUPS || p.filter == FILTER_RAW || f >= p.cutoff);
+        const bool keep = on & (MODE == NWAY_DUPS || p.filter == FILTER_RAW || f >= p.cutoff);
         keep_bits |= keep ? 1u << i : 0u;
         acc_sum += keep ? f : 0u;
+        kpre[i] = wave_kept;
+        wave_kept += (u32) __popcll (__builtin_amdgcn_ballot_w64 (keep));
       }
     }
-    const u32 kc = (u32) __builtin_popcount (keep_bits);
-    const u32 kincl = dpp_inclusive_scan_u32 (kc);
-    if (lane == WAVE - 1) sh.wkept[wid] = kincl;
-    PHASE_STAMP (5);
+    if (lane == 0) sh.wkept[wid] = wave_kept;
+    PHASE_STAMP (13);
     __syncthreads (); /* B6: kept per wavefront; the staging area is free */
+    PHASE_STAMP (14);
     u32 tile_total;
     {
       const u32 x = lane < NW ? sh.wkept[lane] : 0u;
@@ -612,18 +764,19 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
       tile_total = (u32) __builtin_amdgcn_readlane ((int) incl2, WAVE - 1);
       const u32 wbase = dpp_wave_sum_u32 (lane < wid ? x : 0u);
       blk_cnt += tile_total;
-      if (MODE == NWAY_UNION && wid == 0) {
+      if (MODE == NWAY_UNION && service) {
         if (lane == 0) publish_u32 (&agg[cur], AGG_READY | tile_total);
       }
-      if (MODE != NWAY_COUNT) {
-        u32 slot = wbase + kincl - kc;
+      if (MODE != NWAY_COUNT && wave_kept) {
 #pragma unroll
         for (int i = 0; i < RPT; i++) {
-          if ((keep_bits >> i) & 1u) {
+          const bool keep = (keep_bits >> i) & 1u;
+          const u64 m = __builtin_amdgcn_ballot_w64 (keep);
+          const u32 slot = wbase + kpre[i] + __builtin_amdgcn_mbcnt_hi ((u32) (m >> 32), __builtin_amdgcn_mbcnt_lo ((u32) m, 0u));
+          if (keep) {
             sh.stage[3 * slot] = (u32) okey[i];
             sh.stage[3 * slot + 1] = (u32) (okey[i] >> 32);
             sh.stage[3 * slot + 2] = ocnt[i];
-            slot++;
           }
         }
       }
@@ -632,22 +785,18 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
     pend_tot = tile_total;
     pend_tile = cur;
     pend_base = out_base;
-    if (wid == 0) {
-      if (hk_tile < ntl && lane < 2 * NWAY_PSTRIDE) sh.rng[r_nn][lane] = hk;
-      if (lane == 0) sh.tile_id[r_nn] = hk_tile;
-    }
-    PHASE_STAMP (6);
-    cur = nxt;
+    PHASE_STAMP (15);
     it++;
     {
-      const int r_cur = r_nxt;
-      r_nxt = r_nn;
-      r_nn = r_cur == 0 ? 2 : r_cur - 1;
+      const int t0 = tb;
+      tb = tb1;
+      tb1 = tb2;
+      tb2 = t0;
     }
   }
 #ifdef GT4_PROFILE_PHASES
   if (tid == GT4_STAMP_TID)
-    for (int i = 0; i < 8; i++) atomicAdd (&ctl->phase_cycles[i], ph[i]);
+    for (int i = 0; i < 24; i++) atomicAdd (&ctl->phase_cycles[i], ph[i]);
 #endif
   /* drain: the last tile is still staged */
   if (MODE != NWAY_COUNT && pend) {
@@ -666,15 +815,6 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
   }
 }
 
-#ifndef GT4_NWAY_NT
-#define GT4_NWAY_NT 1024
-#endif
-#ifndef GT4_NWAY_RPT
-#define GT4_NWAY_RPT 4
-#endif
-#ifndef GT4_NWAY_NBF
-#define GT4_NWAY_NBF 2
-#endif
 constexpr int NWAY_NT = GT4_NWAY_NT;
 constexpr int NWAY_RPT = GT4_NWAY_RPT;
 constexpr int NWAY_NBF = GT4_NWAY_NBF;
@@ -917,11 +1057,11 @@ int gt4hip_nway_union (gt4hip_context *ctx, const gt4hip_list *const lists[], ui
     if (l == 0) {
 #ifdef GT4_PROFILE_PHASES
       {
-        static const char *names[8] = { "wait+bucket+atomic", "B1+scan", "B2+starts+fetch", "B3+group", "B4+rank+fold+resolve", "B5+writeout+order", "B6+stage", "-" };
+        static const char *names[24] = { "p0 wait+bucket+atomic+zero", "B1", "scan1", "B2", "scan2+fetch issue", "B3", "group", "B4", "clear+rank", "fold", "service", "B5", "writeout", "order", "B6", "stage+publish", "sv:-", "sv:table", "sv:ticket+row", "sv:try writeout", "-", "-", "-", "-" };
         unsigned long long tot = 0;
-        for (int i = 0; i < 8; i++) tot += ctx->ctl_host->phase_cycles[i];
+        for (int i = 0; i < 24; i++) tot += ctx->ctl_host->phase_cycles[i];
         fprintf (stderr, "[nway phases] tiles %llu:", (unsigned long long) tiles);
-        for (int i = 0; i < 8; i++) fprintf (stderr, " %s %.1f%%", names[i], tot ? 100.0 * ctx->ctl_host->phase_cycles[i] / tot : 0.0);
+        for (int i = 0; i < 20; i++) fprintf (stderr, " %s %.1f%%", names[i], tot ? 100.0 * ctx->ctl_host->phase_cycles[i] / tot : 0.0);
         fprintf (stderr, " | avg cycles/tile %.0f\n", tiles ? (double) tot / tiles : 0.0);
       }
 #endif
