@@ -89,7 +89,7 @@ extern "C" int gt4hip_create (int device, gt4hip_context **out)
     const char *e = getenv ("GT4HIP_DYNAMIC"); /* diagnostic: the whole test-suite through the other dealing */
     ctx->dynamic = e ? atoi (e) : 0; /* 0: automatic */
   }
-  ctx->kway_enabled = 0; /* measured slower than the pairwise tree (DESIGN.md, N-way): option "kway" = 1 selects it */
+  ctx->kway_enabled = 1; /* N-way unions of three lists or more take the one-pass tile kernel (gt4hip_nway.hip); option "kway": 0 the pairwise tree, 2 also two lists */
   snprintf (ctx->info, sizeof ctx->info, "%s|%s|%d|%zu", prop.name, prop.gcnArchName, prop.multiProcessorCount, prop.totalGlobalMem);
   if ((e = hipStreamCreateWithFlags (&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
     delete ctx->pool;
@@ -163,7 +163,7 @@ extern "C" int gt4hip_set_option (gt4hip_context *ctx, const char *name, int64_t
   else if (!strcmp (name, "grid")) ctx->grid_override = value;
   else if (!strcmp (name, "scan_group")) ctx->scan_group = (int) value;
   else if (!strcmp (name, "dynamic")) ctx->dynamic = (int) value;
-  else if (!strcmp (name, "kway")) ctx->kway_enabled = value != 0;
+  else if (!strcmp (name, "kway")) ctx->kway_enabled = (int) value;
   else if (!strcmp (name, "kway_g")) ctx->kway_g = value;
   else if (!strcmp (name, "kway_vt")) ctx->kway_vt = value;
   else if (!strcmp (name, "spin_limit")) ctx->spin_limit = value > 0 ? (uint32_t) value : 0u;
@@ -912,7 +912,7 @@ extern "C" int gt4hip_union_multi (gt4hip_context *ctx, const gt4hip_list *const
     if (lists[j]->n_words) work.push_back (lists[j]); /* :525-532 empty lists are dropped */
   const uint32_t wl = lists[0]->word_length;
   if (work.empty ()) return empty_result (ctx, wl, count_only != 0, res);
-  if (ctx->kway_enabled && work.size () >= 3) {
+  if (ctx->kway_enabled && work.size () >= (ctx->kway_enabled >= 2 ? 2u : 3u)) {
     int done = 0;
     const int krc = union_multi_kway (ctx, work, (uint32_t) rule, cutoff, ovr, count_only != 0, res, &done);
     if (krc || done) return krc;

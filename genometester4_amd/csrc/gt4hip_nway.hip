@@ -73,15 +73,27 @@ struct NwayParams {
   u32 num_tiles;
   u32 dynamic;         /* tiles by ticket (ctl->ticket) instead of round-robin */
   u32 force_fallback;  /* tests: every tile takes the search path */
+  u32 scan_group;      /* the scanner workgroup as summers + chainer (launches with very many rows) */
 };
 
 /* ------------------------------------------------------------------ K5 / K6: samples and tile boundaries */
 
-__global__ void k_nway_sample (const u32 *__restrict__ list, u64 n_samples, u32 *__restrict__ out)
+/* every S-th key of every list of `lo` (the last key of every full block of S records) -> the lists of `up` */
+__global__ void k_nway_sample (NwayParams lo, NwayParams up)
 {
+  u64 total = 0;
+  for (u32 i = 0; i < up.k; i++) total += up.n[i];
   const u64 step = (u64) gridDim.x * blockDim.x;
-  for (u64 j = (u64) blockIdx.x * blockDim.x + threadIdx.x; j < n_samples; j += step) {
-    const u64 src = (j + 1) * NWAY_SAMPLE - 1; /* the last key of every full block of S records */
+  for (u64 g = (u64) blockIdx.x * blockDim.x + threadIdx.x; g < total; g += step) {
+    u64 j = g;
+    u32 i = 0;
+    while (j >= up.n[i]) {
+      j -= up.n[i];
+      i++;
+    }
+    const u32 *__restrict__ list = lo.list[i];
+    u32 *__restrict__ out = const_cast<u32 *> (up.list[i]);
+    const u64 src = (j + 1) * NWAY_SAMPLE - 1;
     out[3 * j] = list[3 * src];
     out[3 * j + 1] = list[3 * src + 1];
     out[3 * j + 2] = 0;
@@ -101,12 +113,19 @@ __device__ __forceinline__ u64 nway_boundary_key (const u32 *__restrict__ merged
  * keys of different lists therefore always meet in one tile.
  * part[t][8]: the smallest key tile t can hold; part[t][9]: shift | direct << 8 | multiplier << 32 of
  * its bucket function (see nway_bucket). */
-__global__ void k_nway_partition (NwayParams p, const u32 *__restrict__ merged, u64 m_total, u32 G, u32 n_buckets, u64 *__restrict__ part)
+/* Two passes, as the pair kernel's partition: pass 0 searches every NWAY_COARSE-th boundary in the whole
+ * lists, pass 1 the others between their coarse neighbours (the cuts are monotone in the boundary
+ * key): half the dependent reads, and neighbouring threads probe the same few cache lines. */
+constexpr u64 NWAY_COARSE = 64;
+
+__global__ void k_nway_partition (NwayParams p, const u32 *__restrict__ merged, u64 m_total, u32 G, u32 n_buckets, u64 *__restrict__ part, int pass)
 {
   const u64 id = (u64) blockIdx.x * blockDim.x + threadIdx.x;
   const u64 t = id / NWAY_PSTRIDE;
   const u32 i = (u32) (id % NWAY_PSTRIDE);
   if (t > p.num_tiles) return;
+  const bool coarse = t % NWAY_COARSE == 0 || t == p.num_tiles;
+  if (i < NWAY_MAX ? (pass == 0) != coarse : pass != 0) return; /* (the tiles' key ranges need no search: pass 0) */
   u64 v = 0;
   if (i < NWAY_MAX) {
     if (i >= p.k || t == 0) {
@@ -117,6 +136,11 @@ __global__ void k_nway_partition (NwayParams p, const u32 *__restrict__ merged, 
       const u64 x = nway_boundary_key (merged, m_total, G, p.num_tiles, t);
       const u32 *__restrict__ L = p.list[i];
       u64 lo = 0, hi = p.n[i];
+      if (!coarse) {
+        const u64 t0 = t - t % NWAY_COARSE, t1 = t0 + NWAY_COARSE < (u64) p.num_tiles ? t0 + NWAY_COARSE : (u64) p.num_tiles;
+        lo = part[t0 * NWAY_PSTRIDE + i];
+        hi = part[t1 * NWAY_PSTRIDE + i];
+      }
       while (lo < hi) {
         const u64 mid = (lo + hi) >> 1;
         if (load_key (L, mid) <= x) lo = mid + 1;
@@ -179,9 +203,13 @@ __global__ void k_nway_check (const u64 *__restrict__ part, u32 num_tiles, u32 c
 
 /* ------------------------------------------------------------------ K7: the tile kernel */
 
+#ifndef GT4_NWAY_WALK
+#define GT4_NWAY_WALK 0 /* 1: the bucket walks read two steps ahead (measured slower: the walk is not what the tile waits for) */
+#endif
 #ifndef GT4_NWAY_SVPRIO
 #define GT4_NWAY_SVPRIO 3
 #endif
+
 #ifndef GT4_NWAY_NT
 #define GT4_NWAY_NT 1024
 #endif
@@ -218,7 +246,7 @@ struct NwayShared {
    * are therefore SKEWED: index i lives at i + i / 32 (nway_skew), which spreads every power-of-two
    * stride over all banks (measured before: 60 % of all LDS cycles were bank conflicts). */
   static constexpr int CAPS = CAP + CAP / 32;                 /* skewed positions */
-  static constexpr int GSZ = (CAPS + NWAY_LIMIT + 3) & ~1;    /* grouped keys: + the longest bucket walk behind the last key */
+  static constexpr int GSZ = (CAPS + NWAY_LIMIT + 5) & ~1;    /* grouped keys: + the longest bucket walk behind the last key */
   union {
     struct {
       u64 skey[CAPS];
@@ -254,6 +282,10 @@ typedef __attribute__ ((address_space (3))) u32 lds_u32;
 typedef __attribute__ ((address_space (3))) u64 lds_u64;
 typedef __attribute__ ((address_space (3))) unsigned char lds_u8;
 template <class T> __device__ __forceinline__ u32 lds_offset (T *p) { return (u32) (uintptr_t) p; }
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wint-to-pointer-cast"
+template <class T> __device__ __forceinline__ T lds_load (u32 byte_offset) { return *(__attribute__ ((address_space (3))) T *) byte_offset; }
+#pragma clang diagnostic pop
 
 /* Two steps of four bucket walks: eight INDEPENDENT 8-byte reads, one wait, eight compares.  Inline
  * assembly because the compiler merges two reads of one walk into a ds_read2_b64 (twice the LDS cycles
@@ -289,6 +321,55 @@ __device__ __forceinline__ void nway_rank_steps (u32 mx, u32 a0, u32 a1, u32 a2,
   if constexpr (J + 2 < NWAY_LIMIT) nway_rank_steps<J + 2> (mx, a0, a1, a2, a3, key, lt);
 }
 
+/* Four bucket walks in step, software-pipelined: the 8-byte reads of steps J + 1 and J + 2 are in flight
+ * while step J is compared (LDS operations return in order: "at most 8 outstanding" means step J's four
+ * have arrived).  Inline assembly because the compiler merges two reads of one walk into a ds_read2_b64
+ * (twice the LDS cycles of two ds_read_b64: MI355X_MICROARCH.md, LDS table) or, told not to (volatile),
+ * waits for every single read; the wait is part of the statement that hands the step's registers on,
+ * so every use of them lies behind it.  The walks read two steps past the longest bucket: into
+ * following buckets or the all-ones behind the last key (see the bucket starts), never counted. */
+__device__ __forceinline__ void nway_walk_issue (u64 (&r)[4], u32 a0, u32 a1, u32 a2, u32 a3, u32 off)
+{
+  asm volatile ("ds_read_b64 %0, %4\n\t"
+                "ds_read_b64 %1, %5\n\t"
+                "ds_read_b64 %2, %6\n\t"
+                "ds_read_b64 %3, %7"
+                : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3])
+                : "v"(a0 + off), "v"(a1 + off), "v"(a2 + off), "v"(a3 + off)
+                : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void nway_walk_wait (u64 (&r)[4])
+{
+  asm volatile ("s_waitcnt lgkmcnt(%4)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : "n"(N) : "memory");
+}
+
+__device__ __forceinline__ void nway_rank_walk (u32 mx, u32 a0, u32 a1, u32 a2, u32 a3, const u64 (&key)[4], u32 (&lt)[4])
+{
+  u64 ra[4], rb[4], rc[4];
+  auto count = [&] (const u64 (&r)[4]) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) lt[k] += r[k] < key[k] ? 1u : 0u;
+  };
+  nway_walk_issue (ra, a0, a1, a2, a3, 0);
+  nway_walk_issue (rb, a0, a1, a2, a3, 8);
+  /* three steps per round, one register set each */
+  for (u32 j = 0; j < mx; j += 3) { /* uniform */
+    nway_walk_issue (rc, a0, a1, a2, a3, 8 * j + 16);
+    nway_walk_wait<8> (ra);
+    count (ra);
+    nway_walk_issue (ra, a0, a1, a2, a3, 8 * j + 24);
+    nway_walk_wait<8> (rb);
+    count (rb);
+    nway_walk_issue (rb, a0, a1, a2, a3, 8 * j + 32);
+    nway_walk_wait<8> (rc);
+    count (rc);
+  }
+  nway_walk_wait<0> (ra); /* the two steps read ahead land before their registers are reused */
+  nway_walk_wait<0> (rb);
+}
+
 __device__ __forceinline__ u64 readlane_u64 (u64 v, int l)
 {
   return (u64) (u32) __builtin_amdgcn_readlane ((int) (u32) v, l) | ((u64) (u32) __builtin_amdgcn_readlane ((int) (u32) (v >> 32), l) << 32);
@@ -301,15 +382,15 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
   typedef NwayShared<NT, RPT, NBF, MODE> Shared;
   constexpr int CAP = Shared::CAP, NW = Shared::NW, NCH = Shared::NCH, NB = Shared::NB;
   constexpr int NWORDS = NB / 2, WPT = NWORDS / NT;
-  constexpr int CAPS = Shared::CAPS, GSZ = Shared::GSZ;
+  constexpr int CAPS = Shared::CAPS;
   static_assert (NCH <= WAVE, "one lane per wave slot builds the slot table");
   static_assert (WPT * NT == NWORDS && WPT >= 1, "every thread scans the same number of counter words");
   static_assert (NW <= 16 && NW >= 2, "wave totals are reduced by one DPP row");
-  static_assert (NWAY_LIMIT % 2 == 0, "bucket walks go two steps at a time");
+  static_assert (NWAY_LIMIT % 6 == 0, "bucket walks go two or three steps a round");
   static_assert (CAP <= 32767 && NB <= 65536, "16-bit bucket counters and starts; bucket, arrival number and a flag share a dword");
   static_assert (2 * NWAY_PSTRIDE <= WAVE, "one lane per partition entry of a tile");
   __shared__ Shared sh;
-  const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+  int tid = threadIdx.x, lane = tid & (WAVE - 1); /* (not const: see the top of the tile loop) */
   const int wid = __builtin_amdgcn_readfirstlane (tid / WAVE);
   const u64 n_rows = ((u64) p.num_tiles + WAVE - 1) / WAVE;
   const u32 spin_limit = p.spin_limit ? p.spin_limit : SPIN_LIMIT;
@@ -323,7 +404,11 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
     role = sh.tick;
     __syncthreads ();
     if (role == 0) {
-      if (wid < 8) scanner_part (agg, carry + 4 * (n_rows + 1), carry, p.num_tiles, ctl, lane, spin_limit, (u32) wid, NW < 8 ? (u32) NW : 8u);
+      /* one wavefront sums and chains the rows while the launch has few enough of them (one hop less
+       * between a tile's total and its successors' offsets: with a single staging area the chain's
+       * latency bounds the time per tile); summers + chainer beyond that */
+      const u32 n_sub = p.scan_group ? (NW < 8 ? (u32) NW : 8u) : 1u;
+      if ((u32) wid < n_sub) scanner_part (agg, carry + 4 * (n_rows + 1), carry, p.num_tiles, ctl, lane, spin_limit, (u32) wid, n_sub);
       return;
     }
   }
@@ -458,6 +543,11 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
 #endif
 
   for (;;) {
+    /* the thread number is made opaque once per tile: addresses and masks derived from it are then
+     * recomputed where they are used (a few VALU each) instead of living in ~25 registers across the
+     * whole loop (hoisted by the compiler), which had the rank walk's registers spill */
+    asm volatile ("" : "+v"(tid));
+    lane = tid & (WAVE - 1);
     u32 cur, n, slots, bk0, bk_mul;
     u64 key_lo, out_base;
     {
@@ -499,6 +589,11 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
         const u32 v = (u32) ((key[k] - key_lo) >> bk_sh);
         u32 b = bk_direct ? v : __umulhi (v, bk_mul);
         b = b < (u32) NB ? b : (u32) NB - 1u;
+#ifdef GT4_NWAY_SKIP_ATOMIC
+        if (MODE == NWAY_UNION) {
+          if ((u32) lane < c) ba[k] = b | 0x80000000u;
+        } else
+#endif
         if ((u32) lane < c) {
           const u32 s16 = (b & 1u) * 16u;
           const u32 old = atomicAdd (&sh.cnt[b >> 1], 1u << s16);
@@ -506,11 +601,23 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
         }
       }
     }
-    /* the ordered tile: counts 0, nothing live; the grouped keys: all-ones (what a bucket walk meets
-     * behind its bucket must not be smaller than any key) */
+    /* the next tile's records: asked for as soon as this tile's have left the registers, a whole
+     * iteration before they are looked at (its table was written during the previous iteration).  One
+     * tile per workgroup is all that is in flight: asked for later (behind the scan) the kernel without
+     * any of its ranking, folding and output still took 21.6 of its 30 ms -- the HBM round trip */
+    {
+      const u32 nxt = uniform32 (sh.hdr[tb1][0]);
+      if (nxt < ntl && (u32) (wid * RPT) < uniform32 (sh.hdr[tb1][2])) fetch (tb1);
+    }
+    /* the ordered tile: counts 0, nothing live */
+#ifdef GT4_NWAY_SKIP_ZERO
+    if (MODE != NWAY_UNION)
+#endif
     for (int i = 4 * tid; i < CAPS; i += 4 * NT) *reinterpret_cast<u32x4 *> (&sh.s.scnt[i]) = u32x4 { 0, 0, 0, 0 };
+#ifdef GT4_NWAY_SKIP_ZERO
+    if (MODE != NWAY_UNION)
+#endif
     for (int i = tid; i < (CAPS + 3) / 4; i += NT) sh.live[i] = 0;
-    for (int i = 2 * tid; i < GSZ; i += 2 * NT) *reinterpret_cast<u32x4 *> (&sh.g[i]) = u32x4 { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu };
     /* service: the chain words of the tile staged one iteration ago are asked for; they are looked at
      * behind B4 at the earliest (the memory counter retires in order: a look waits for every older
      * operation of this wavefront, the previous write-out's stores included) */
@@ -562,10 +669,16 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
 #pragma unroll
       for (int i = 0; i < WPT; i++) sh.cnt[tid * WPT + i] = (tbase + ex[2 * i]) | ((tbase + ex[2 * i + 1]) << 16);
       if (tid == NT - 1) sh.cnt[NWORDS] = tbase + tsum; /* start of the bucket behind the last = the tile's records */
+      /* What a bucket walk meets behind its bucket must not be smaller than any key: the following
+       * buckets' keys are not, and the one skewed slot a bucket that crosses a multiple of 32 leaves
+       * free behind its last key gets all-ones here, as do the slots behind the tile's last key */
+#pragma unroll
+      for (int j = 0; j < 2 * WPT; j++) {
+        const u32 s0 = tbase + ex[j], e0 = tbase + (j + 1 < 2 * WPT ? ex[j + 1 < 2 * WPT ? j + 1 : 0] : tsum);
+        if ((e0 >> 5) != (s0 >> 5)) sh.g[e0 + (s0 >> 5)] = ~0ull;
+      }
+      if (tid < NWAY_LIMIT + 2) sh.g[nway_skew (n) + (u32) tid] = ~0ull; /* (+2: the walks read two steps ahead) */
     }
-    /* the next tile's records */
-    const u32 nxt = uniform32 (sh.hdr[tb1][0]);
-    if (nxt < ntl && (u32) (wid * RPT) < uniform32 (sh.hdr[tb1][2])) fetch (tb1);
     PHASE_STAMP (4);
     __syncthreads (); /* B3: bucket starts */
     PHASE_STAMP (5);
@@ -574,7 +687,11 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
     u32 st[RPT];
 #pragma unroll
     for (int k = 0; k < RPT; k++) st[k] = 0;
+#ifdef GT4_NWAY_SKIP_GROUP
+    if (has_rec && MODE != NWAY_UNION) {
+#else
     if (has_rec) {
+#endif
 #pragma unroll
       for (int k = 0; k < RPT; k++) {
         const u32 b = ba[k] & 0xffffu;
@@ -606,11 +723,17 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
         /* every lane runs the longest bucket's length (rounded up to even): behind its own bucket a lane
          * meets larger keys or all-ones */
         if constexpr (RPT == 4) {
+#ifdef GT4_NWAY_SKIP_RANK /* (subtractive builds: the union kernel alone, timing only) */
+          if (MODE != NWAY_UNION) nway_rank_steps<0> (mx, ga[0], ga[1], ga[2], ga[3], key, lt);
+#elif GT4_NWAY_WALK
+          nway_rank_walk (mx, ga[0], ga[1], ga[2], ga[3], key, lt);
+#else
           nway_rank_steps<0> (mx, ga[0], ga[1], ga[2], ga[3], key, lt);
+#endif
         } else {
           for (u32 j = 0; j < mx; j++) {
 #pragma unroll
-            for (int k = 0; k < RPT; k++) lt[k] += *(lds_u64 *) (ga[k] + 8u * j) < key[k] ? 1u : 0u;
+            for (int k = 0; k < RPT; k++) lt[k] += lds_load<u64> (ga[k] + 8u * j) < key[k] ? 1u : 0u;
           }
         }
 #pragma unroll
@@ -660,7 +783,11 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
     PHASE_STAMP (8);
 
     /* ---- the key once per position, the counts folded by LDS atomics */
+#ifdef GT4_NWAY_SKIP_FOLD
+    if (has_rec && MODE != NWAY_UNION) {
+#else
     if (has_rec) {
+#endif
 #pragma unroll
       for (int k = 0; k < RPT; k++) {
         if (!(ba[k] >> 31)) continue;
@@ -696,6 +823,10 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
     if (service) {
       PHASE_STAMP (16);
       build_table (sv_row, sv_t2, tb2);
+#ifdef GT4_NWAY_SV_TWICE /* experiment: is the service wavefront's work in front of everybody's barrier? */
+      asm volatile ("" : "+v"(sv_row));
+      build_table (sv_row, sv_t2, tb2);
+#endif
       PHASE_STAMP (17);
       const u32 t3 = uniform32 (sv_tk);
       sv_t2 = t3;
@@ -736,13 +867,17 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
       ocnt[i] = 0;
       kpre[i] = 0;
     }
+#ifdef GT4_NWAY_SKIP_ORDER
+    if (has_pos && MODE != NWAY_UNION) {
+#else
     if (has_pos) {
+#endif
 #pragma unroll
       for (int i = 0; i < RPT; i++) {
         const u32 q = nway_skew ((u32) (wid * RPT + i) * WAVE + (u32) lane);
-        const bool on = *(lds_u8 *) (lds_offset (&sh.live[0]) + q) != 0;
-        okey[i] = *(lds_u64 *) (lds_offset (&sh.s.skey[0]) + 8u * q);
-        u32 f = *(lds_u32 *) (lds_offset (&sh.s.scnt[0]) + 4u * q);
+        const bool on = lds_load<unsigned char> (lds_offset (&sh.live[0]) + q) != 0;
+        okey[i] = lds_load<u64> (lds_offset (&sh.s.skey[0]) + 8u * q);
+        u32 f = lds_load<u32> (lds_offset (&sh.s.scnt[0]) + 4u * q);
         if (MODE == NWAY_DUPS) f = 0;
         else if (p.rule == 7u) f = p.count_override;
         ocnt[i] = f;
@@ -947,11 +1082,11 @@ int gt4hip_nway_union (gt4hip_context *ctx, const gt4hip_list *const lists[], ui
       up.p.list[i] = (const u32 *) up.owned[i]->dev;
       up.p.n[i] = m;
       up.total += m;
-      if (m) {
-        u64 g = (m + 255) / 256;
-        if (g > 4096) g = 4096;
-        hipLaunchKernelGGL (k_nway_sample, dim3 ((unsigned) g), dim3 (256), 0, st, lo.p.list[i], m, (u32 *) up.owned[i]->dev);
-      }
+    }
+    if (!rc && up.total) {
+      u64 g = (up.total + 255) / 256;
+      if (g > 16384) g = 16384;
+      hipLaunchKernelGGL (k_nway_sample, dim3 ((unsigned) g), dim3 (256), 0, st, lo.p, up.p);
     }
     levels.push_back (up);
     if (rc) {
@@ -978,8 +1113,9 @@ int gt4hip_nway_union (gt4hip_context *ctx, const gt4hip_list *const lists[], ui
       lv.p.num_tiles = (u32) tiles;
       if ((rc = nway_grow (ctx, (void **) &ctx->kway_part, &ctx->kway_part_bytes, (size_t) (tiles + 1) * NWAY_PSTRIDE * 8))) break;
       const u64 threads = (tiles + 1) * NWAY_PSTRIDE;
-      hipLaunchKernelGGL (k_nway_partition, dim3 ((unsigned) ((threads + 255) / 256)), dim3 (256), 0, st, lv.p, merged ? (const u32 *) merged->dev : NULL,
-                          m_total, G, (u32) (NWAY_NBF * NWAY_CAP), (u64 *) ctx->kway_part);
+      for (int pass = 0; pass < 2; pass++)
+        hipLaunchKernelGGL (k_nway_partition, dim3 ((unsigned) ((threads + 255) / 256)), dim3 (256), 0, st, lv.p, merged ? (const u32 *) merged->dev : NULL,
+                            m_total, G, (u32) (NWAY_NBF * NWAY_CAP), (u64 *) ctx->kway_part, pass);
       hipMemsetAsync (ctx->scratch, 0, 64, st);
       hipLaunchKernelGGL (k_nway_check, dim3 ((unsigned) ((tiles + 255) / 256)), dim3 (256), 0, st, (const u64 *) ctx->kway_part, (u32) tiles, (u32) NWAY_CAP,
                           (u32 *) ctx->scratch);
@@ -1011,6 +1147,7 @@ int gt4hip_nway_union (gt4hip_context *ctx, const gt4hip_list *const lists[], ui
     lv.p.spin_limit = ctx->spin_limit;
     lv.p.force_fallback = ctx->kway_vt == 99 ? 1u : 0u; /* option "kway_vt" = 99: every tile takes the search path (tests) */
     const int mode = l > 0 ? NWAY_DUPS : (count_only ? NWAY_COUNT : NWAY_UNION);
+    lv.p.scan_group = ctx->scan_group > 0 ? 1u : (ctx->scan_group < 0 ? 0u : (tiles > (48000ull << 6) ? 1u : 0u));
     lv.p.dynamic = ctx->dynamic > 0 ? 1u : (ctx->dynamic < 0 ? 0u : (mode == NWAY_UNION ? 1u : 0u));
     u32 *dst = NULL;
     if (l > 0) {

@@ -148,6 +148,37 @@ def test_clustered_keys(ctx):
     _check(ctx, lists, k=25)
 
 
+@pytest.mark.parametrize("span_bits", [14, 22, 31])
+def test_dense_keys_take_the_narrow_path(ctx, span_bits):
+    """Tiles whose keys span less than 2^32 group and walk 4-byte keys relative to the tile's smallest
+    possible key (the bench's lists do; random 40-bit universes do not)."""
+    rng = np.random.default_rng(span_bits)
+    base = np.uint64(0x0123456789000000)
+    keys = base + np.unique(rng.integers(0, 1 << span_bits, size=min(90000, 1 << (span_bits - 1)), dtype=np.uint64))
+    lists = []
+    for j in range(5):
+        m = rng.random(len(keys)) < (0.9 if j < 3 else 0.3)
+        lists.append(U.make_records(keys[m], rng.integers(0, 7, size=int(m.sum()), dtype=np.uint32)))
+    _check(ctx, lists, k=32, expect_kway=len(keys) > 10)
+    _check(ctx, lists, k=32, rule=4, cutoff=2, expect_kway=len(keys) > 10)
+
+
+@pytest.mark.parametrize("span", [(1 << 32) - 1, 1 << 32, (1 << 32) + 1])
+def test_one_tile_spanning_2_pow_32(ctx, span):
+    """One tile from key x to key x + span: the last narrow span, the first wide ones; the low dwords
+    of the keys wrap inside the tile."""
+    rng = np.random.default_rng(span & 0xff)
+    x = 0x00000007fffffff0
+    inner = x + np.unique(rng.integers(1, span, size=1500, dtype=np.uint64))
+    keys = np.unique(np.concatenate([np.array([x, x + span], dtype=np.uint64), inner.astype(np.uint64)]))
+    lists = []
+    for j in range(3):
+        m = rng.random(len(keys)) < 0.7
+        m[0] = m[-1] = True
+        lists.append(U.make_records(keys[m], rng.integers(1, 9, size=int(m.sum()), dtype=np.uint32)))
+    _check(ctx, lists, k=32)
+
+
 def test_tile_overflow_is_retried_with_fewer_samples_per_tile(ctx):
     """64 samples per tile = 8192 records expected per tile > the LDS capacity: the partition check
     refuses, the cut is redone with fewer samples per tile; still the reference's bytes."""
