@@ -1,4 +1,4 @@
-"""Full-size parity (BASELINE.json configs 1, 2 and 4 at their real sizes) on one MI355X.
+"""Full-size parity (BASELINE.json configs 1, 2, 3 and 4 at their real sizes) on one MI355X.
 
 No CPU oracle finishes 4e9 records in test time, but every set operation is KEY-LOCAL: the result
 for key x depends only on the records with key x.  So besides size-independent identities the GPU
@@ -136,3 +136,79 @@ def test_config4_shape_k32_full_key_range(ctx):
     st, out, _ = ctx.compare(b, c, 1 | 2)
     assert st[2][0] == 0 and st[1][0] == n + m
     check_windows(b, c, out, st, 1 | 2)
+
+
+def _check_multi_windows(lists, out, n_words, total, cutoff, rule, ovr=1):
+    """N-way analogue of check_windows: key windows cut out of every list by lower_bound, the oracle's
+    union_multi (reference src/glistcompare.c:545-591) on the slices, byte-compared with the slice of
+    the GPU output between the same keys; header totals recounted on the device."""
+    longest = max(lists, key=lambda l: l.n_words)
+    n = longest.n_words
+    w4 = WINDOW // 4
+    starts = {0, n // 2, max(0, n - w4)}
+    if out.n_words > (1 << 31):  # a window around output record 2^31
+        starts.add(min(max(0, n - w4), max(0, int((1 << 31) * n / out.n_words) - w4 // 2)))
+    checked = 0
+    for i0 in sorted(starts):
+        i1 = min(n, i0 + w4)
+        lo = longest.get_word(i0)[0] if i0 else 0
+        to_end = i1 == n
+        hi = None if to_end else longest.get_word(i1)[0]
+
+        def cut(lst):
+            first = lst.lower_bound(lo) if lo else 0
+            last = lst.n_words if to_end else lst.lower_bound(hi)
+            return first, last
+
+        host = []
+        for l in lists:
+            f, e = cut(l)
+            host.append(l.download_range(f, e - f))
+        rc, n_exp, _, recs = O.union_multi(host, cutoff, rule, ovr)
+        assert rc == 0
+        fo, lo_ = cut(out)
+        assert lo_ - fo == n_exp, "window at %d: %d records, oracle %d" % (i0, lo_ - fo, n_exp)
+        assert out.download_range(fo, lo_ - fo).tobytes() == recs.tobytes(), "window at %d differs from the oracle" % i0
+        checked += n_exp
+    assert checked > 0
+    assert out.n_words == n_words and out.sum_counts() == total and out.is_sorted()
+
+
+def test_config3_eight_way_union_full_size(ctx):
+    """BASELINE config 3 on one GPU: the union of eight 5e8-entry k=25 lists (the bench's construction:
+    even lists share one key set, odd lists own disjoint residue classes) -- by the one-pass N-way tile
+    kernel and by the pairwise tree (whose intermediate levels keep every key and add raw counts,
+    src/glistcompare.c:545-591), each against the oracle on key windows, and against each other."""
+    n = 500_000_000
+    lists = []
+    for j in range(8):
+        lst = ctx.alloc(n, 25)
+        shared = j % 2 == 0
+        ctx.generate_ex(lst, n, 7 if shared else 100 + j, 50 + j, 8, 16, 0 if shared else 1 + j)
+        lists.append(lst)
+    before = ctx.get_counter("kway_calls")
+    rc, nw, tot, out = ctx.union_multi(lists)
+    assert rc == 0 and nw == 5 * n
+    assert ctx.get_counter("kway_calls") == before + 1 and ctx.get_counter("single_pass_fallbacks") == 0
+    _check_multi_windows(lists, out, nw, tot, 1, 0)
+    probe = out.download_range(nw // 3, 200000).tobytes()
+    out.free()
+    ctx.set_option("kway", 0)
+    try:
+        rc, nw_t, tot_t, out_t = ctx.union_multi(lists)
+    finally:
+        ctx.set_option("kway", 1)
+    assert (rc, nw_t, tot_t) == (0, nw, tot)
+    _check_multi_windows(lists, out_t, nw, tot, 1, 0)
+    assert out_t.download_range(nw // 3, 200000).tobytes() == probe
+    out_t.free()
+    # rule MAX with a cutoff on the result (union_multi :574): both paths again
+    rc, nw2, tot2, out2 = ctx.union_multi(lists, 5, 4)
+    assert rc == 0
+    _check_multi_windows(lists, out2, nw2, tot2, 5, 4)
+    ctx.set_option("kway", 0)
+    try:
+        rc, nw3, tot3, _ = ctx.union_multi(lists, 5, 4, 1, True)
+    finally:
+        ctx.set_option("kway", 1)
+    assert (nw3, tot3) == (nw2, tot2)

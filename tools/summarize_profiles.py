@@ -11,7 +11,7 @@ import csv, glob, json, os, sys
 
 src, tag = sys.argv[1], sys.argv[2]
 workload = sys.argv[3] if len(sys.argv) > 3 else "intersect"
-ROUND = os.environ.get("GT4_ROUND", "round2")
+ROUND = os.environ.get("GT4_ROUND", "round3")
 dst = os.path.join(src, "summary")
 os.makedirs(dst, exist_ok=True)
 
@@ -65,7 +65,7 @@ fetch, fpath = pmc("fetch", "FETCH_SIZE")
 write, wpath = pmc("write", "WRITE_SIZE")
 if fetch and write:
     # dominant kernel = the merge kernel instantiation with the most fetched bytes in total
-    cand = [k for k in fetch if k.startswith("k_pair_merge") or k.startswith("k_kway")]
+    cand = [k for k in fetch if k.startswith("k_pair_merge") or k.startswith("k_nway")]
     dom = max(cand, key=lambda k: sum(fetch[k].values()))
     fv = list(fetch[dom].values())
     wv = list(write.get(dom, {}).values())
@@ -91,7 +91,16 @@ if fetch and write:
                   "correction of MI355X_MICROARCH.md (HBM section); WRITE_SIZE as is",
         "source": ["profiles/%s/" % ROUND + os.path.basename(fpath), "profiles/%s/" % ROUND + os.path.basename(wpath)],
     }
-    if workload == "union8":
+    if workload == "union8" and dom.startswith("k_nway_merge"):
+        # one launch of the dominant instantiation per union; the call's other kernels (key samples, their
+        # merges, the tile partition) are counted into the per-union figure
+        unions = max(1, len(fv))
+        tj["unions_per_pmc_pass"] = unions
+        tj["all_nway_kernels_hbm_bytes_per_union"] = (all_f + all_w) / unions
+        tj["note"] = ("one launch of the one-pass N-way tile kernel per 8-way union (hbm_bytes_per_launch); the per-union figure adds "
+                      "the sample, partition and sample-merge kernels of the call; the bench runs every step twice (with and without "
+                      "the gather), so a PMC pass of --steps 2 --warmup 1 holds more unions than steps")
+    elif workload == "union8":
         # 7 pair merges per union: count the unions of the pass from the launches themselves
         launches = sum(len(fetch[k]) for k in cand)
         unions = max(1, launches // 7)
