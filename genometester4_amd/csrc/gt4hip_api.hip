@@ -832,7 +832,7 @@ static int union_multi_kway (gt4hip_context *ctx, const std::vector<const gt4hip
     drop ();
     return rc;
   }
-  if (cur.size () < 3) {
+  if (cur.size () < (ctx->kway_enabled >= 2 ? 2u : 3u)) {
     /* (possible only behind a level of eight-way merges) the last one or two go through the pair kernel */
     gt4hip_list empty_b;
     memset (&empty_b, 0, sizeof empty_b);

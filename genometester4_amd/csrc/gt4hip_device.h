@@ -310,7 +310,18 @@ __device__ __forceinline__ void scanner_part (u32 *agg, u64 *rowsum, u64 *carry_
 }
 
 /* A tile's global output offset: carry of its row + counts of the tiles before it in the row.
- * `a` and `c` are the values of an earlier, speculative load of the same words (or 0). */
+ * `a` and `c` are the values of an earlier, speculative load of the same words (or 0).
+ * LOOK-BACK (round 3): when the row's carry is not published yet the wavefront does not wait for the
+ * scanner but goes back up to RESOLVE_LOOKBACK rows itself: carry[row - r] plus the complete rows in
+ * between (64 counts per load, one DPP sum each) is the same number.  The scanner may then lag that
+ * many rows behind the workers without anybody waiting for it -- with one staging area (the
+ * any-combination pair kernel, the N-way kernel) the chain's round trip otherwise bounds the time per
+ * tile (measured: the N-way kernel stripped of all its ranking and output still took 21.6 of 30 ms). */
+#ifndef GT4_RESOLVE_LOOKBACK
+#define GT4_RESOLVE_LOOKBACK 0 /* per kernel file: the pair kernels take 3 (-u -d -c 3: 24.14 -> 23.48 ms); the N-way kernel's service wavefront loses 9 % to the extra loads and keeps 0 */
+#endif
+constexpr int RESOLVE_LOOKBACK = GT4_RESOLVE_LOOKBACK;
+
 __device__ __forceinline__ u64 resolve_offset (u32 *agg, u64 *carry, u64 tile, int lane, u32 a, u64 c, PairControl *ctl, u32 spin_limit)
 {
   const u64 row = tile / WAVE;
@@ -322,7 +333,36 @@ __device__ __forceinline__ u64 resolve_offset (u32 *agg, u64 *carry, u64 tile, i
 #ifdef GT4_PROFILE_PHASES
   const bool agg_ok0 = __all (!mine || (a & AGG_READY) != 0), carry_ok0 = (c & CARRY_READY) != 0;
 #endif
-  while (!__all (!mine || (a & AGG_READY) != 0) || !(c & CARRY_READY)) {
+  u64 back = 0; /* counts of the complete rows between the carry used and this row */
+  for (;;) {
+    const bool own_ok = __all (!mine || (a & AGG_READY) != 0);
+    if (own_ok && (c & CARRY_READY)) break;
+    if (own_ok && RESOLVE_LOOKBACK > 0) {
+      /* the rows before this one, nearest first: all their counts and one carry, asked for together */
+      u32 ar[RESOLVE_LOOKBACK > 0 ? RESOLVE_LOOKBACK : 1];
+      u64 cr[RESOLVE_LOOKBACK > 0 ? RESOLVE_LOOKBACK : 1];
+#pragma unroll
+      for (int r = 0; r < RESOLVE_LOOKBACK; r++) {
+        const bool has = row > (u64) r;
+        ar[r] = has ? peek_u32 (&agg[(row - 1 - r) * WAVE + lane]) : 0u;
+        cr[r] = has ? peek_u64 (&carry[row - 1 - r]) : 0ull;
+      }
+      u64 sum = 0;
+      bool found = false, rows_ok = true;
+#pragma unroll
+      for (int r = 0; r < RESOLVE_LOOKBACK; r++) {
+        if (found || !rows_ok || row <= (u64) r) continue; /* uniform */
+        rows_ok = __all ((ar[r] & AGG_READY) != 0);
+        if (!rows_ok) continue;
+        sum += dpp_wave_sum_u32 (ar[r] & ~AGG_READY);
+        if (cr[r] & CARRY_READY) {
+          found = true;
+          c = cr[r];
+          back = sum;
+        }
+      }
+      if (found) break;
+    }
     if (++spins > spin_limit) {
       if (lane == 0) atomicOr (&ctl->error, 1u);
       break;
@@ -344,7 +384,7 @@ __device__ __forceinline__ u64 resolve_offset (u32 *agg, u64 *carry, u64 tile, i
     atomicAdd (&ctl->resolve_stats[4], carry_ok0 ? 0ull : 1ull);
   }
 #endif
-  return (c & ~CARRY_READY) + dpp_wave_sum_u32 (mine ? (a & ~AGG_READY) : 0u);
+  return (c & ~CARRY_READY) + back + dpp_wave_sum_u32 (mine ? (a & ~AGG_READY) : 0u);
 }
 
 /* Tile write-out: `tot` packed records from an LDS staging slot (16-byte aligned) to the output

@@ -19,6 +19,9 @@
  *   K3 k_scan_*       tile-count scan for the two-pass fallback.
  *   K0 k_generate     synthetic ascending lists written straight into HBM (bench only).
  */
+#ifndef GT4_RESOLVE_LOOKBACK
+#define GT4_RESOLVE_LOOKBACK 3
+#endif
 #include "gt4hip_device.h"
 
 #ifndef GT4_NARROW
