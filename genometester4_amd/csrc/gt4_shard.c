@@ -59,16 +59,21 @@ uint64_t gt4_listfile_lower_bound (const GT4ListFile *lf, uint64_t key)
 
 /* ------------------------------------------------------------------ shared between the workers */
 
+/* cross-process flags: release stores behind the data they guard, acquire loads in front of it */
 typedef struct {
-  volatile uint32_t done;
+  uint32_t done;
   uint64_t n[4], t[4];
 } ChunkTotals;
 
+static int chunk_done (const ChunkTotals *c) { return __atomic_load_n (&c->done, __ATOMIC_ACQUIRE) != 0; }
+static void chunk_set_done (ChunkTotals *c) { __atomic_store_n (&c->done, 1u, __ATOMIC_RELEASE); }
+
 typedef struct {
-  volatile int failed;          /* any worker: stop */
-  volatile int rule_rejected;
+  int failed;                   /* any worker: stop */
+  int rule_rejected;
   char message[512];
-  volatile uint64_t hbm_limit;  /* published by worker 0 before the plan is made */
+  uint64_t limits[MAX_RANKS];   /* every worker's memory budget (bytes); the plan is made from the smallest */
+  uint64_t hbm_limit;           /* the budget the plan was made from (worker 0, for the record) */
   unsigned char comm_id[GT4HIP_COMM_ID_BYTES];
   pthread_barrierattr_t bar_attr;
   pthread_barrier_t bar;
@@ -112,9 +117,11 @@ static int make_plan (const GT4ShardJob *job, uint64_t hbm_limit, Plan *plan)
   if (want < G) want = G;
   want = (want + G - 1) / G * G;
   const uint64_t n_long = job->files[longest].header.n_words;
+  const uint64_t cap = (uint64_t) (1u << 22) / G * G; /* the shared block holds 2^22 chunk records; every worker owns equally many chunks */
   for (;;) {
-    if (want > (1u << 22)) want = 1u << 22;
+    if (want > cap) want = cap;
     const unsigned int C = (unsigned int) want;
+    if ((uint64_t) job->n_files * ((uint64_t) C + 1) > (1ull << 28)) return 2; /* a cut table beyond 2 GiB: the budget is far too small for these inputs */
     uint64_t *cut = (uint64_t *) malloc ((size_t) job->n_files * (C + 1) * sizeof (uint64_t));
     if (!cut) return 1;
     for (unsigned int c = 0; c <= C; c++) {
@@ -134,12 +141,13 @@ static int make_plan (const GT4ShardJob *job, uint64_t hbm_limit, Plan *plan)
       for (unsigned int f = 0; f < job->n_files; f++) sum += cut[(size_t) f * (C + 1) + c + 1] - cut[(size_t) f * (C + 1) + c];
       if (sum > worst) worst = sum;
     }
-    if (worst <= budget || C >= (1u << 22) || (uint64_t) C >= 2 * n_long + G) {
+    if (worst <= budget) {
       plan->n_chunks = C;
       plan->cut = cut;
       return 0;
     }
     free (cut);
+    if ((uint64_t) C >= cap || (uint64_t) C >= 2 * n_long + G) return 2; /* finer cuts do not exist or would not help: the budget cannot be met */
     want *= 2;
   }
 }
@@ -163,7 +171,9 @@ typedef struct {
   uint64_t out_n[SLOTS][4];
   int out_fd[4];
   gt4hip_comm *comm;
-  volatile int local_failed;
+  int local_failed;
+  int check_sorted;            /* GT4HIP_CHECK_SORTED */
+  uint64_t budget_bytes;       /* device bytes the plan was made for */
   double t_load, t_merge, t_write;
 } Worker;
 
@@ -174,16 +184,23 @@ static double now_s (void)
   return ts.tv_sec + ts.tv_nsec * 1e-9;
 }
 
+static int shared_failed (const Shared *sh) { return __atomic_load_n (&sh->failed, __ATOMIC_ACQUIRE); }
+
 static void worker_fail (Worker *w, const char *fmt, const char *detail)
 {
-  if (!w->sh->failed) {
+  int expected = 0;
+  /* the first failure writes the message; the flag is published behind it */
+  static pthread_mutex_t lock = PTHREAD_MUTEX_INITIALIZER; /* (this worker's threads) */
+  pthread_mutex_lock (&lock);
+  if (!shared_failed (w->sh)) {
     snprintf (w->sh->message, sizeof w->sh->message, fmt, detail);
-    w->sh->failed = 1;
+    __atomic_compare_exchange_n (&w->sh->failed, &expected, 1, 0, __ATOMIC_RELEASE, __ATOMIC_RELAXED);
   }
-  w->local_failed = 1;
+  pthread_mutex_unlock (&lock);
+  __atomic_store_n (&w->local_failed, 1, __ATOMIC_RELEASE);
 }
 
-static int stopped (const Worker *w) { return w->sh->failed || w->local_failed; }
+static int stopped (const Worker *w) { return shared_failed (w->sh) || __atomic_load_n (&w->local_failed, __ATOMIC_ACQUIRE); }
 
 static void *loader_main (void *arg)
 {
@@ -194,7 +211,7 @@ static void *loader_main (void *arg)
   for (unsigned int f = 0; f < job->n_files; f++) fds[f] = -1;
   if (gt4hip_create (w->device, &ctx)) worker_fail (w, "Error: %s", gt4hip_last_error (NULL));
   /* the worker's contexts share one device: each may keep at most a third of the budget pooled */
-  if (ctx) gt4hip_set_option (ctx, "pool_cap_mb", (int64_t) (w->sh->hbm_limit / 3 >> 20));
+  if (ctx) gt4hip_set_option (ctx, "pool_cap_mb", (int64_t) (w->budget_bytes / 3 >> 20));
   for (unsigned int f = 0; f < job->n_files && !stopped (w); f++) {
     if (job->files[f].index_kmers) continue;
     fds[f] = open (job->files[f].filename, O_RDONLY);
@@ -223,6 +240,14 @@ static void *loader_main (void *arg)
         rc = gt4hip_list_upload_fd (ctx, fds[f], lf->header.list_start + 12 * first, last - first, job->word_length, &w->in[slot][f]);
       }
       if (rc) worker_fail (w, "Error: uploading to the GPU failed: %s", gt4hip_last_error (ctx));
+      else if (w->check_sorted && last > first) {
+        /* GT4HIP_CHECK_SORTED=1: the chunk strictly ascending, and above the record in front of it (the
+         * cuts were made by binary searches that trusted the order) */
+        int sorted = 0;
+        if (gt4hip_list_is_sorted (ctx, w->in[slot][f], &sorted) || !sorted ||
+            (first > 0 && gt4_listfile_key_at (lf, first - 1) >= gt4_listfile_key_at (lf, first)))
+          worker_fail (w, "Error: File %s is not sorted by k-mer (strictly ascending, unique)", lf->filename);
+      }
     }
     w->t_load += now_s () - t0;
     sem_post (&w->slot_loaded[slot]);
@@ -246,6 +271,8 @@ static void *writer_main (void *arg)
   gt4hip_context *ctx = NULL;
   const int writes = !job->prm.count_only;
   if (writes && gt4hip_create (w->device, &ctx)) worker_fail (w, "Error: %s", gt4hip_last_error (NULL));
+  uint64_t start[4] = { 0, 0, 0, 0 }; /* records of chunks 0 .. summed - 1 per output: a running prefix */
+  unsigned int summed = 0;
   for (unsigned int i = 0; i < w->n_mine; i++) {
     const int slot = (int) (i % SLOTS);
     const unsigned int c = (unsigned int) w->rank + i * (unsigned int) job->n_ranks;
@@ -256,10 +283,10 @@ static void *writer_main (void *arg)
       const unsigned int first_chunk = c;
       if (!job->gather_rccl || w->rank == 0) {
         /* records of all earlier chunks = where this one starts in each output file */
-        uint64_t start[4] = { 0, 0, 0, 0 };
-        for (unsigned int q = 0; q < first_chunk && !stopped (w); q++) {
-          while (!w->sh->chunk[q].done && !stopped (w)) usleep (50);
-          for (int s = 0; s < 4; s++) start[s] += w->sh->chunk[q].n[s];
+        for (; summed < first_chunk && !stopped (w); summed++) {
+          while (!chunk_done (&w->sh->chunk[summed]) && !stopped (w)) usleep (50);
+          if (stopped (w)) break;
+          for (int s = 0; s < 4; s++) start[s] += w->sh->chunk[summed].n[s];
         }
         /* every output stream of the chunk in one call: the copy threads are dealt to the files */
         const gt4hip_list *wl[4];
@@ -321,7 +348,7 @@ static void merge_chunk (Worker *w, gt4hip_context *ctx, int slot, unsigned int 
                      : gt4hip_intersect_multi (ctx, (const gt4hip_list *const *) w->in[slot], job->n_files, job->prm.cutoff, job->prm.rule,
                                                job->prm.count_override, job->prm.count_only, &res);
     if (rc == GT4HIP_ERULE) {
-      w->sh->rule_rejected = 1;
+      __atomic_store_n (&w->sh->rule_rejected, 1, __ATOMIC_RELEASE);
       worker_fail (w, "%s", gt4hip_last_error (ctx));
       return;
     }
@@ -342,8 +369,12 @@ static void gather_round (Worker *w, gt4hip_context *ctx, int slot, unsigned int
 {
   const GT4ShardJob *job = w->job;
   const int G = job->n_ranks;
+  if (c0 + (unsigned int) G > w->plan->n_chunks) {
+    worker_fail (w, "Error: %s", "internal: a gather round reaches beyond the chunk plan");
+    return;
+  }
   for (int q = 0; q < G; q++)
-    while (!w->sh->chunk[c0 + q].done && !stopped (w)) usleep (20);
+    while (!chunk_done (&w->sh->chunk[c0 + q]) && !stopped (w)) usleep (20);
   if (stopped (w)) return;
   for (int s = 0; s < 4; s++) {
     if (!job->out_name[s]) continue;
@@ -373,6 +404,7 @@ static int worker_main (const GT4ShardJob *job, Shared *sh, int rank)
   w->job = job;
   w->sh = sh;
   w->rank = rank;
+  w->check_sorted = getenv ("GT4HIP_CHECK_SORTED") && atoi (getenv ("GT4HIP_CHECK_SORTED"));
   const int G = job->n_ranks;
   for (int s = 0; s < 4; s++) w->out_fd[s] = -1;
 
@@ -385,23 +417,38 @@ static int worker_main (const GT4ShardJob *job, Shared *sh, int rank)
     if (gt4hip_create (w->device, &ctx)) worker_fail (w, "Error: %s", gt4hip_last_error (NULL));
     if (ctx && job->debug) fprintf (errf, "Worker %d of %d: device %d: %s\n", rank, G, w->device, gt4hip_device_info (ctx));
   }
-  /* ---- worker 0 fixes the memory budget (the plan must be the same everywhere) and the RCCL id */
-  if (rank == 0) {
+  /* ---- the memory budget: the caller's, or 70 % of what THIS worker's device has free right now
+   * (divided among the workers that share the device); the plan is made from the smallest budget of
+   * all workers, so it is the same everywhere */
+  {
     uint64_t limit = job->hbm_limit;
     if (!limit && ctx) {
       uint64_t free_b = 0, total_b = 0;
       gt4hip_device_memory (ctx, &free_b, &total_b);
-      limit = free_b / 10 * 7;
+      const int n_dev = gt4hip_device_count ();
+      const int sharing = n_dev > 0 ? (G + n_dev - 1) / n_dev : G;
+      limit = free_b / 10 * 7 / (uint64_t) (sharing > 0 ? sharing : 1);
     }
-    sh->hbm_limit = limit ? limit : (1ull << 30);
-    if (job->gather_rccl && !stopped (w) && gt4hip_comm_unique_id (sh->comm_id)) worker_fail (w, "Error: %s", gt4hip_comm_last_error ());
+    sh->limits[rank] = limit ? limit : (1ull << 30);
   }
+  if (rank == 0 && job->gather_rccl && !stopped (w) && gt4hip_comm_unique_id (sh->comm_id)) worker_fail (w, "Error: %s", gt4hip_comm_last_error ());
   if (G > 1) pthread_barrier_wait (&sh->bar);
+  uint64_t budget_bytes = sh->limits[0];
+  for (int r = 1; r < G; r++)
+    if (sh->limits[r] < budget_bytes) budget_bytes = sh->limits[r];
   Plan plan = { 0, NULL };
-  if (make_plan (job, sh->hbm_limit, &plan)) worker_fail (w, "Error: %s", "out of memory while planning the chunks");
-  if (!stopped (w) && plan.n_chunks != sh->n_chunks) worker_fail (w, "Error: %s", "internal: chunk plans differ");
-  if (ctx) gt4hip_set_option (ctx, "pool_cap_mb", (int64_t) (sh->hbm_limit / 3 >> 20));
+  {
+    const int prc = make_plan (job, budget_bytes, &plan);
+    if (prc == 1) worker_fail (w, "Error: %s", "out of memory while planning the chunks");
+    else if (prc) worker_fail (w, "Error: %s", "the inputs cannot be cut into key-range chunks that fit the device memory budget (GT4HIP_HBM_LIMIT)");
+  }
+  if (rank == 0) {
+    sh->hbm_limit = budget_bytes;
+    sh->n_chunks = plan.n_chunks;
+  }
+  if (ctx) gt4hip_set_option (ctx, "pool_cap_mb", (int64_t) (budget_bytes / 3 >> 20));
   w->plan = &plan;
+  w->budget_bytes = budget_bytes;
   w->n_mine = stopped (w) ? 0 : (plan.n_chunks - (unsigned int) rank + (unsigned int) G - 1) / (unsigned int) G;
   if (job->gather_rccl && G >= 1 && !stopped (w)) {
     if (gt4hip_comm_create (ctx, sh->comm_id, G, rank, &w->comm)) worker_fail (w, "Error: %s", gt4hip_last_error (ctx));
@@ -422,6 +469,7 @@ static int worker_main (const GT4ShardJob *job, Shared *sh, int rank)
     }
   }
   if (G > 1) pthread_barrier_wait (&sh->bar);
+  if (!stopped (w) && plan.n_chunks != sh->n_chunks) worker_fail (w, "Error: %s", "internal: chunk plans differ");
   if (writes && rank != 0 && !job->gather_rccl && !stopped (w)) {
     for (int s = 0; s < 4; s++) {
       if (!job->out_name[s]) continue;
@@ -457,8 +505,7 @@ static int worker_main (const GT4ShardJob *job, Shared *sh, int rank)
     }
     const double t0 = now_s ();
     if (!stopped (w)) merge_chunk (w, ctx, slot, c);
-    __sync_synchronize ();
-    sh->chunk[c].done = 1;
+    chunk_set_done (&sh->chunk[c]);
     if (job->gather_rccl && writes && !stopped (w)) gather_round (w, ctx, slot, c - (unsigned int) rank);
     w->t_merge += now_s () - t0;
     outs_pending[slot] = 1;
@@ -477,13 +524,20 @@ static int worker_main (const GT4ShardJob *job, Shared *sh, int rank)
   if (w->comm) gt4hip_comm_destroy (w->comm);
   /* a worker that stopped early still marks its chunks so that nobody waits for them */
   if (stopped (w))
-    for (unsigned int i = 0; i < w->n_mine; i++) sh->chunk[(unsigned int) rank + i * (unsigned int) G].done = 1;
+    for (unsigned int i = 0; i < w->n_mine; i++) chunk_set_done (&sh->chunk[(unsigned int) rank + i * (unsigned int) G]);
   for (int s = 0; s < 4; s++)
     if (w->out_fd[s] >= 0 && rank != 0) close (w->out_fd[s]);
+  if (G > 1 && job->gather_rccl && stopped (w)) {
+    /* the peers may be inside a collective that this worker will never join: leave at once (this is a
+     * forked worker); the parent sees the exit code, ends the others and removes the temporaries */
+    fflush (stdout);
+    fflush (stderr);
+    _exit (1);
+  }
   if (G > 1) pthread_barrier_wait (&sh->bar); /* every extent is written */
 
   /* ---- worker 0: back-patch the headers (reference :907-915, :592-595) and rename into place */
-  int rc = stopped (w) || sh->failed ? 1 : 0;
+  int rc = stopped (w) ? 1 : 0;
   if (rank == 0 && writes) {
     for (int s = 0; s < 4; s++) {
       if (!job->out_name[s] || w->out_fd[s] < 0) continue;
@@ -540,49 +594,20 @@ int gt4_shard_run (const GT4ShardJob *job, GT4ShardResult *res)
     return 1;
   }
   const int G = job->n_ranks;
-  if (G > 1 || job->gather_rccl) {
+  if (G > 1) {
     pthread_barrierattr_init (&sh->bar_attr);
     pthread_barrierattr_setpshared (&sh->bar_attr, PTHREAD_PROCESS_SHARED);
     pthread_barrier_init (&sh->bar, &sh->bar_attr, (unsigned int) G);
   }
   int rc = 0;
-  if (G == 1 && !job->gather_rccl) {
-    /* one worker, in this process.  Every worker makes the plan itself from the same inputs and the
-     * same budget; the budget is the caller's, or 70 % of what the device has free right now. */
-    GT4ShardJob j1 = *job;
-    if (!j1.hbm_limit) {
-      gt4hip_context *probe = NULL;
-      if (gt4hip_create (getenv ("GT4HIP_DEVICE") ? atoi (getenv ("GT4HIP_DEVICE")) : 0, &probe)) {
-        fprintf (stderr, "Error: %s\n", gt4hip_last_error (NULL));
-        munmap (sh, bytes);
-        return 1;
-      }
-      uint64_t free_b = 0, total_b = 0;
-      gt4hip_device_memory (probe, &free_b, &total_b);
-      gt4hip_destroy (probe);
-      j1.hbm_limit = free_b / 10 * 7;
-      if (!j1.hbm_limit) j1.hbm_limit = 1ull << 30;
-    }
-    Plan p;
-    if (make_plan (&j1, j1.hbm_limit, &p)) {
-      munmap (sh, bytes);
-      return 1;
-    }
-    sh->n_chunks = p.n_chunks;
-    free (p.cut);
-    rc = worker_main (&j1, sh, 0);
+  if (G == 1) {
+    /* one worker, in this process (also with the RCCL gather of one rank: no fork, so it does not
+     * matter whether the caller has touched HIP already) */
+    rc = worker_main (job, sh, 0);
   } else {
-    /* several GPUs (or the RCCL path, whose library is kept out of the calling process): the budget
-     * must be explicit or defaulted WITHOUT touching HIP in this process */
-    GT4ShardJob jn = *job;
-    if (!jn.hbm_limit) jn.hbm_limit = 128ull << 30; /* per worker; GT4HIP_HBM_LIMIT overrides */
-    Plan p;
-    if (make_plan (&jn, jn.hbm_limit, &p)) {
-      munmap (sh, bytes);
-      return 1;
-    }
-    sh->n_chunks = p.n_chunks;
-    free (p.cut);
+    /* several GPUs: one worker process each, forked BEFORE anything in this process touches HIP; the
+     * workers find their budgets and make the plan themselves */
+    const GT4ShardJob jn = *job;
     fflush (stdout);
     fflush (stderr);
     pid_t pids[MAX_RANKS];
@@ -619,18 +644,31 @@ int gt4_shard_run (const GT4ShardJob *job, GT4ShardResult *res)
       left--;
       if (!WIFEXITED (status)) {
         if (!killed) fprintf (stderr, "Error: GPU worker %d ended abnormally (status 0x%x)\n", r, status);
-        sh->failed = 1;
+        __atomic_store_n (&sh->failed, 1, __ATOMIC_RELEASE);
         rc = 1;
         killed = 1;
         for (int q = 0; q < G; q++)
           if (pids[q] > 0) kill (pids[q], SIGKILL);
       } else if (WEXITSTATUS (status)) {
-        /* a worker that failed has left the pipeline; the others see the flag, skip their remaining
-         * work and meet it at the final barrier -- except in gather mode, where they may be waiting
-         * for it inside a collective */
+        /* a worker that failed normally leaves through the barriers together with the others (they see
+         * the flag and skip their remaining work): by the time the first one is reaped the others are
+         * past every barrier or about to be.  One that left early -- out of memory before the first
+         * barrier, or out of a collective its peers still sit in -- would leave them waiting for ever:
+         * give them a moment, then end them. */
         rc = 1;
-        sh->failed = 1;
-        if (job->gather_rccl) {
+        __atomic_store_n (&sh->failed, 1, __ATOMIC_RELEASE);
+        for (int wait_ms = 0; wait_ms < 2000 && left > 0; wait_ms += 20) {
+          int st2 = 0;
+          const pid_t p2 = waitpid (-1, &st2, WNOHANG);
+          if (p2 > 0) {
+            for (int q = 0; q < G; q++)
+              if (pids[q] == p2) {
+                pids[q] = 0;
+                left--;
+              }
+          } else usleep (20000);
+        }
+        if (left > 0) {
           killed = 1;
           for (int q = 0; q < G; q++)
             if (pids[q] > 0) kill (pids[q], SIGKILL);
@@ -657,7 +695,7 @@ int gt4_shard_run (const GT4ShardJob *job, GT4ShardResult *res)
         res->total_count[s] += sh->chunk[c].t[s];
       }
   if (rc && sh->message[0] && !sh->rule_rejected) fprintf (stderr, "%s\n", sh->message);
-  if (G > 1 || job->gather_rccl) pthread_barrier_destroy (&sh->bar);
+  if (G > 1) pthread_barrier_destroy (&sh->bar);
   munmap (sh, bytes);
   return rc;
 }

@@ -17,7 +17,7 @@
 
 using namespace gt4;
 
-static char g_create_err[512] = "";
+static thread_local char g_create_err[512] = ""; /* per thread: a worker's loader, merger and writer threads each create a context (found by ThreadSanitizer on the CPU harness) */
 
 static void pool_flush (gt4hip_context *ctx);
 

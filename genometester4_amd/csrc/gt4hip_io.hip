@@ -53,7 +53,9 @@ struct Worker {
   pthread_t thread;
   void *pinned[2];
   hipStream_t stream;
-  int err;           /* errno-style: 0 ok, 1 read/write failed, 2 HIP failed */
+  int err;           /* 0 ok, 1 read/write failed (sys_errno, file_off_failed say what and where), 2 HIP failed */
+  int sys_errno;     /* errno of the failing pread / pwrite on THIS thread; -1: the file ended early */
+  long long fail_off;
 };
 
 }  // namespace
@@ -71,6 +73,8 @@ struct gt4hip_io {
 
 namespace {
 
+/* 0, or the errno of the failing call; -1: the file ended early (no errno at all) -- kept per copy
+ * thread, because errno is thread-local and the message is composed by the calling thread */
 int full_pread (int fd, void *buf, size_t len, off_t off)
 {
   char *p = (char *) buf;
@@ -78,9 +82,9 @@ int full_pread (int fd, void *buf, size_t len, off_t off)
     const ssize_t r = pread (fd, p, len, off);
     if (r < 0) {
       if (errno == EINTR) continue;
-      return 1;
+      return errno ? errno : EIO;
     }
-    if (r == 0) return 1; /* file shorter than its header promised */
+    if (r == 0) return -1; /* file shorter than its header promised */
     p += r;
     off += r;
     len -= (size_t) r;
@@ -95,7 +99,7 @@ int full_pwrite (int fd, const void *buf, size_t len, off_t off)
     const ssize_t r = pwrite (fd, p, len, off);
     if (r < 0) {
       if (errno == EINTR) continue;
-      return 1;
+      return errno ? errno : EIO;
     }
     p += r;
     off += r;
@@ -147,7 +151,11 @@ void run_pieces (Worker *w, const Job &j, size_t index, size_t T)
       const size_t off = p * PIECE, len = j.bytes - off < PIECE ? j.bytes - off : PIECE;
       if (busy[slot] && hipEventSynchronize (ev[slot]) != hipSuccess) w->err = 2;
       if (j.kind == JOB_FD_TO_DEV) {
-        if (full_pread (j.fd, w->pinned[slot], len, j.file_off + (off_t) off)) w->err = 1;
+        if (const int e = full_pread (j.fd, w->pinned[slot], len, j.file_off + (off_t) off)) {
+          w->err = 1;
+          w->sys_errno = e;
+          w->fail_off = (long long) (j.file_off + (off_t) off);
+        }
       } else {
         memcpy (w->pinned[slot], j.src_mem + off, len);
       }
@@ -191,7 +199,11 @@ void run_pieces (Worker *w, const Job &j, size_t index, size_t T)
       }
       if (!w->err) {
         if (j.kind == JOB_DEV_TO_FD) {
-          if (full_pwrite (j.fd, w->pinned[done_slot], done_len, j.file_off + (off_t) done_off)) w->err = 1;
+          if (const int e = full_pwrite (j.fd, w->pinned[done_slot], done_len, j.file_off + (off_t) done_off)) {
+            w->err = 1;
+            w->sys_errno = e;
+            w->fail_off = (long long) (j.file_off + (off_t) done_off);
+          }
         } else {
           memcpy (j.dst_mem + done_off, w->pinned[done_slot], done_len);
         }
@@ -281,7 +293,9 @@ int io_run (gt4hip_context *ctx, const Job &job, const char *what)
   while (io->running) pthread_cond_wait (&io->cv_done, &io->mu);
   pthread_mutex_unlock (&io->mu);
   for (int i = 0; i < io->n_threads; i++) {
-    if (io->w[i].err == 1) return gt4hip_fail (ctx, GT4HIP_EIO, "%s: file I/O failed: %s", what, strerror (errno));
+    if (io->w[i].err == 1)
+      return gt4hip_fail (ctx, GT4HIP_EIO, "%s: file I/O failed near byte %lld: %s", what, io->w[i].fail_off,
+                          io->w[i].sys_errno < 0 ? "the file is shorter than its header promises" : strerror (io->w[i].sys_errno));
     if (io->w[i].err == 2) {
       (void) hipGetLastError ();
       return gt4hip_fail (ctx, GT4HIP_EHIP, "%s: a HIP copy failed", what);

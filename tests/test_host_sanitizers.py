@@ -1,0 +1,122 @@
+"""The C host of the product under AddressSanitizer + UndefinedBehaviorSanitizer and under
+ThreadSanitizer, WITHOUT a GPU: csrc/gt4_glistcompare_cli.c, gt4_shard.c (key-range plan, fork, barriers,
+semaphore pipeline, shared totals, pwrite extents, header back-patching, failure paths) and
+gt4_listfile.c linked against tests/harness/gt4hip_stub.c -- a CPU stand-in for the device layer that
+runs the set operations through the CPU oracle.  The golden reference invocations are replayed with
+one, two and three worker processes and through 1-KiB chunks: exit code, stdout, stderr and every output
+file must be the reference's bytes, and no sanitizer may report anything.  Failures injected into one
+worker (context creation, the merge, the gather buffer, the collective itself) must end the whole run
+with exit code 1, no temporaries and no hang.  (Next 8; ADVICE round 2 on
+gt4_shard.c.)"""
+import os
+import subprocess
+import tempfile
+
+import pytest
+
+import golden_util as G
+from genometester4_amd.listio import write_list, write_list_v40
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HARNESS = os.path.join(ROOT, "tests", "harness")
+CASES, INPUTS, OUTPUTS = G.load()
+GL_CASES = [c for c in CASES if c["tool"] == "glistcompare"]
+# a spread of the golden runs: every operation set, rules, cutoffs, -du, N-way, count_only, errors
+SPREAD = [c for i, c in enumerate(GL_CASES) if i % 7 == 0 or c["id"].startswith(("multi_", "err_", "empty", "wrap", "v40"))]
+
+
+@pytest.fixture(scope="module")
+def binaries():
+    r = subprocess.run(["make", "-C", HARNESS], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return {k: os.path.join(HARNESS, "_build", "glistcompare_" + k) for k in ("asan", "tsan")}
+
+
+@pytest.fixture(scope="module")
+def workdir():
+    d = tempfile.mkdtemp(prefix="gt4san_")
+    for name, (rec, k, flavour) in INPUTS.items():
+        (write_list_v40 if flavour == "v40" else write_list)(os.path.join(d, name + ".list"), rec, k)
+    yield d
+    import shutil
+    shutil.rmtree(d, ignore_errors=True)
+
+
+def _run(binary, argv, cwd, env_extra, timeout=120):
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0:exitcode=97", UBSAN_OPTIONS="print_stacktrace=1:exitcode=98",
+               TSAN_OPTIONS="exitcode=99:halt_on_error=0", **env_extra)
+    before = set(os.listdir(cwd))
+    p = subprocess.run([binary] + argv, cwd=cwd, capture_output=True, timeout=timeout, env=env)
+    created = sorted(set(os.listdir(cwd)) - before)
+    data = {}
+    for f in created:
+        with open(os.path.join(cwd, f), "rb") as fh:
+            data[f] = fh.read()
+        os.remove(os.path.join(cwd, f))
+    return p.returncode, p.stdout.decode("latin-1"), p.stderr.decode("latin-1"), data
+
+
+def _clean(err):
+    """stderr without sanitizer chatter must be the reference's; any sanitizer report fails the test"""
+    assert "Sanitizer" not in err and "runtime error" not in err, err[-3000:]
+    return err
+
+
+MODES = [("one worker", {"GT4HIP_GPUS": "1"}),
+         ("1 KiB chunks", {"GT4HIP_GPUS": "1", "GT4HIP_HBM_LIMIT": "1024"}),
+         ("two workers", {"GT4HIP_GPUS": "2", "GT4HIP_STUB_DEVICES": "2", "GT4HIP_HBM_LIMIT": "4096"}),
+         ("three workers, gathered", {"GT4HIP_GPUS": "3", "GT4HIP_STUB_DEVICES": "3", "GT4HIP_HBM_LIMIT": "2048", "GT4HIP_GATHER": "rccl"})]
+
+
+@pytest.mark.parametrize("san", ["asan", "tsan"])
+@pytest.mark.parametrize("mode", MODES, ids=[m[0] for m in MODES])
+def test_golden_runs_under_sanitizers(binaries, workdir, san, mode):
+    for case in SPREAD:
+        rc, out, err, files = _run(binaries[san], case["argv"], workdir, mode[1])
+        err = _clean(err)
+        assert rc == case["exit"], (case["id"], rc, err[-500:])
+        assert out == case["stdout"], case["id"]
+        assert err == case["stderr"], case["id"]
+        assert sorted(files) == sorted(case["files"]), case["id"]
+        for name, data in files.items():
+            assert data == bytes(OUTPUTS["%s/%s" % (case["id"], name)]), "%s: %s differs from the reference output" % (case["id"], name)
+
+
+@pytest.mark.parametrize("san", ["asan", "tsan"])
+@pytest.mark.parametrize("what,gather", [("create:1", False), ("merge:1", False), ("merge:0", True), ("alloc_gather:0", True), ("gatherv:2", True),
+                                         ("gatherv:0", True), ("create:2", True)])
+def test_a_failing_worker_ends_the_run_cleanly(binaries, workdir, san, what, gather):
+    """One worker of three fails at a given point; with the gather its peers may already sit in the
+    collective.  The run must end with exit code 1 within seconds, say why, and leave no files."""
+    env = {"GT4HIP_GPUS": "3", "GT4HIP_STUB_DEVICES": "3", "GT4HIP_HBM_LIMIT": "4096", "GT4HIP_STUB_FAIL": what}
+    if gather:
+        env["GT4HIP_GATHER"] = "rccl"
+    rc, out, err, files = _run(binaries[san], ["A8.list", "B8.list", "-u", "-i", "-d", "-o", "failing"], workdir, env, timeout=60)
+    _clean(err)
+    assert rc == 1, (rc, err)
+    assert "Error" in err or "injected" in err, err
+    assert not files, files
+
+
+@pytest.mark.parametrize("san", ["asan", "tsan"])
+def test_unsorted_input_is_refused_in_the_chunked_path(binaries, workdir, san):
+    rec, k, _ = INPUTS["A8"]
+    bad = rec.copy()
+    bad[[30, 31]] = bad[[31, 30]]
+    write_list(os.path.join(workdir, "unsorted.list"), bad, k)
+    try:
+        env = {"GT4HIP_GPUS": "2", "GT4HIP_STUB_DEVICES": "2", "GT4HIP_HBM_LIMIT": "2048", "GT4HIP_CHECK_SORTED": "1"}
+        rc, out, err, files = _run(binaries[san], ["A8.list", "unsorted.list", "-u", "-o", "u"], workdir, env)
+        _clean(err)
+        assert rc == 1 and "unsorted.list is not sorted" in err and not files
+        rc, out, err, files = _run(binaries[san], ["A8.list", "B8.list", "-u", "--count_only"], workdir, env)
+        assert rc == 0, err
+    finally:
+        os.remove(os.path.join(workdir, "unsorted.list"))
+
+
+def test_budget_that_cannot_be_met_is_an_error(binaries, workdir):
+    """12 bytes of device memory: no key-range cut fits; the tool says so instead of running out of memory later"""
+    rc, out, err, files = _run(binaries["asan"], ["A8.list", "B8.list", "-u", "-o", "tiny"], workdir, {"GT4HIP_GPUS": "2", "GT4HIP_STUB_DEVICES": "2", "GT4HIP_HBM_LIMIT": "12"})
+    _clean(err)
+    assert rc == 1 and "cannot be cut into key-range chunks" in err and not files
