@@ -288,7 +288,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=2_000_000_000, help="entries per list per GPU")
+    ap.add_argument("--n", "--entries", dest="n", type=int, default=2_000_000_000,
+                    help="entries per list per GPU (--entries: the spelling to use under torch.distributed.run, whose own parser takes --n for an abbreviation)")
     ap.add_argument("--k", type=int, default=25)
     ap.add_argument("--cpu-sample", type=int, default=200_000_000, help="records per list timed on the CPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -297,8 +298,12 @@ def main():
                     help="intersect: BASELINE configs[1] (default, the headline metric); c2: configs[2], union + first complement "
                          "with cutoff 3 on the same pair; union8: configs[3], 8-way union sharded by key range over the ranks "
                          "with an RCCL gatherv to rank 0 (strong scaling)")
-    ap.add_argument("--n8", type=int, default=500_000_000, help="union8: entries per list (whole job)")
+    ap.add_argument("--n8", "--entries8", dest="n8", type=int, default=500_000_000, help="union8: entries per list (whole job)")
     ap.add_argument("--tree", action="store_true", help="union8: the pairwise tree instead of the one-pass N-way kernel")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="intersect / c2 with --gpus N: weak = one independent pair of --n entries per GPU (default); strong = ONE "
+                         "pair of --n entries, every rank merges its key range (gt4hip_shard_first_key) and the header totals are "
+                         "all-gathered inside every step")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -325,20 +330,27 @@ def main():
     if args.workload == "union8":
         return bench_union8(args, ctx, capi, rank, local_rank, world)
     n = args.n
+    strong = args.scaling == "strong"
     ops = capi.OP_INTRSEC if args.workload == "intersect" else (capi.OP_UNION | capi.OP_DIFF1)
     cutoff = 1 if args.workload == "intersect" else 3
     op_bits = [bit for bit in (1, 2, 4) if ops & bit]
     while True:
         try:
-            a, b = build_lists(ctx, capi, n, args.k, 1000 * rank)
-            outs = {bit: ctx.alloc({1: 2 * n, 2: n, 4: n}[bit], args.k) for bit in op_bits}
+            # strong scaling: every rank builds the SAME pair and keeps its key range of it
+            a, b = build_lists(ctx, capi, n, args.k, 0 if strong else 1000 * rank)
+            if strong and world > 1:
+                from genometester4_amd import distributed as D
+                sh = D.DeviceShards(ctx, rank, world, None)
+                full_a, full_b = a, b
+                a, b = sh.shard_of(full_a, args.k), sh.shard_of(full_b, args.k)
+            outs = {bit: ctx.alloc(max(1, {1: a.n_words + b.n_words, 2: min(a.n_words, b.n_words), 4: a.n_words}[bit]), args.k) for bit in op_bits}
             break
         except capi.Gt4HipError as e:
             if e.code != capi.ENOMEM or n < 1_000_000:
                 raise
             log("rank %d: %d entries per list do not fit (%s); halving" % (rank, n, e))
             n //= 2
-    if world > 1:  # all ranks must run the same shape
+    if world > 1 and not strong:  # all ranks must run the same shape
         t = torch.tensor([n], dtype=torch.int64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         if int(t.item()) != n:
@@ -346,8 +358,20 @@ def main():
             a, b = a.slice(0, n), b.slice(0, n)
     n_a, n_b = a.n_words, b.n_words
 
+    exchange_ms = []
+    job_stat = {}  # strong scaling: the job-wide header totals of the last step
+
     def step():
         st, _, timing = ctx.compare(a, b, ops, cutoff=cutoff, out=outs)
+        if strong and world > 1:
+            # the one exchange a sharded pair operation needs: per-shard header totals,
+            # all-gathered over RCCL inside the step
+            from genometester4_amd import distributed as D
+            t0 = time.perf_counter()
+            xdev = "cuda" if dist.get_backend() == "nccl" else None  # (the one-device test hook runs over gloo)
+            job = {bit: tuple(sum(x[i] for x in D.exchange_totals(st[bit][0], st[bit][1], device=xdev)) for i in (0, 1)) for bit in op_bits}
+            exchange_ms.append((time.perf_counter() - t0) * 1e3)
+            job_stat.update(job)
         return st, timing
 
     def fence():
@@ -370,11 +394,19 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     totals = [sum(stat[bit][0] for bit in op_bits), sum(stat[bit][1] for bit in op_bits) & 0x7FFFFFFFFFFFFFFF]
+    per_rank = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        # the only exchange the sharded intersection needs: per-shard header totals
+        box = [None] * world
+        dist.all_gather_object(box, {"rank": rank, "shard_input_records": n_a + n_b, "merge_kernel_ms": statistics.mean(kernel_ms),
+                                     "totals_exchange_ms": statistics.mean(exchange_ms) if exchange_ms else 0.0})
+        per_rank = box
+    if world > 1 and strong:
+        totals = [sum(job_stat[bit][0] for bit in op_bits), sum(job_stat[bit][1] for bit in op_bits) & 0x7FFFFFFFFFFFFFFF]  # exchanged inside the step
+    elif world > 1:
+        # independent shards: the header totals are summed once, for the report
         g = [torch.zeros(2, dtype=torch.int64, device="cuda") for _ in range(world)]
         dist.all_gather(g, torch.tensor(totals, dtype=torch.int64, device="cuda"))
         totals = [int(sum(x[0].item() for x in g)), int(sum(x[1].item() for x in g))]
@@ -388,32 +420,37 @@ def main():
         names = {1: "union", 2: "intrsec", 4: "diff1"}
         if args.workload == "intersect":
             metric = "k-mers merged/sec, 2-list k=%d intersection (glistcompare -i), lists resident in HBM" % args.k
-            wl = ("single-GPU" if world == 1 else "%d independent key-range shards, one per GPU:" % world) + " intersection, two %d-entry k=%d lists (%.1f GB each) per GPU, |A n B| = n/2" % (n, args.k, 12 * n / 1e9)
+            if strong and world > 1:
+                wl = "ONE intersection of two %d-entry k=%d lists (%.1f GB each), key-range sharded over %d GPUs (gt4hip_shard_first_key), header totals all-gathered in every step, |A n B| = n/2" % (n, args.k, 12 * n / 1e9, world)
+            else:
+                wl = ("single-GPU" if world == 1 else "%d independent key-range shards, one per GPU:" % world) + " intersection, two %d-entry k=%d lists (%.1f GB each) per GPU, |A n B| = n/2" % (n, args.k, 12 * n / 1e9)
             kernel = "k_pair_merge<1024, 6, MODE_LOOKBACK, intersection, folded MIN>"
         else:
             metric = "k-mers merged/sec, 2-list k=%d union + first complement, cutoff %d (glistcompare -u -d -c %d), lists resident in HBM" % (args.k, cutoff, cutoff)
-            wl = ("single-GPU" if world == 1 else "%d independent key-range shards, one per GPU:" % world) + " union + difference_first with --cutoff %d, two %d-entry k=%d lists (%.1f GB each) per GPU, |A n B| = n/2" % (cutoff, n, args.k, 12 * n / 1e9)
+            wl = ("single-GPU" if world == 1 else ("ONE job key-range sharded over %d GPUs:" % world if strong else "%d independent key-range shards, one per GPU:" % world)) + " union + difference_first with --cutoff %d, two %d-entry k=%d lists (%.1f GB each) per GPU, |A n B| = n/2" % (cutoff, n, args.k, 12 * n / 1e9)
             kernel = "k_pair_merge<1024, 4, MODE_LOOKBACK, any combination of outputs, default rules>"
         res = {
             "metric": metric,
-            "value": world * (n_a + n_b) * args.steps / elapsed,
+            "value": (2 * n if strong else world * (n_a + n_b)) * args.steps / elapsed,
             "unit": "k-mers/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "u64 keys + u32 counts",
             "data": "synthetic",
             "config": {
                 "workload": wl,
-                "entries_per_list_per_gpu": n,
+                "per_rank": per_rank,
+                "entries_per_list_per_gpu": n if not (strong and world > 1) else None,
+                "entries_per_list": n if strong else None,
                 "word_length": args.k,
                 "output_records": {names[bit]: stat[bit][0] for bit in op_bits} if world == 1 else totals[0],
                 "output_total_count": {names[bit]: stat[bit][1] for bit in op_bits} if world == 1 else totals[1],
-                "sharding": "one key-range shard per GPU, no data-path collective" if world > 1 else "none",
+                "sharding": ("one job, key ranges of equal width, totals all-gather per step" if strong else "one key-range shard per GPU, no data-path collective") if world > 1 else "none",
                 "path": "two_pass" if args.two_pass else "single_pass_lookback",
                 "device": ctx.device_info(),
             },

@@ -1,0 +1,93 @@
+"""The multi-rank paths on real devices.
+
+With TWO OR MORE GPUs visible: `bench.py` under `torch.distributed.run` with the nccl (= RCCL) backend --
+the strong-scaling intersection (one job cut by gt4hip_shard_first_key, header totals all-gathered
+every step) and the 8-way union with the RCCL gatherv of the C ABI (grouped ncclSend / ncclRecv between
+two devices) -- must report the very totals the single-GPU run reports; `glistcompare --gpus 2` with
+GT4HIP_GATHER=rccl is covered by tests/test_sharded_cli.py (it expects the reference's bytes there).
+With ONE GPU these cases skip, and the bench's multi-rank control flow is driven with both ranks on
+device 0 over gloo instead (GT4_BENCH_ONE_DEVICE: RCCL refuses two ranks on one device).
+
+Reference for what is sharded: scripts/MakeUnion.pl:31-95 (the tree of pairwise unions this replaces),
+src/glistcompare.c:843-905 (the pair loop)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _n_devices():
+    from genometester4_amd import capi
+    return capi.lib().gt4hip_device_count()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _bench(n_ranks, args, env_extra=None):
+    env = dict(os.environ, **(env_extra or {}))
+    if n_ranks == 1:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + args
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks), "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(n_ranks)] + args
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+SMALL_PAIR = ["--workload", "intersect", "--entries", "6000000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+SMALL_UNION = ["--workload", "union8", "--entries8", "1500000", "--steps", "2", "--warmup", "1"]
+
+
+def test_strong_scaling_line_equals_the_default_line_on_one_gpu():
+    one = _bench(1, SMALL_PAIR)
+    strong = _bench(1, SMALL_PAIR + ["--scaling", "strong"])
+    assert strong["config"]["output_records"] == one["config"]["output_records"]
+    assert strong["config"]["output_total_count"] == one["config"]["output_total_count"]
+    assert strong["metric"] == one["metric"] and strong["n_gpus"] == 1
+
+
+def test_two_ranks_on_one_device_strong_scaling_control_flow():
+    """both ranks on device 0, reductions over gloo: the sharding arithmetic, the per-step totals
+    exchange and the report, without RCCL"""
+    one = _bench(1, SMALL_PAIR)
+    two = _bench(2, SMALL_PAIR + ["--scaling", "strong"], {"GT4_BENCH_ONE_DEVICE": "1"})
+    assert two["scaling"] == "strong" and two["n_gpus"] == 2
+    assert two["config"]["output_records"] == one["config"]["output_records"]["intrsec"]
+    assert two["config"]["output_total_count"] == one["config"]["output_total_count"]["intrsec"]
+    shards = two["config"]["per_rank"]
+    assert sum(r["shard_input_records"] for r in shards) == 2 * 6000000
+
+
+@pytest.mark.skipif("_n_devices() < 2", reason="needs two GPUs")
+def test_two_gpus_strong_scaling_intersection_over_rccl():
+    one = _bench(1, SMALL_PAIR)
+    two = _bench(2, SMALL_PAIR + ["--scaling", "strong"])
+    assert two["config"]["output_records"] == one["config"]["output_records"]["intrsec"]
+    assert two["config"]["output_total_count"] == one["config"]["output_total_count"]["intrsec"]
+    assert sum(r["shard_input_records"] for r in two["config"]["per_rank"]) == 2 * 6000000
+
+
+@pytest.mark.skipif("_n_devices() < 2", reason="needs two GPUs")
+def test_two_gpus_eight_way_union_with_rccl_gatherv():
+    one = _bench(1, SMALL_UNION)
+    two = _bench(2, SMALL_UNION)
+    assert two["config"]["output_records"] == one["config"]["output_records"]
+    assert two["config"]["output_total_count"] == one["config"]["output_total_count"]
+    assert two["config"]["gathered_bytes_per_step"] > 0
+    assert sum(r["shard_input_records"] for r in two["config"]["per_rank"]) == 8 * 1500000
