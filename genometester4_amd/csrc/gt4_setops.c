@@ -148,17 +148,28 @@ unsigned int gt4_write_union (GT4HipWordList *arrays[], unsigned int n_arrays, u
   header->total_count = res.total_count;
   unsigned int bad = 0;
   if (ofile) {
-    /* header, then the records, streamed device -> host -> fd (:65, :104-121) */
+    /* header, then the records (:65, :104-121).  A seekable file takes the library's copy threads
+     * (pinned staging, several writers of disjoint extents: gt4hip_list_write_fd) from the current
+     * position and is left positioned behind the last record, as sequential writes would leave it;
+     * a pipe or socket gets the records streamed device -> host -> fd */
     bad |= write_fully (ofile, header, sizeof *header);
     const uint64_t n = res.n_words;
-    void *buf = n ? malloc ((size_t) (n < DOWNLOAD_CHUNK ? n : DOWNLOAD_CHUNK) * 12u) : NULL;
-    if (n && !buf) bad = 1;
-    for (uint64_t first = 0; first < n && !bad; first += DOWNLOAD_CHUNK) {
-      const uint64_t cnt = n - first < DOWNLOAD_CHUNK ? n - first : DOWNLOAD_CHUNK;
-      if (gt4hip_list_download_range (ctx, res.out, first, cnt, buf)) bad = 1;
-      else bad |= write_fully (ofile, buf, (size_t) cnt * 12u);
+    const off_t pos = bad ? (off_t) -1 : lseek (ofile, 0, SEEK_CUR);
+    if (n && !bad && pos >= 0) {
+      if (gt4hip_list_write_fd (ctx, res.out, 0, n, ofile, (uint64_t) pos)) {
+        fprintf (stderr, "gt4_write_union: %s\n", gt4hip_last_error (ctx));
+        bad = 1;
+      } else if (lseek (ofile, pos + (off_t) (n * 12u), SEEK_SET) < 0) bad = 1;
+    } else if (n && !bad) {
+      void *buf = malloc ((size_t) (n < DOWNLOAD_CHUNK ? n : DOWNLOAD_CHUNK) * 12u);
+      if (!buf) bad = 1;
+      for (uint64_t first = 0; first < n && !bad; first += DOWNLOAD_CHUNK) {
+        const uint64_t cnt = n - first < DOWNLOAD_CHUNK ? n - first : DOWNLOAD_CHUNK;
+        if (gt4hip_list_download_range (ctx, res.out, first, cnt, buf)) bad = 1;
+        else bad |= write_fully (ofile, buf, (size_t) cnt * 12u);
+      }
+      free (buf);
     }
-    free (buf);
   }
   gt4hip_list_free (res.out);
   return bad;
