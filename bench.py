@@ -283,6 +283,116 @@ def bench_union8(args, ctx, capi, rank, local_rank, world):
     ctx.close()
 
 
+def bench_sort(args, ctx, capi):
+    """SURVEY 8f N2 (glistmaker's table step): --ns random k-mer words in HBM -> sorted (word, occurrences)
+    list (wordtable_sort + wordtable_find_frequencies, reference src/word-table.c:217-260 on top of
+    src/utils.c:127-198), by gt4hip_device_words_to_list: LSD radix sort, 8-bit digits, then the fold."""
+    import numpy as np
+    import torch
+    n, k = args.ns, args.k
+    bits = 64 if k >= 32 else 2 * k
+    passes = (bits + 7) // 8
+    g = torch.Generator(device="cuda")
+    g.manual_seed(1234)
+    # repeats as a genome has them: a quarter of the words drawn from a small pool, the rest uniform
+    pristine = torch.randint(0, (1 << min(bits, 62)), (n,), dtype=torch.int64, device="cuda", generator=g)
+    pool = torch.randint(0, (1 << min(bits, 62)), (max(1, n // 64),), dtype=torch.int64, device="cuda", generator=g)
+    idx = torch.randint(0, pool.numel(), (n // 4,), dtype=torch.int64, device="cuda", generator=g)
+    pristine[: n // 4] = pool[idx]
+    del idx
+    work = torch.empty_like(pristine)
+    sort_ms, fold_ms, wall = [], [], []
+    n_out = total = 0
+    for it in range(args.warmup + args.steps):
+        work.copy_(pristine)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        lst = ctx.device_words_to_list(work.data_ptr(), n, k)
+        ctx.synchronize()
+        dt = time.perf_counter() - t0
+        if it >= args.warmup:
+            wall.append(dt)
+            sort_ms.append(ctx.get_counter("sort_us") / 1000.0)
+            fold_ms.append(ctx.get_counter("fold_us") / 1000.0)
+        n_out, total = lst.n_words, lst.sum_counts()
+        assert total == n
+        if it == 0:
+            assert lst.is_sorted()
+        lst.free()
+    s_ms = statistics.mean(sort_ms)
+    alg = 16 * passes * n  # SURVEY / VERDICT: 16 bytes moved per word and pass (read + write)
+    res = {"metric": "k-mer words sorted and folded/sec (glistmaker table step), k=%d, words resident in HBM" % k,
+           "value": n / statistics.mean(wall), "unit": "words/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": statistics.mean(wall) * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "u64 words", "data": "synthetic",
+           "config": {"workload": "sort + fold of %d random k=%d words (a quarter drawn from a pool of %d) -> %d-record list" % (n, k, max(1, n // 64), n_out),
+                      "words": n, "word_length": k, "radix_passes": passes, "output_records": n_out, "device": ctx.device_info()},
+           "roofline": {"bound": "hbm", "kernel": "k_radix_hist + k_radix_scatter x %d passes" % passes, "achieved": alg / (s_ms * 1e-3) / 1e9,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "algorithmic_bytes_per_launch": alg, "kernel_ms_avg": s_ms, "fold_ms_avg": statistics.mean(fold_ms),
+                        "note": "achieved = 16 B x passes x words / time of the radix passes (HIP events); the histogram pass reads the words once more (24 B per word and pass really move)"}}
+    if not args.no_cpu_baseline:
+        m = min(n, args.cpu_sample // 4)
+        host = pristine[:m].cpu().numpy().astype(np.uint64)
+        t0 = time.perf_counter()
+        u, c = np.unique(host, return_counts=True)
+        dt = time.perf_counter() - t0
+        res["cpu_baseline"] = {"value": m / dt, "unit": "words/s", "cores": 1, "host_nproc": os.cpu_count(), "kind": "port",
+                               "sample": "numpy.unique(return_counts=True) of the first %d words (sort + run lengths, one thread): what wordtable_sort + wordtable_find_frequencies compute" % m}
+        dev = ctx.words_to_list(host, k).download()
+        res["verified"] = bool(len(dev) == len(u) and (dev["key"] == u).all() and (dev["count"] == c.astype(np.uint32)).all())
+    print(json.dumps(res), flush=True)
+    ctx.close()
+
+
+def bench_table(args, ctx, capi):
+    """SURVEY 8f N3 (glistquery's multi-list dump): per-key count table of --nt-lists lists of --nt entries
+    (gt4_union's callback rows, reference src/set-operations.c:131-183) by gt4hip_union_table: the N-way
+    union gives the keys, every column is one more streaming merge (rule SECOND) + a column copy."""
+    nl, n, k = args.nt_lists, args.nt, args.k
+    lists = []
+    for j in range(nl):
+        lst = ctx.alloc(n, k)
+        shared = j % 2 == 0
+        ctx.generate_ex(lst, n, 7 if shared else 100 + j, 50 + j, 8, 16, 0 if shared else 1 + j)
+        lists.append(lst)
+    wall, tab = [], []
+    n_keys = 0
+    for it in range(args.warmup + args.steps):
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        n_keys = ctx.union_table_device(lists)
+        ctx.synchronize()
+        if it >= args.warmup:
+            wall.append(time.perf_counter() - t0)
+            tab.append(ctx.get_counter("table_us") / 1000.0)
+    t_ms = statistics.mean(tab)
+    alg = 12 * nl * n + (8 + 4 * nl) * n_keys
+    res = {"metric": "k-mers tabulated/sec (glistquery multi-list dump: per-key counts of %d lists), lists resident in HBM" % nl,
+           "value": nl * n / statistics.mean(wall), "unit": "k-mers/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": statistics.mean(wall) * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "u64 keys + u32 counts", "data": "synthetic",
+           "config": {"workload": "count table of %d lists x %d k=%d entries -> %d keys x %d counts" % (nl, n, k, n_keys, nl),
+                      "lists": nl, "entries_per_list": n, "keys": n_keys, "device": ctx.device_info()},
+           "roofline": {"bound": "hbm", "kernel": "k_nway_merge (the keys) + %d x (k_pair_merge union + k_extract_column)" % nl,
+                        "achieved": alg / (t_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "traffic": None, "algorithmic_bytes_per_launch": alg, "kernel_ms_avg": t_ms,
+                        "note": "algorithmic = every input record read once + the table written once; the call is %d launches: achieved is over the whole call" % (2 * nl + 4)}}
+    if not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as O
+        m = min(n, args.cpu_sample // (4 * nl))
+        last_key, _ = lists[0].get_word(m - 1)
+        host = [l.download_range(0, l.lower_bound(last_key + 1)) for l in lists]
+        t0 = time.perf_counter()
+        rc, n_u, _, _ = O.union_multi(host, 0, 4, 1)
+        dt = time.perf_counter() - t0
+        res["cpu_baseline"] = {"value": sum(len(h) for h in host) / dt, "unit": "k-mers/s", "cores": 1, "host_nproc": os.cpu_count(), "kind": "port",
+                               "sample": "oracle/gt4_oracle.c union_multi walk (the loop gt4_union shares, set-operations.c:153-181) over the first %d records of every list, one thread" % m}
+    print(json.dumps(res), flush=True)
+    ctx.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -294,7 +404,10 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=200_000_000, help="records per list timed on the CPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--two-pass", action="store_true", help="count+scan+write instead of the single-pass kernel")
-    ap.add_argument("--workload", choices=["intersect", "c2", "union8"], default="intersect",
+    ap.add_argument("--ns", type=int, default=1_000_000_000, help="sort: words")
+    ap.add_argument("--nt", type=int, default=100_000_000, help="table: entries per list")
+    ap.add_argument("--nt-lists", type=int, default=6, help="table: lists")
+    ap.add_argument("--workload", choices=["intersect", "c2", "union8", "sort", "table"], default="intersect",
                     help="intersect: BASELINE configs[1] (default, the headline metric); c2: configs[2], union + first complement "
                          "with cutoff 3 on the same pair; union8: configs[3], 8-way union sharded by key range over the ranks "
                          "with an RCCL gatherv to rank 0 (strong scaling)")
@@ -329,6 +442,10 @@ def main():
         ctx.set_option("two_pass", 1)
     if args.workload == "union8":
         return bench_union8(args, ctx, capi, rank, local_rank, world)
+    if args.workload == "sort":
+        return bench_sort(args, ctx, capi)
+    if args.workload == "table":
+        return bench_table(args, ctx, capi)
     n = args.n
     strong = args.scaling == "strong"
     ops = capi.OP_INTRSEC if args.workload == "intersect" else (capi.OP_UNION | capi.OP_DIFF1)

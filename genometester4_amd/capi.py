@@ -53,6 +53,7 @@ SYMBOLS = [
     "gt4hip_get_counter", "gt4hip_device_memory", "gt4hip_list_upload_fd", "gt4hip_list_load_fd", "gt4hip_list_load",
     "gt4hip_list_write_fd", "gt4hip_lists_write_fd", "gt4hip_shard_first_key", "gt4hip_comm_unique_id", "gt4hip_comm_create", "gt4hip_comm_destroy",
     "gt4hip_comm_rank", "gt4hip_comm_size", "gt4hip_comm_last_error", "gt4hip_comm_gatherv", "gt4hip_sort_words", "gt4hip_words_to_list",
+    "gt4hip_device_words_to_list",
 ]
 
 _lib = None
@@ -124,6 +125,7 @@ def lib():
             "gt4hip_comm_gatherv": (C.c_int, [vp, vp, C.POINTER(u64), C.c_int, vp]),
             "gt4hip_sort_words": (C.c_int, [vp, vp, u64, u32]),
             "gt4hip_words_to_list": (C.c_int, [vp, vp, u64, u32, C.POINTER(vp)]),
+            "gt4hip_device_words_to_list": (C.c_int, [vp, vp, u64, u32, C.POINTER(vp)]),
         }
         for name, (res, args) in sig.items():
             f = getattr(L, name)
@@ -255,6 +257,21 @@ class Context:
         h = C.c_void_p()
         self._chk(lib().gt4hip_words_to_list(self.h, w.ctypes.data if len(w) else None, len(w), word_length, C.byref(h)))
         return DeviceList(self, h)
+
+    def device_words_to_list(self, device_ptr, n_words, word_length) -> "DeviceList":
+        """The same for n_words packed words at `device_ptr` (device memory; sorted in place)."""
+        h = C.c_void_p()
+        self._chk(lib().gt4hip_device_words_to_list(self.h, C.c_void_p(device_ptr), n_words, word_length, C.byref(h)))
+        return DeviceList(self, h)
+
+    def union_table_device(self, lists):
+        """gt4hip_union_table without the download: (n_keys, free function) -- for timing."""
+        arr = (C.c_void_p * len(lists))(*[l.h for l in lists])
+        t = CountTable()
+        self._chk(lib().gt4hip_union_table(self.h, arr, len(lists), C.byref(t)))
+        n = t.n_keys
+        lib().gt4hip_table_free(C.byref(t))
+        return n
 
     def device_memory(self):
         f, t = C.c_uint64(), C.c_uint64()

@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <new>
 #include <utility>
 #include <vector>
@@ -181,6 +182,9 @@ extern "C" int gt4hip_get_counter (gt4hip_context *ctx, const char *name, uint64
   else if (!strcmp (name, "kway_overflows")) *value = ctx->kway_overflows;
   else if (!strcmp (name, "nway_kernel_us")) *value = (uint64_t) (ctx->nway_kernel_ms * 1000.0);
   else if (!strcmp (name, "nway_tiles")) *value = ctx->nway_tiles;
+  else if (!strcmp (name, "sort_us")) *value = (uint64_t) (ctx->sort_ms * 1000.0);
+  else if (!strcmp (name, "fold_us")) *value = (uint64_t) (ctx->fold_ms * 1000.0);
+  else if (!strcmp (name, "table_us")) *value = (uint64_t) (ctx->table_ms * 1000.0);
   else return gt4hip_fail (ctx, GT4HIP_EINVAL, "unknown counter %s", name);
   return GT4HIP_OK;
 }
@@ -1046,6 +1050,12 @@ static int table_alloc (gt4hip_context *ctx, gt4hip_count_table *table, uint64_t
 extern "C" int gt4hip_union_table (gt4hip_context *ctx, const gt4hip_list *const lists[], uint32_t n_lists, gt4hip_count_table *table)
 {
   if (!ctx || !lists || !n_lists || !table) return GT4HIP_EINVAL;
+  const auto t_begin = std::chrono::steady_clock::now ();
+  struct Stamp { /* wall time of the whole call (several launches and read-backs), for bench.py --workload table */
+    gt4hip_context *c;
+    std::chrono::steady_clock::time_point t0;
+    ~Stamp () { c->table_ms = std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now () - t0).count (); }
+  } stamp = { ctx, t_begin };
   memset (table, 0, sizeof *table);
   table->n_lists = n_lists;
   /* all distinct keys ascending = N-way union with nothing filtered out (count >= 0) */

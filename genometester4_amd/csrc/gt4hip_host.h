@@ -49,6 +49,8 @@ struct gt4hip_context {
   int64_t kway_vt;           /* option "kway_vt": positions per thread in a merge pass, at least (0 = default) */
   uint64_t kway_overflows;   /* calls that fell back to the tree because a tile would not fit LDS */
   uint64_t kway_calls;       /* N-way unions done by the one-pass kernel */
+  double table_ms;           /* the last gt4hip_union_table, wall time of the call */
+  double sort_ms, fold_ms;   /* the last gt4hip_device_words_to_list: radix sort and fold (HIP events) */
   double nway_kernel_ms;     /* the last one-pass launch's kernel time (HIP events on the library's stream) and tiles */
   uint64_t nway_tiles;
   gt4hip_io *io;            /* file <-> HBM staging (gt4hip_io.hip), NULL until first used */

@@ -57,7 +57,14 @@ constexpr int NWAY_MAX = 8;       /* lists per launch */
 #endif
 constexpr int NWAY_SAMPLE = GT4_NWAY_SAMPLE; /* S: one sample per S records */
 constexpr int NWAY_PSTRIDE = 10;  /* u64 per tile boundary in the partition table: eight cuts, the tile's smallest possible key, interpolation constants */
-constexpr int NWAY_LIMIT = 24;    /* keys per bucket the search-free path handles */
+#ifndef GT4_NWAY_LIMIT
+#define GT4_NWAY_LIMIT 48
+#endif
+#ifndef GT4_NWAY_TRY0
+#define GT4_NWAY_TRY0 32
+#endif
+constexpr int NWAY_LIMIT = GT4_NWAY_LIMIT;    /* keys per bucket the bucket walks handle */
+constexpr int NWAY_TRY0 = GT4_NWAY_TRY0;     /* ... that the interpolation's buckets may hold before the tile is bucketed by a pivot run instead */
 
 enum : int { NWAY_COUNT = 0, NWAY_UNION = 1, NWAY_DUPS = 2 };
 
@@ -72,7 +79,7 @@ struct NwayParams {
   u32 spin_limit;
   u32 num_tiles;
   u32 dynamic;         /* tiles by ticket (ctl->ticket) instead of round-robin */
-  u32 force_fallback;  /* tests: every tile takes the search path */
+  u32 force_fallback;  /* tests: 1 every tile takes the search path, 2 every tile is bucketed by its pivot run */
   u32 scan_group;      /* the scanner workgroup as summers + chainer (launches with very many rows) */
 };
 
@@ -179,8 +186,30 @@ __global__ void k_nway_partition (NwayParams p, const u32 *__restrict__ merged, 
       const u32 bl = D ? 64u - (u32) __builtin_clzll (D) : 0u;
       const u32 sh = bl > 32u ? bl - 32u : 0u;
       const u32 vmax = (u32) (D >> sh);
-      if (vmax < n_buckets) v = (u64) sh | (1ull << 8);
-      else v = (u64) sh | ((((u64) n_buckets << 32) / ((u64) vmax + 1ull)) << 32);
+      const bool direct = vmax < n_buckets;
+      const u32 mul = direct ? 0u : (u32) (((u64) n_buckets << 32) / ((u64) vmax + 1ull));
+      v = (u64) sh | (direct ? 1ull << 8 : (u64) mul << 32);
+      /* Will the interpolation work?  The tile's own samples tell: G keys spread over thousands of
+       * buckets share hardly any when the keys are spread evenly; stretches of adjacent keys between
+       * wide gaps put most of them into a few.  Such a tile is bucketed by its pivot run at once. */
+      if (merged && t + 1 < p.num_tiles) {
+        const u64 first = t * (u64) G, last = (t + 1) * (u64) G < m_total ? (t + 1) * (u64) G : m_total;
+        u32 prev = 0xffffffffu, same = 0, cnt = 0;
+        u64 prev_key = 0;
+        bool have_prev = false;
+        for (u64 j = first; j < last; j++) {
+          const u64 x = load_key (merged, j);
+          if (x < lo || x > hi || (have_prev && x == prev_key)) continue; /* (equal keys of different lists share a bucket by right) */
+          prev_key = x;
+          have_prev = true;
+          const u32 vv = (u32) ((x - lo) >> sh);
+          const u32 b = direct ? vv : __umulhi (vv, mul);
+          same += b == prev ? 1u : 0u;
+          prev = b;
+          cnt++;
+        }
+        if (cnt >= 8 && 2 * same > cnt) v |= 1ull << 9;
+      }
     }
   }
   part[t * NWAY_PSTRIDE + i] = v;
@@ -386,7 +415,7 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
   static_assert (NCH <= WAVE, "one lane per wave slot builds the slot table");
   static_assert (WPT * NT == NWORDS && WPT >= 1, "every thread scans the same number of counter words");
   static_assert (NW <= 16 && NW >= 2, "wave totals are reduced by one DPP row");
-  static_assert (NWAY_LIMIT % 6 == 0, "bucket walks go two or three steps a round");
+  static_assert (NWAY_LIMIT % 6 == 0 && NWAY_TRY0 <= NWAY_LIMIT, "bucket walks go two or three steps a round");
   static_assert (CAP <= 32767 && NB <= 65536, "16-bit bucket counters and starts; bucket, arrival number and a flag share a dword");
   static_assert (2 * NWAY_PSTRIDE <= WAVE, "one lane per partition entry of a tile");
   __shared__ Shared sh;
@@ -489,7 +518,18 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
     h = lane == 6 ? lo_hi : h;
     h = lane == 7 ? (u32) base : h;
     h = lane == 8 ? (u32) (base >> 32) : h;
-    if (lane < 9) sh.hdr[tb][lane] = h;
+    /* the longest run: the pivot of the second bucketing attempt (first position, records) */
+    u32 pv_len = 0, pv_base = 0;
+#pragma unroll
+    for (int q = 0; q < NWAY_MAX; q++) {
+      const u32 lq = (u32) __builtin_amdgcn_readlane ((int) len, q), bq = (u32) __builtin_amdgcn_readlane ((int) excl, q) * WAVE;
+      const bool better = lq > pv_len; /* uniform */
+      pv_base = better ? bq : pv_base;
+      pv_len = better ? lq : pv_len;
+    }
+    h = lane == 9 ? pv_base : h;
+    h = lane == 10 ? pv_len : h;
+    if (lane < 11) sh.hdr[tb][lane] = h;
   };
 
   /* The tile's records, fetched one tile ahead into registers.  A wavefront fetches 64 consecutive
@@ -571,7 +611,7 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
     const bool has_rec = (u32) (wid * RPT) < slots;          /* this wavefront holds records of the tile */
     const bool has_pos = (u32) (wid * RPT * WAVE) < n;       /* ... positions of the ordered tile */
 
-    /* ---- phase 0: the prefetched records: bucket number, arrival number (one LDS atomic) */
+    /* ---- phase 0: the prefetched records leave the fetch registers */
     u64 key[RPT];
     u32 cnt[RPT], ba[RPT]; /* ba: bucket | arrival number << 16 | valid << 31 */
 #pragma unroll
@@ -582,136 +622,214 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
     if (has_rec) {
 #pragma unroll
       for (int k = 0; k < RPT; k++) {
-        const int chunk = wid * RPT + k;
-        const u32 c = uniform32 (sh.slot_cnt[tb][chunk]);
         key[k] = (u64) pre[k].x | ((u64) pre[k].y << 32);
         cnt[k] = pre[k].z;
-        const u32 v = (u32) ((key[k] - key_lo) >> bk_sh);
-        u32 b = bk_direct ? v : __umulhi (v, bk_mul);
-        b = b < (u32) NB ? b : (u32) NB - 1u;
-#ifdef GT4_NWAY_SKIP_ATOMIC
-        if (MODE == NWAY_UNION) {
-          if ((u32) lane < c) ba[k] = b | 0x80000000u;
-        } else
-#endif
-        if ((u32) lane < c) {
-          const u32 s16 = (b & 1u) * 16u;
-          const u32 old = atomicAdd (&sh.cnt[b >> 1], 1u << s16);
-          ba[k] = b | (((old >> s16) & 0x7fffu) << 16) | 0x80000000u;
+      }
+    }
+    u32 xagg = 0;
+    u64 xcarry = 0;
+    u32 st[RPT];
+    u32 mx = 0;
+    bool accepted = false; /* the buckets of the last attempt are walked (else: the search path) */
+    /* one bucketing pass over bucket numbers bk[]: count (arrival numbers), scan, group the keys */
+    auto count_pass = [&] (const u32 (&bk)[RPT]) {
+      if (has_rec) {
+#pragma unroll
+        for (int k = 0; k < RPT; k++) {
+          const int chunk = wid * RPT + k;
+          const u32 c = uniform32 (sh.slot_cnt[tb][chunk]);
+          const u32 b = bk[k] < (u32) NB ? bk[k] : (u32) NB - 1u;
+          ba[k] = 0;
+          if ((u32) lane < c) {
+            const u32 s16 = (b & 1u) * 16u;
+            const u32 old = atomicAdd (&sh.cnt[b >> 1], 1u << s16);
+            ba[k] = b | (((old >> s16) & 0x7fffu) << 16) | 0x80000000u;
+          }
         }
       }
+    };
+    auto bucket_pass = [&] (u32 limit) {
+      PHASE_STAMP (0);
+      __syncthreads (); /* B1: every record is counted */
+      PHASE_STAMP (1);
+
+      /* ---- scan of the bucket counters: WPT words (two 16-bit counters each) per thread */
+      u32 ex[2 * WPT];
+      u32 tsum = 0, tmax = 0;
+      {
+        u32 w[WPT];
+#pragma unroll
+        for (int i = 0; i < WPT; i++) w[i] = sh.cnt[tid * WPT + i];
+#pragma unroll
+        for (int i = 0; i < WPT; i++) {
+          const u32 a = w[i] & 0xffffu, b = w[i] >> 16;
+          ex[2 * i] = tsum;
+          tsum += a;
+          ex[2 * i + 1] = tsum;
+          tsum += b;
+          tmax = a > tmax ? a : tmax;
+          tmax = b > tmax ? b : tmax;
+        }
+      }
+      const u32 incl = dpp_inclusive_scan_u32 (tsum);
+      const u32 wmx = dpp_wave_max_u32 (tmax);
+      if (lane == WAVE - 1) {
+        sh.wtot[wid] = incl;
+        sh.wmax[wid] = wmx;
+      }
+      PHASE_STAMP (2);
+      __syncthreads (); /* B2: wave totals */
+      PHASE_STAMP (3);
+      {
+        const u32 x = lane < NW ? sh.wtot[lane] : 0u;
+        const u32 y = lane < NW ? sh.wmax[lane] : 0u;
+        const u32 wbase = dpp_wave_sum_u32 (lane < wid ? x : 0u);
+        mx = dpp_wave_max_u32 (y);
+        const u32 tbase = wbase + incl - tsum;
+#pragma unroll
+        for (int i = 0; i < WPT; i++) sh.cnt[tid * WPT + i] = (tbase + ex[2 * i]) | ((tbase + ex[2 * i + 1]) << 16);
+        if (tid == NT - 1) sh.cnt[NWORDS] = tbase + tsum; /* start of the bucket behind the last = the tile's records */
+        /* What a bucket walk meets behind its bucket must not be smaller than any key: the following
+         * buckets' keys are not, and the skewed slots a bucket that crosses multiples of 32 leaves free
+         * behind its last key (two at most: walked buckets hold no more than 48 keys) get all-ones here,
+         * as do the slots behind the tile's last key */
+#pragma unroll
+        for (int j = 0; j < 2 * WPT; j++) {
+          const u32 s0 = tbase + ex[j], e0 = tbase + (j + 1 < 2 * WPT ? ex[j + 1 < 2 * WPT ? j + 1 : 0] : tsum);
+          if ((e0 >> 5) != (s0 >> 5)) {
+            sh.g[e0 + (s0 >> 5)] = ~0ull;
+            if ((e0 >> 5) - (s0 >> 5) > 1u) sh.g[e0 + (s0 >> 5) + 1u] = ~0ull;
+          }
+        }
+        if (tid < NWAY_LIMIT + 2) sh.g[nway_skew (n) + (u32) tid] = ~0ull; /* (+2: the walks read two steps ahead) */
+      }
+      PHASE_STAMP (4);
+      __syncthreads (); /* B3: bucket starts */
+      PHASE_STAMP (5);
+
+      /* ---- the keys grouped by bucket */
+#pragma unroll
+      for (int k = 0; k < RPT; k++) st[k] = 0;
+      accepted = mx <= limit;
+      if (has_rec && accepted) {
+#pragma unroll
+        for (int k = 0; k < RPT; k++) {
+          const u32 b = ba[k] & 0xffffu;
+          const u32 w0 = sh.cnt[b >> 1];
+          const u32 s = (b & 1u) ? w0 >> 16 : w0; /* start of the bucket */
+          st[k] = (ba[k] >> 31) ? (s & 0xffffu) : 0u;
+          if (ba[k] >> 31) sh.g[nway_skew (st[k]) + ((ba[k] >> 16) & 0x7fffu)] = key[k]; /* a bucket's keys stay together */
+        }
+      }
+      PHASE_STAMP (6);
+      __syncthreads (); /* B4: keys grouped */
+      PHASE_STAMP (7);
+#pragma unroll
+      for (int i = 0; i < WPT; i++) sh.cnt[tid * WPT + i] = 0; /* the next pass's / the next tile's counters */
+    };
+
+    /* ---- buckets.  First by interpolation inside the tile's key range (no search at all).  If a bucket
+     * then holds more than NWAY_TRY0 keys -- clustered keys: stretches of adjacent keys with wide gaps
+     * put a whole stretch into one bucket -- the tile is bucketed again, by RANK IN ITS LONGEST RUN (one
+     * binary search per record in that run's keys, copied to LDS): a bucket then holds what the other
+     * runs have between two neighbours of the pivot run, whatever the keys' values.  Only a tile that
+     * defeats that too (more than NWAY_LIMIT keys in a bucket) takes the full search path below. */
+    const bool pivot_first = ((bk0 >> 9) & 1u) && p.force_fallback == 0; /* the partition found the tile's samples clustered */
+    auto pivot_buckets = [&] (u32 (&bk)[RPT]) {
+      const u32 pv_base = uniform32 (sh.hdr[tb][9]), pv_len = uniform32 (sh.hdr[tb][10]);
+      /* the pivot run's keys to LDS, in order (its records sit at positions pv_base ..; sh.s.skey is free until the fold) */
+      if (has_rec) {
+#pragma unroll
+        for (int k = 0; k < RPT; k++) {
+          const u32 c = uniform32 (sh.slot_cnt[tb][wid * RPT + k]);
+          const u32 q = (u32) (wid * RPT + k) * WAVE + (u32) lane - pv_base;
+          if ((u32) lane < c && q < pv_len) sh.s.skey[q] = key[k];
+        }
+      }
+      __syncthreads (); /* pivot keys complete (and the counters are zero) */
+      /* sub-buckets per gap between two pivot keys, by interpolation inside the gap (what lies between
+       * two neighbours of the longest run is spread evenly far more often than the tile as a whole) */
+      u32 sub_bits = 0;
+      while (sub_bits < 3 && ((pv_len + 1u) << (sub_bits + 1)) <= (u32) NB) sub_bits++;
+      const float sub_n = (float) (1u << sub_bits);
+      u32 lb[RPT]; /* lower bounds in the pivot run: the searches of a thread's records in step */
+#pragma unroll
+      for (int k = 0; k < RPT; k++) lb[k] = 0;
+      for (u32 h = 1u << (31 - __builtin_clz (pv_len | 1u)); h; h >>= 1) { /* uniform trip count */
+        u64 pk[RPT];
+#pragma unroll
+        for (int k = 0; k < RPT; k++) pk[k] = sh.s.skey[(lb[k] + h <= pv_len ? lb[k] + h : 1u) - 1u];
+#pragma unroll
+        for (int k = 0; k < RPT; k++) lb[k] = (lb[k] + h <= pv_len && pk[k] < key[k]) ? lb[k] + h : lb[k];
+      }
+#pragma unroll
+      for (int k = 0; k < RPT; k++) {
+        const u32 b = lb[k];
+        /* key in (pk[b-1], pk[b]]: its place in the gap, monotone in the key (float conversions and
+         * products by positive constants are), the same for equal keys */
+        u32 sub = 0;
+        if (b > 0 && b < pv_len) {
+          const u64 lo_k = sh.s.skey[b - 1u], d = sh.s.skey[b] - lo_k, x = key[k] - lo_k;
+          const u32 shf = d >> 24 ? 40u - (u32) __builtin_clzll (d) : 0u; /* d >> shf below 2^24: exact in a float */
+          const float q = (float) (u32) (x >> shf) * sub_n / (float) ((u32) (d >> shf) + 1u);
+          sub = (u32) q;
+          sub = sub < (1u << sub_bits) ? sub : (1u << sub_bits) - 1u;
+        }
+        bk[k] = (b << sub_bits) + sub;
+      }
+    };
+    {
+      u32 bk[RPT];
+      if (__builtin_expect (pivot_first, 0)) {
+        pivot_buckets (bk);
+      } else {
+#pragma unroll
+        for (int k = 0; k < RPT; k++) {
+          const u32 v = (u32) ((key[k] - key_lo) >> bk_sh);
+          bk[k] = bk_direct ? v : __umulhi (v, bk_mul);
+        }
+      }
+      count_pass (bk); /* (the atomics first: their round trip overlaps what follows) */
     }
     /* the next tile's records: asked for as soon as this tile's have left the registers, a whole
      * iteration before they are looked at (its table was written during the previous iteration).  One
-     * tile per workgroup is all that is in flight: asked for later (behind the scan) the kernel without
-     * any of its ranking, folding and output still took 21.6 of its 30 ms -- the HBM round trip */
+     * tile per workgroup is all that is in flight. */
     {
       const u32 nxt = uniform32 (sh.hdr[tb1][0]);
       if (nxt < ntl && (u32) (wid * RPT) < uniform32 (sh.hdr[tb1][2])) fetch (tb1);
     }
     /* the ordered tile: counts 0, nothing live */
-#ifdef GT4_NWAY_SKIP_ZERO
-    if (MODE != NWAY_UNION)
-#endif
     for (int i = 4 * tid; i < CAPS; i += 4 * NT) *reinterpret_cast<u32x4 *> (&sh.s.scnt[i]) = u32x4 { 0, 0, 0, 0 };
-#ifdef GT4_NWAY_SKIP_ZERO
-    if (MODE != NWAY_UNION)
-#endif
     for (int i = tid; i < (CAPS + 3) / 4; i += NT) sh.live[i] = 0;
     /* service: the chain words of the tile staged one iteration ago are asked for; they are looked at
      * behind B4 at the earliest (the memory counter retires in order: a look waits for every older
      * operation of this wavefront, the previous write-out's stores included) */
-    u32 xagg = 0;
-    u64 xcarry = 0;
     if (service && MODE == NWAY_UNION && pend) {
       const u64 prow = pend_tile / WAVE;
       if ((u32) lane < pend_tile % WAVE) xagg = peek_u32 (&agg[prow * WAVE + lane]);
       xcarry = peek_u64 (&carry[prow]);
     }
-    PHASE_STAMP (0);
-    __syncthreads (); /* B1: every record is counted */
-    PHASE_STAMP (1);
 
-    /* ---- scan of the bucket counters: WPT words (two 16-bit counters each) per thread */
-    u32 ex[2 * WPT];
-    u32 tsum = 0, tmax = 0;
-    {
-      u32 w[WPT];
-#pragma unroll
-      for (int i = 0; i < WPT; i++) w[i] = sh.cnt[tid * WPT + i];
-#pragma unroll
-      for (int i = 0; i < WPT; i++) {
-        const u32 a = w[i] & 0xffffu, b = w[i] >> 16;
-        ex[2 * i] = tsum;
-        tsum += a;
-        ex[2 * i + 1] = tsum;
-        tsum += b;
-        tmax = a > tmax ? a : tmax;
-        tmax = b > tmax ? b : tmax;
-      }
+    /* ---- buckets.  Attempt 0: by interpolation inside the tile's key range (no search at all).  If a
+     * bucket holds more than NWAY_TRY0 keys -- clustered keys: stretches of adjacent keys with wide
+     * gaps put a whole stretch into one bucket -- attempt 1 buckets by RANK IN THE TILE'S LONGEST RUN
+     * (one binary search per record in that run's keys, copied to LDS): buckets then hold what the other
+     * runs have between two neighbours of the pivot run, whatever the keys' values.  Only a tile that
+     * defeats that too (more than NWAY_LIMIT keys in a bucket) takes the full search path below. */
+    bucket_pass (p.force_fallback ? 0u : (pivot_first ? (u32) NWAY_LIMIT : (u32) NWAY_TRY0));
+    if (p.force_fallback && mx == 0) accepted = true; /* (an empty tile) */
+    if (__builtin_expect (!accepted && !pivot_first && p.force_fallback != 1, 0)) { /* (cold: laid out behind the loop) */
+      u32 bk[RPT];
+      pivot_buckets (bk);
+      count_pass (bk);
+      bucket_pass ((u32) NWAY_LIMIT);
     }
-    const u32 incl = dpp_inclusive_scan_u32 (tsum);
-    const u32 wmx = dpp_wave_max_u32 (tmax);
-    if (lane == WAVE - 1) {
-      sh.wtot[wid] = incl;
-      sh.wmax[wid] = wmx;
-    }
-    PHASE_STAMP (2);
-    __syncthreads (); /* B2: wave totals */
-    PHASE_STAMP (3);
-    u32 mx;
-    {
-      const u32 x = lane < NW ? sh.wtot[lane] : 0u;
-      const u32 y = lane < NW ? sh.wmax[lane] : 0u;
-      const u32 wbase = dpp_wave_sum_u32 (lane < wid ? x : 0u);
-      mx = dpp_wave_max_u32 (y);
-      const u32 tbase = wbase + incl - tsum;
-#pragma unroll
-      for (int i = 0; i < WPT; i++) sh.cnt[tid * WPT + i] = (tbase + ex[2 * i]) | ((tbase + ex[2 * i + 1]) << 16);
-      if (tid == NT - 1) sh.cnt[NWORDS] = tbase + tsum; /* start of the bucket behind the last = the tile's records */
-      /* What a bucket walk meets behind its bucket must not be smaller than any key: the following
-       * buckets' keys are not, and the one skewed slot a bucket that crosses a multiple of 32 leaves
-       * free behind its last key gets all-ones here, as do the slots behind the tile's last key */
-#pragma unroll
-      for (int j = 0; j < 2 * WPT; j++) {
-        const u32 s0 = tbase + ex[j], e0 = tbase + (j + 1 < 2 * WPT ? ex[j + 1 < 2 * WPT ? j + 1 : 0] : tsum);
-        if ((e0 >> 5) != (s0 >> 5)) sh.g[e0 + (s0 >> 5)] = ~0ull;
-      }
-      if (tid < NWAY_LIMIT + 2) sh.g[nway_skew (n) + (u32) tid] = ~0ull; /* (+2: the walks read two steps ahead) */
-    }
-    PHASE_STAMP (4);
-    __syncthreads (); /* B3: bucket starts */
-    PHASE_STAMP (5);
-
-    /* ---- the keys grouped by bucket */
-    u32 st[RPT];
-#pragma unroll
-    for (int k = 0; k < RPT; k++) st[k] = 0;
-#ifdef GT4_NWAY_SKIP_GROUP
-    if (has_rec && MODE != NWAY_UNION) {
-#else
-    if (has_rec) {
-#endif
-#pragma unroll
-      for (int k = 0; k < RPT; k++) {
-        const u32 b = ba[k] & 0xffffu;
-        const u32 w0 = sh.cnt[b >> 1];
-        const u32 s = (b & 1u) ? w0 >> 16 : w0; /* start of the bucket */
-        st[k] = (ba[k] >> 31) ? (s & 0xffffu) : 0u;
-        if (ba[k] >> 31) sh.g[nway_skew (st[k]) + ((ba[k] >> 16) & 0x7fffu)] = key[k]; /* a bucket's keys stay together */
-      }
-    }
-    PHASE_STAMP (6);
-    __syncthreads (); /* B4: keys grouped */
-    PHASE_STAMP (7);
-#pragma unroll
-    for (int i = 0; i < WPT; i++) sh.cnt[tid * WPT + i] = 0; /* the next tile's counters */
 
     /* ---- position of every record = number of smaller keys in the tile */
     u32 pos[RPT];
 #pragma unroll
     for (int k = 0; k < RPT; k++) pos[k] = 0;
-    if (mx <= (u32) NWAY_LIMIT && !p.force_fallback) {
+    if (__builtin_expect (accepted, 1)) {
       if (has_rec) {
         u32 lt[RPT], ga[RPT];
         const u32 g0 = lds_offset (&sh.g[0]);
@@ -723,9 +841,7 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
         /* every lane runs the longest bucket's length (rounded up to even): behind its own bucket a lane
          * meets larger keys or all-ones */
         if constexpr (RPT == 4) {
-#ifdef GT4_NWAY_SKIP_RANK /* (subtractive builds: the union kernel alone, timing only) */
-          if (MODE != NWAY_UNION) nway_rank_steps<0> (mx, ga[0], ga[1], ga[2], ga[3], key, lt);
-#elif GT4_NWAY_WALK
+#if GT4_NWAY_WALK
           nway_rank_walk (mx, ga[0], ga[1], ga[2], ga[3], key, lt);
 #else
           nway_rank_steps<0> (mx, ga[0], ga[1], ga[2], ga[3], key, lt);
@@ -783,11 +899,7 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
     PHASE_STAMP (8);
 
     /* ---- the key once per position, the counts folded by LDS atomics */
-#ifdef GT4_NWAY_SKIP_FOLD
-    if (has_rec && MODE != NWAY_UNION) {
-#else
     if (has_rec) {
-#endif
 #pragma unroll
       for (int k = 0; k < RPT; k++) {
         if (!(ba[k] >> 31)) continue;
@@ -867,11 +979,7 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
       ocnt[i] = 0;
       kpre[i] = 0;
     }
-#ifdef GT4_NWAY_SKIP_ORDER
-    if (has_pos && MODE != NWAY_UNION) {
-#else
     if (has_pos) {
-#endif
 #pragma unroll
       for (int i = 0; i < RPT; i++) {
         const u32 q = nway_skew ((u32) (wid * RPT + i) * WAVE + (u32) lane);
@@ -1145,7 +1253,7 @@ int gt4hip_nway_union (gt4hip_context *ctx, const gt4hip_list *const lists[], ui
     lv.p.count_override = ovr;
     lv.p.filter = filter;
     lv.p.spin_limit = ctx->spin_limit;
-    lv.p.force_fallback = ctx->kway_vt == 99 ? 1u : 0u; /* option "kway_vt" = 99: every tile takes the search path (tests) */
+    lv.p.force_fallback = ctx->kway_vt == 99 ? 1u : (ctx->kway_vt == 98 ? 2u : 0u); /* option "kway_vt" = 99 / 98: every tile takes the search path / the pivot-run buckets (tests) */
     const int mode = l > 0 ? NWAY_DUPS : (count_only ? NWAY_COUNT : NWAY_UNION);
     lv.p.scan_group = ctx->scan_group > 0 ? 1u : (ctx->scan_group < 0 ? 0u : (tiles > (48000ull << 6) ? 1u : 0u));
     lv.p.dynamic = ctx->dynamic > 0 ? 1u : (ctx->dynamic < 0 ? 0u : (mode == NWAY_UNION ? 1u : 0u));

@@ -281,56 +281,82 @@ extern "C" int gt4hip_sort_words (gt4hip_context *ctx, void *device_words, uint6
   return rc;
 }
 
-extern "C" int gt4hip_words_to_list (gt4hip_context *ctx, const uint64_t *host_words, uint64_t n_words, uint32_t word_length, gt4hip_list **out)
+/* sorted device words -> list of (word, occurrences); `tmp` holds n_words u64 of scratch */
+static int fold_sorted_words (gt4hip_context *ctx, const u64 *words, u64 *tmp, uint64_t n_words, uint32_t word_length, gt4hip_list **out)
 {
-  if (!ctx || !out || (n_words && !host_words) || !word_length || word_length > 32) return GT4HIP_EINVAL;
-  HIPCHK (ctx, hipSetDevice (ctx->device));
-  *out = NULL;
-  if (!n_words) return gt4hip_list_new (ctx, 0, word_length, out);
-  u64 *words = NULL, *tmp = NULL;
-  if (gt4hip_dev_alloc (ctx, (void **) &words, (size_t) n_words * 8) != hipSuccess || gt4hip_dev_alloc (ctx, (void **) &tmp, (size_t) n_words * 8) != hipSuccess) {
-    if (words) hipFree (words);
-    return gt4hip_fail (ctx, GT4HIP_ENOMEM, "gt4hip_words_to_list: device buffers for %llu words", (unsigned long long) n_words);
-  }
   hipStream_t st = ctx->stream;
   int rc = GT4HIP_OK;
   gt4hip_list *l = NULL;
-  hipError_t e = hipMemcpyAsync (words, host_words, (size_t) n_words * 8, hipMemcpyHostToDevice, st);
-  if (e != hipSuccess) rc = gt4hip_fail (ctx, GT4HIP_EHIP, "gt4hip_words_to_list: upload failed: %s", hipGetErrorString (e));
-  if (!rc) rc = radix_sort_device (ctx, words, tmp, n_words, word_length);
+  hipError_t e;
+  /* block head counts, then head positions */
+  const uint64_t n_blocks = (n_words + FOLD_TILE - 1) / FOLD_TILE;
+  u64 *block_heads = NULL;
+  if (gt4hip_dev_alloc (ctx, (void **) &block_heads, (size_t) (n_blocks + 1) * 8) != hipSuccess) rc = gt4hip_fail (ctx, GT4HIP_ENOMEM, "gt4hip_words_to_list: workspace");
   if (!rc) {
-    /* `tmp` is free now: block head counts, then head positions */
-    const uint64_t n_blocks = (n_words + FOLD_TILE - 1) / FOLD_TILE;
-    u64 *block_heads = NULL;
-    if (gt4hip_dev_alloc (ctx, (void **) &block_heads, (size_t) (n_blocks + 1) * 8) != hipSuccess) rc = gt4hip_fail (ctx, GT4HIP_ENOMEM, "gt4hip_words_to_list: workspace");
+    hipLaunchKernelGGL (k_fold_count, dim3 ((unsigned) n_blocks), dim3 (FOLD_NT), 0, st, words, n_words, block_heads);
+    hipLaunchKernelGGL (k_fold_scan, dim3 (1), dim3 (1024), 0, st, block_heads, n_blocks, ctx->scratch);
+    hipLaunchKernelGGL (k_fold_positions, dim3 ((unsigned) n_blocks), dim3 (FOLD_NT), 0, st, words, n_words, block_heads, tmp);
+    e = hipMemcpyAsync (ctx->scratch_host, ctx->scratch, 8, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize (st);
+    if (e != hipSuccess) rc = gt4hip_fail (ctx, GT4HIP_EHIP, "gt4hip_words_to_list: %s", hipGetErrorString (e));
+  }
+  if (!rc) {
+    const uint64_t n_heads = ctx->scratch_host[0];
+    rc = gt4hip_list_new (ctx, n_heads, word_length, &l);
     if (!rc) {
-      hipLaunchKernelGGL (k_fold_count, dim3 ((unsigned) n_blocks), dim3 (FOLD_NT), 0, st, words, n_words, block_heads);
-      hipLaunchKernelGGL (k_fold_scan, dim3 (1), dim3 (1024), 0, st, block_heads, n_blocks, ctx->scratch);
-      hipLaunchKernelGGL (k_fold_positions, dim3 ((unsigned) n_blocks), dim3 (FOLD_NT), 0, st, words, n_words, block_heads, tmp);
-      e = hipMemcpyAsync (ctx->scratch_host, ctx->scratch, 8, hipMemcpyDeviceToHost, st);
-      if (e == hipSuccess) e = hipStreamSynchronize (st);
+      u64 g = (n_heads + 255) / 256;
+      if (g > 8192) g = 8192;
+      if (g < 1) g = 1;
+      hipLaunchKernelGGL (k_fold_records, dim3 ((unsigned) g), dim3 (256), 0, st, words, n_words, tmp, n_heads, (u32 *) l->dev);
+      e = hipStreamSynchronize (st);
       if (e != hipSuccess) rc = gt4hip_fail (ctx, GT4HIP_EHIP, "gt4hip_words_to_list: %s", hipGetErrorString (e));
     }
-    if (!rc) {
-      const uint64_t n_heads = ctx->scratch_host[0];
-      rc = gt4hip_list_new (ctx, n_heads, word_length, &l);
-      if (!rc) {
-        u64 g = (n_heads + 255) / 256;
-        if (g > 8192) g = 8192;
-        if (g < 1) g = 1;
-        hipLaunchKernelGGL (k_fold_records, dim3 ((unsigned) g), dim3 (256), 0, st, words, n_words, tmp, n_heads, (u32 *) l->dev);
-        e = hipStreamSynchronize (st);
-        if (e != hipSuccess) rc = gt4hip_fail (ctx, GT4HIP_EHIP, "gt4hip_words_to_list: %s", hipGetErrorString (e));
-      }
-    }
-    if (block_heads) hipFree (block_heads);
   }
-  hipFree (words);
-  hipFree (tmp);
+  if (block_heads) hipFree (block_heads);
   if (rc) {
     if (l) gt4hip_list_free (l);
     return rc;
   }
   *out = l;
   return GT4HIP_OK;
+}
+
+/* The same for words that are in device memory already (sorted in place, then folded): what a k-mer
+ * extraction kernel upstream would hand over; also what bench.py --workload sort times. */
+extern "C" int gt4hip_device_words_to_list (gt4hip_context *ctx, void *device_words, uint64_t n_words, uint32_t word_length, gt4hip_list **out)
+{
+  if (!ctx || !out || (n_words && !device_words) || !word_length || word_length > 32) return GT4HIP_EINVAL;
+  HIPCHK (ctx, hipSetDevice (ctx->device));
+  *out = NULL;
+  if (!n_words) return gt4hip_list_new (ctx, 0, word_length, out);
+  u64 *tmp = NULL;
+  if (gt4hip_dev_alloc (ctx, (void **) &tmp, (size_t) n_words * 8) != hipSuccess)
+    return gt4hip_fail (ctx, GT4HIP_ENOMEM, "gt4hip_device_words_to_list: %llu bytes of scratch", (unsigned long long) n_words * 8);
+  hipEventRecord (ctx->ev[0], ctx->stream);
+  int rc = radix_sort_device (ctx, (u64 *) device_words, tmp, n_words, word_length);
+  hipEventRecord (ctx->ev[1], ctx->stream);
+  if (!rc) rc = fold_sorted_words (ctx, (const u64 *) device_words, tmp, n_words, word_length, out);
+  hipEventRecord (ctx->ev[2], ctx->stream);
+  hipStreamSynchronize (ctx->stream);
+  float ms = 0;
+  if (hipEventElapsedTime (&ms, ctx->ev[0], ctx->ev[1]) == hipSuccess) ctx->sort_ms = ms;
+  if (hipEventElapsedTime (&ms, ctx->ev[1], ctx->ev[2]) == hipSuccess) ctx->fold_ms = ms;
+  hipFree (tmp);
+  return rc;
+}
+
+extern "C" int gt4hip_words_to_list (gt4hip_context *ctx, const uint64_t *host_words, uint64_t n_words, uint32_t word_length, gt4hip_list **out)
+{
+  if (!ctx || !out || (n_words && !host_words) || !word_length || word_length > 32) return GT4HIP_EINVAL;
+  HIPCHK (ctx, hipSetDevice (ctx->device));
+  *out = NULL;
+  if (!n_words) return gt4hip_list_new (ctx, 0, word_length, out);
+  u64 *words = NULL;
+  if (gt4hip_dev_alloc (ctx, (void **) &words, (size_t) n_words * 8) != hipSuccess)
+    return gt4hip_fail (ctx, GT4HIP_ENOMEM, "gt4hip_words_to_list: device buffers for %llu words", (unsigned long long) n_words);
+  hipError_t e = hipMemcpyAsync (words, host_words, (size_t) n_words * 8, hipMemcpyHostToDevice, ctx->stream);
+  int rc = e == hipSuccess ? GT4HIP_OK : gt4hip_fail (ctx, GT4HIP_EHIP, "gt4hip_words_to_list: upload failed: %s", hipGetErrorString (e));
+  if (!rc) rc = gt4hip_device_words_to_list (ctx, words, n_words, word_length, out);
+  hipFree (words);
+  return rc;
 }

@@ -269,6 +269,9 @@ int gt4hip_sort_words (gt4hip_context *ctx, void *device_words, uint64_t n_words
  * to its temporary lists before gt4_write_union collates them (src/glistmaker.c:914-924, :333, :814). */
 int gt4hip_words_to_list (gt4hip_context *ctx, const uint64_t *host_words, uint64_t n_words, uint32_t word_length,
                           gt4hip_list **out);
+/* The same for words already in device memory (sorted in place, then folded). */
+int gt4hip_device_words_to_list (gt4hip_context *ctx, void *device_words, uint64_t n_words, uint32_t word_length,
+                                 gt4hip_list **out);
 
 /* ---------------------------------------------------------------- synthetic lists (bench) */
 

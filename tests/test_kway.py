@@ -126,6 +126,21 @@ def test_every_tile_through_the_search_path(ctx):
         ctx.set_option("kway_vt", 0)
 
 
+def test_every_tile_bucketed_by_its_pivot_run(ctx):
+    """Option kway_vt = 98: every tile skips the interpolation and is bucketed by rank in its longest run
+    (what tiles with clustered keys do on their own)."""
+    ctx.set_option("kway_vt", 98)
+    try:
+        for n_lists, rule, cutoff in ((3, 0, 1), (8, 4, 2), (5, 7, 3), (8, 1, 0)):
+            rng = np.random.default_rng(989 + n_lists)
+            _check(ctx, _random_lists(rng, n_lists, 50000), rule=rule, cutoff=cutoff)
+        # identical lists: every key eight times, the pivot's buckets hold eight keys each
+        keys = np.unique(rng.integers(0, 1 << 50, size=60000, dtype=np.uint64))
+        _check(ctx, [U.make_records(keys, rng.integers(1, 9, size=len(keys), dtype=np.uint32)) for _ in range(8)], k=25)
+    finally:
+        ctx.set_option("kway_vt", 0)
+
+
 def test_clustered_keys(ctx):
     """Clusters of adjacent keys 2^40 apart: the interpolation puts a whole cluster into one bucket, the
     tiles take the search path on their own."""
