@@ -286,7 +286,8 @@ def bench_union8(args, ctx, capi, rank, local_rank, world):
 def bench_sort(args, ctx, capi):
     """SURVEY 8f N2 (glistmaker's table step): --ns random k-mer words in HBM -> sorted (word, occurrences)
     list (wordtable_sort + wordtable_find_frequencies, reference src/word-table.c:217-260 on top of
-    src/utils.c:127-198), by gt4hip_device_words_to_list: LSD radix sort, 8-bit digits, then the fold."""
+    src/utils.c:127-198), by gt4hip_device_words_to_list: LSD radix sort, 8-bit digits (one histogram kernel for all passes,
+    one chained-scan scatter kernel per pass), then the fold."""
     import numpy as np
     import torch
     n, k = args.ns, args.k
@@ -330,7 +331,7 @@ def bench_sort(args, ctx, capi):
            "roofline": {"bound": "hbm", "kernel": "k_radix_hist + k_radix_scatter x %d passes" % passes, "achieved": alg / (s_ms * 1e-3) / 1e9,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                         "algorithmic_bytes_per_launch": alg, "kernel_ms_avg": s_ms, "fold_ms_avg": statistics.mean(fold_ms),
-                        "note": "achieved = 16 B x passes x words / time of the radix passes (HIP events); the histogram pass reads the words once more (24 B per word and pass really move)"}}
+                        "note": "achieved = 16 B x passes x words / time of the sort (HIP events: histogram kernel + passes); the histogram kernel reads the words once more (8 B per word, once)"}}
     if not args.no_cpu_baseline:
         m = min(n, args.cpu_sample // 4)
         host = pristine[:m].cpu().numpy().astype(np.uint64)

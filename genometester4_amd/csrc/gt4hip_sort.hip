@@ -7,132 +7,236 @@
  * on top of hybridInPlaceRadixSort256 (src/utils.c:127-198: in-place MSD radix sort, 8-bit digits,
  * insertion sort below 32 words; only the digits below 2 * wordlength bits are visited).
  *
- *   K8 k_radix_hist     per block of 2048 words: how many words carry each value of the pass's 8-bit digit
- *      k_radix_scan_*   exclusive prefix of those counts in (digit, block) order = where every block's
- *                       words of every digit go
- *   K9 k_radix_scatter  stable placement: eight rounds of 256 words per block; inside a wavefront the
- *                       words of one digit find each other with eight ballots, wavefronts are ordered
- *                       through per-wavefront digit counts in LDS, rounds through running counts
+ *   K8 k_radix_hist     ONE read of the words: how many carry each value of every pass's 8-bit digit
+ *      k_radix_bases    exclusive prefix over the digits = where each digit's words start, per pass
+ *   K9 k_radix_scatter  one launch per pass, one 8192-word tile per workgroup (by ticket): stable ranks inside
+ *                       a wavefront by eight ballots (lanes with the same digit find each other) on top of
+ *                       per-wavefront digit counters in LDS; the tile sorted by digit in LDS; where it goes
+ *                       behind the earlier tiles by a chained scan over per-(tile, digit) state words
+ *                       (aggregate published early, look-back four tiles per round trip); the tile leaves
+ *                       LDS in runs of one digit
  *   K10 k_fold_*        heads of the runs of equal words (word differs from its left neighbour) ->
  *                       their positions, compacted in order; count = distance to the next head
  *
  * LSD order (least significant digit first, every pass stable), ceil (2k / 8) passes, two buffers.
- * An HBM-bound streaming sort: 16 bytes moved per word and pass.
+ * An HBM-bound streaming sort: 16 bytes moved per word and pass, 8 more once for the histograms.
+ * Measured (1e9 random 50-bit words, MI355X): 36.3 ms; the first version of this file (a histogram
+ * kernel per pass, words scattered 8 bytes at a time) took 100.6 ms, rocprim::radix_sort_keys 40.5 ms
+ * (profiles/round3/r3_sort_experiments.log).
  */
 #include "gt4hip_device.h"
 #include "gt4hip_host.h"
 
+#include <stdio.h>
 #include <string.h>
 
 namespace gt4 {
 
 namespace {
 
-constexpr int RADIX_NT = 256;
-constexpr int RADIX_ITEMS = 8;
+typedef u32 u32x2 __attribute__ ((ext_vector_type (2)));
+
+/* ---- radix sort: one histogram kernel for all passes, then one scatter kernel per pass */
+
+#ifndef GT4_RADIX_NT
+#define GT4_RADIX_NT 512
+#endif
+#ifndef GT4_RADIX_ITEMS
+#define GT4_RADIX_ITEMS 16
+#endif
+constexpr int RADIX_NT = GT4_RADIX_NT;        /* threads per tile */
+constexpr int RADIX_ITEMS = GT4_RADIX_ITEMS;  /* words per thread */
 constexpr int RADIX_TILE = RADIX_NT * RADIX_ITEMS;
+constexpr int RADIX_NW = RADIX_NT / WAVE;
+constexpr int RADIX_MAX_PASSES = 8;
+#ifndef GT4_RADIX_WAVES
+#define GT4_RADIX_WAVES 4 /* wavefronts per SIMD the scatter kernel's registers must leave room for: two workgroups per CU */
+#endif
+#ifndef GT4_RADIX_LOOK
+#define GT4_RADIX_LOOK 4
+#endif
+constexpr int RADIX_LOOK = GT4_RADIX_LOOK; /* earlier tiles inspected per round trip of the look-back */
+constexpr int HIST_NT = 256;
+constexpr int HIST_ITEMS = 16;
 
-__global__ __launch_bounds__ (RADIX_NT) void k_radix_hist (const u64 *__restrict__ in, u64 n, u32 shift, u32 *__restrict__ hist, u32 n_blocks)
+/* Tile states of the chained scan, one 64-bit word per (tile, digit): what the tile holds of the digit
+ * (AGG) or what all tiles up to and including it hold (PREFIX), tagged with the pass so that the words
+ * need no clearing between passes.  A word is published and read whole: no fences. */
+constexpr u64 RADIX_AGG = 1ull << 62, RADIX_PREFIX = 2ull << 62;
+constexpr u64 RADIX_VALUE = (1ull << 56) - 1;
+__device__ __forceinline__ u64 radix_tag (u32 pass) { return (u64) (pass + 1) << 56; }
+
+/* all passes' digit counts in one read of the words: LDS counters per block, flushed by global atomics */
+__global__ __launch_bounds__ (HIST_NT) void k_radix_hist (const u64 *__restrict__ in, u64 n, u32 passes, u64 *__restrict__ ghist)
 {
-  __shared__ u32 h[256];
-  h[threadIdx.x] = 0;
+  __shared__ u32 h[RADIX_MAX_PASSES][256];
+  for (u32 p = 0; p < passes; p++) h[p][threadIdx.x] = 0;
   __syncthreads ();
-  const u64 base = (u64) blockIdx.x * RADIX_TILE;
+  const u64 chunk = (u64) HIST_NT * HIST_ITEMS;
+  for (u64 base = (u64) blockIdx.x * chunk; base < n; base += (u64) gridDim.x * chunk) {
+    u64 w[HIST_ITEMS];
 #pragma unroll
-  for (int r = 0; r < RADIX_ITEMS; r++) {
-    const u64 i = base + (u64) r * RADIX_NT + threadIdx.x;
-    if (i < n) atomicAdd (&h[(u32) (in[i] >> shift) & 255u], 1u);
-  }
-  __syncthreads ();
-  hist[(u64) threadIdx.x * n_blocks + blockIdx.x] = h[threadIdx.x]; /* digit-major: the scan walks one digit's blocks in a row */
-}
-
-/* one block per digit: exclusive prefix of its row in place, row total to totals[digit] */
-__global__ __launch_bounds__ (1024) void k_radix_scan_rows (u32 *__restrict__ hist, u32 n_blocks, u64 *__restrict__ totals)
-{
-  __shared__ u32 wsum[16];
-  __shared__ u64 carry_s;
-  u32 *row = hist + (u64) blockIdx.x * n_blocks;
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  if (threadIdx.x == 0) carry_s = 0;
-  __syncthreads ();
-  for (u32 b0 = 0; b0 < n_blocks; b0 += 1024) {
-    const u32 i = b0 + threadIdx.x;
-    const u32 v = i < n_blocks ? row[i] : 0u;
-    const u32 incl = dpp_inclusive_scan_u32 (v);
-    if (lane == 63) wsum[wid] = incl;
-    __syncthreads ();
-    u32 before = 0, all = 0;
-    for (int w = 0; w < 16; w++) {
-      const u32 s = wsum[w];
-      before += w < wid ? s : 0u;
-      all += s;
+    for (int r = 0; r < HIST_ITEMS; r++) {
+      const u64 i = base + (u64) r * HIST_NT + threadIdx.x;
+      w[r] = i < n ? in[i] : 0;
     }
-    const u64 c = carry_s;
-    /* offsets of one digit stay below 2^32 as long as the whole array does (checked by the host) */
-    if (i < n_blocks) row[i] = (u32) (c + before + incl - v);
-    __syncthreads ();
-    if (threadIdx.x == 0) carry_s = c + all;
-    __syncthreads ();
-  }
-  if (threadIdx.x == 0) totals[blockIdx.x] = carry_s;
-}
-
-__global__ void k_radix_scan_totals (u64 *totals)
-{
-  if (threadIdx.x) return;
-  u64 run = 0;
-  for (int d = 0; d < 256; d++) {
-    const u64 v = totals[d];
-    totals[d] = run;
-    run += v;
-  }
-}
-
-__global__ __launch_bounds__ (RADIX_NT) void k_radix_scatter (const u64 *__restrict__ in, u64 *__restrict__ out, u64 n, u32 shift, const u32 *__restrict__ hist,
-                                                             const u64 *__restrict__ totals, u32 n_blocks)
-{
-  constexpr int NW = RADIX_NT / WAVE;
-  __shared__ u32 running[256];  /* words of each digit placed by earlier rounds of this block */
-  __shared__ u32 wcnt[NW][256]; /* words of each digit per wavefront, this round */
-  __shared__ u64 gbase[256];    /* where this block's words of each digit start in `out` */
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  running[tid] = 0;
 #pragma unroll
-  for (int w = 0; w < NW; w++) wcnt[w][tid] = 0;
-  gbase[tid] = totals[tid] + hist[(u64) tid * n_blocks + blockIdx.x];
+    for (int r = 0; r < HIST_ITEMS; r++) {
+      if (base + (u64) r * HIST_NT + threadIdx.x < n)
+        for (u32 p = 0; p < passes; p++) atomicAdd (&h[p][(u32) (w[r] >> (8 * p)) & 255u], 1u);
+    }
+  }
   __syncthreads ();
-  const u64 base = (u64) blockIdx.x * RADIX_TILE;
+  for (u32 p = 0; p < passes; p++)
+    if (h[p][threadIdx.x]) atomicAdd ((unsigned long long *) &ghist[p * 256 + threadIdx.x], (unsigned long long) h[p][threadIdx.x]);
+}
+
+/* per pass: where the words of every digit start (exclusive prefix over the digits); block = pass */
+__global__ __launch_bounds__ (256) void k_radix_bases (u64 *__restrict__ ghist)
+{
+  __shared__ u64 ws[4];
+  u64 *row = ghist + (u64) blockIdx.x * 256;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const u64 v = row[threadIdx.x];
+  const u64 incl = wave_inclusive_scan (v, lane);
+  if (lane == 63) ws[wid] = incl;
+  __syncthreads ();
+  u64 before = 0;
+  for (int w = 0; w < wid; w++) before += ws[w];
+  row[threadIdx.x] = before + incl - v;
+}
+
+/* One pass: tile t's words go behind everything the earlier tiles hold of the same digit, in the order
+ * they came (stable).  Tiles are taken by ticket, so a tile's predecessors have all started.
+ *   1. a wavefront owns RADIX_ITEMS * 64 consecutive words, read 64 at a time; the lanes holding the same
+ *      digit find each other with eight ballots; the wavefront's private digit counters (LDS) give every
+ *      word its rank among the wavefront's words of that digit;
+ *   2. digit totals of the tile -> published (AGG); prefix over wavefronts and digits = every word's
+ *      place in the tile sorted by digit; the words go there (LDS);
+ *   3. 256 threads look back, one per digit, over the earlier tiles' states until they meet a PREFIX;
+ *      the tile's own PREFIX is published;
+ *   4. the tile leaves LDS in digit order: runs of one digit go to consecutive addresses. */
+__global__ __launch_bounds__ (RADIX_NT, GT4_RADIX_WAVES) void k_radix_scatter (const u64 *__restrict__ in, u64 *__restrict__ out, u64 n, u32 pass, const u64 *__restrict__ gbase,
+                                                                              u64 *__restrict__ state, u32 *__restrict__ ticket)
+{
+  __shared__ u64 keys[RADIX_TILE];
+  __shared__ u32 wcnt[RADIX_NW][256]; /* per wavefront: words of each digit so far; later: where the wavefront's words of the digit start in the sorted tile */
+  __shared__ u32 hcnt[256];          /* words of each digit in the tile */
+  __shared__ u64 gofs[256];          /* address of the tile's first word of each digit in `out`, minus its place in the sorted tile */
+  __shared__ u32 wtot[4];
+  __shared__ u32 tile_s;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const u32 shift = 8 * pass;
+  if (tid == 0) tile_s = atomicAdd (ticket, 1u);
+#pragma unroll
+  for (int i = tid; i < RADIX_NW * 256; i += RADIX_NT) (&wcnt[0][0])[i] = 0;
+  if (tid < 256) hcnt[tid] = 0;
+  __syncthreads ();
+  const u64 tile = tile_s;
+  const u64 base = tile * RADIX_TILE;
+  const u32 nv = n - base < (u64) RADIX_TILE ? (u32) (n - base) : (u32) RADIX_TILE;
+  u64 key[RADIX_ITEMS];
+  {
+    /* a range-checked descriptor over the tile: no per-lane bounds, no addresses in registers */
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc ((void *) (in + base), 0, (int) (8 * nv), 0x00020000);
+#pragma unroll
+    for (int r = 0; r < RADIX_ITEMS; r++) {
+      const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64 (rs, 8 * lane, 8 * WAVE * (wid * RADIX_ITEMS + r), 0);
+      key[r] = (u64) v.x | ((u64) v.y << 32);
+    }
+  }
+  /* what the tile holds of every digit, as early as it can be known (LDS atomics; the stable ranks
+   * below take several times as long): the later tiles look back for it */
+#pragma unroll
   for (int r = 0; r < RADIX_ITEMS; r++) {
-    const u64 i = base + (u64) r * RADIX_NT + tid;
-    const bool in_range = i < n;
-    const u64 key = in_range ? in[i] : 0;
-    const u32 d = (u32) (key >> shift) & 255u;
-    /* lanes of this wavefront with the same digit (out-of-range lanes match nobody) */
-    u64 m = __builtin_amdgcn_ballot_w64 (in_range);
+    const u32 q = (u32) (wid * RADIX_ITEMS + r) * WAVE + (u32) lane;
+    if (q < nv) atomicAdd (&hcnt[(u32) (key[r] >> shift) & 255u], 1u);
+  }
+  __syncthreads ();
+  u32 cnt_d = 0;
+  if (tid < 256) {
+    cnt_d = hcnt[tid];
+    __hip_atomic_store (&state[tile * 256 + tid], (tile == 0 ? RADIX_PREFIX : RADIX_AGG) | radix_tag (pass) | (u64) cnt_d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  u32 rk[RADIX_ITEMS / 2]; /* 16 bits each */
+#pragma unroll
+  for (int r = 0; r < RADIX_ITEMS; r++) {
+    const u32 q = (u32) (wid * RADIX_ITEMS + r) * WAVE + (u32) lane;
+    const bool valid = q < nv;
+    const u32 d = (u32) (key[r] >> shift) & 255u;
+    u64 m = __builtin_amdgcn_ballot_w64 (valid);
 #pragma unroll
     for (int b = 0; b < 8; b++) {
       const u64 bal = __builtin_amdgcn_ballot_w64 ((d >> b) & 1u);
       m &= ((d >> b) & 1u) ? bal : ~bal;
     }
-    const u32 below = (u32) __popcll (m & ((1ull << lane) - 1ull));
-    if (in_range && below == 0) wcnt[wid][d] = (u32) __popcll (m);
-    __syncthreads ();
-    u32 pos = running[d] + below;
-    for (int w = 0; w < NW; w++) pos += w < wid ? wcnt[w][d] : 0u;
-    const u64 dst = gbase[d] + pos;
-    __syncthreads ();
-    {
-      u32 t = 0;
+    const u32 below = __builtin_amdgcn_mbcnt_hi ((u32) (m >> 32), __builtin_amdgcn_mbcnt_lo ((u32) m, 0u));
+    /* every lane of the group reads the counter, then its first lane adds the group (LDS executes a
+     * wavefront's accesses in order) */
+    const u32 old = valid ? wcnt[wid][d] : 0u;
+    if (valid && below == 0) wcnt[wid][d] = old + (u32) __popcll (m);
+    rk[r / 2] = (r & 1) ? rk[r / 2] | ((old + below) << 16) : old + below;
+  }
+  /* digit d = tid: its first place in the sorted tile */
+  u32 ls = 0;
+  if (tid < 256) {
+    const u32 incl = dpp_inclusive_scan_u32 (cnt_d);
+    if (lane == 63) wtot[wid] = incl;
+    ls = incl - cnt_d;
+  }
+  __syncthreads ();
+  if (tid < 256) {
+    for (int w = 0; w < wid; w++) ls += wtot[w];
+    u32 run = ls;
 #pragma unroll
-      for (int w = 0; w < NW; w++) {
-        t += wcnt[w][tid];
-        wcnt[w][tid] = 0;
-      }
-      running[tid] += t;
+    for (int w = 0; w < RADIX_NW; w++) { /* -> where wavefront w's words of the digit start */
+      const u32 c = wcnt[w][tid];
+      wcnt[w][tid] = run;
+      run += c;
     }
-    if (in_range) out[dst] = key;
-    __syncthreads ();
+  }
+  __syncthreads ();
+  /* the tile sorted by digit, in LDS */
+#pragma unroll
+  for (int r = 0; r < RADIX_ITEMS; r++) {
+    const u32 q = (u32) (wid * RADIX_ITEMS + r) * WAVE + (u32) lane;
+    const u32 d = (u32) (key[r] >> shift) & 255u;
+    if (q < nv) keys[wcnt[wid][d] + ((rk[r / 2] >> (16 * (r & 1))) & 0xffffu)] = key[r];
+  }
+  /* look back: what the earlier tiles hold of digit tid */
+  if (tid < 256) {
+    u64 excl = 0;
+    if (tile > 0) {
+      /* RADIX_LOOK earlier tiles per round trip: the states are asked for together and summed in order
+       * up to the first PREFIX (a serial walk meets ~20 AGG states per tile: 20 dependent round trips) */
+      const u64 mine = radix_tag (pass) >> 56;
+      auto ready = [&] (u64 v) { return (v >> 62) != 0 && ((v >> 56) & 63u) == mine; };
+      bool done = false;
+      for (u64 j = tile; !done; j -= RADIX_LOOK) {
+        u64 v[RADIX_LOOK];
+#pragma unroll
+        for (int i = 0; i < RADIX_LOOK; i++)
+          v[i] = j >= (u64) (1 + i) ? __hip_atomic_load (&state[(j - 1 - i) * 256 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (RADIX_PREFIX | radix_tag (pass));
+#pragma unroll
+        for (int i = 0; i < RADIX_LOOK; i++) {
+          if (done) continue;
+          while (!ready (v[i])) v[i] = __hip_atomic_load (&state[(j - 1 - i) * 256 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          excl += v[i] & RADIX_VALUE;
+          done = (v[i] & RADIX_PREFIX) != 0;
+        }
+      }
+      __hip_atomic_store (&state[tile * 256 + tid], RADIX_PREFIX | radix_tag (pass) | (excl + cnt_d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    gofs[tid] = gbase[pass * 256 + tid] + excl - ls;
+  }
+  __syncthreads ();
+#pragma unroll
+  for (int r = 0; r < RADIX_ITEMS; r++) {
+    const u32 q = (u32) r * RADIX_NT + (u32) tid;
+    if (q < nv) {
+      const u64 k = keys[q];
+      out[gofs[(u32) (k >> shift) & 255u] + q] = k;
+    }
   }
 }
 
@@ -233,39 +337,43 @@ __global__ void k_fold_records (const u64 *__restrict__ w, u64 n, const u64 *__r
 
 using namespace gt4;
 
-/* Sorts n 64-bit words in device memory ascending; `tmp` holds n more.  The result is in `words`. */
-static int radix_sort_device (gt4hip_context *ctx, u64 *words, u64 *tmp, uint64_t n, uint32_t word_length)
+/* Sorts n 64-bit words in device memory ascending; `tmp` holds n more.  The sorted words end up in
+ * `words` or in `tmp` (odd number of passes): *result says where. */
+static int radix_sort_device (gt4hip_context *ctx, u64 *words, u64 *tmp, uint64_t n, uint32_t word_length, u64 **result)
 {
+  *result = words;
   if (n < 2) return GT4HIP_OK;
-  if (n >= (1ull << 32)) return gt4hip_fail (ctx, GT4HIP_EINVAL, "gt4hip_sort_words: at most 2^32 - 1 words per call (%llu given)", (unsigned long long) n);
+  if (n >= RADIX_VALUE) return gt4hip_fail (ctx, GT4HIP_EINVAL, "gt4hip_sort_words: %llu words", (unsigned long long) n);
   const uint32_t bits = word_length >= 32 ? 64 : 2 * word_length;
   const uint32_t passes = (bits + 7) / 8;
-  const uint32_t n_blocks = (uint32_t) ((n + RADIX_TILE - 1) / RADIX_TILE);
-  u32 *hist = NULL;
-  u64 *totals = NULL;
-  if (gt4hip_dev_alloc (ctx, (void **) &hist, (size_t) 256 * n_blocks * 4) != hipSuccess ||
-      gt4hip_dev_alloc (ctx, (void **) &totals, 256 * 8) != hipSuccess) {
-    if (hist) hipFree (hist);
-    return gt4hip_fail (ctx, GT4HIP_ENOMEM, "gt4hip_sort_words: workspace allocation failed");
-  }
-  u64 *src = words, *dst = tmp;
+  const uint64_t tiles = (n + RADIX_TILE - 1) / RADIX_TILE;
+  if (tiles >= (1ull << 32)) return gt4hip_fail (ctx, GT4HIP_EINVAL, "gt4hip_sort_words: %llu words", (unsigned long long) n);
+  /* workspace: digit bases of every pass, a ticket per pass, the tile states */
+  const size_t head = (size_t) RADIX_MAX_PASSES * 256 * 8 + 64;
+  char *ws = NULL;
+  if (gt4hip_dev_alloc (ctx, (void **) &ws, head + (size_t) tiles * 256 * 8) != hipSuccess)
+    return gt4hip_fail (ctx, GT4HIP_ENOMEM, "gt4hip_sort_words: workspace of %llu bytes", (unsigned long long) (head + tiles * 256 * 8));
+  u64 *ghist = (u64 *) ws;
+  u32 *tickets = (u32 *) (ws + (size_t) RADIX_MAX_PASSES * 256 * 8);
+  u64 *state = (u64 *) (ws + head);
   hipStream_t st = ctx->stream;
+  hipError_t e = hipMemsetAsync (ws, 0, head + (size_t) tiles * 256 * 8, st);
+  u64 hb = (n + (u64) HIST_NT * HIST_ITEMS - 1) / ((u64) HIST_NT * HIST_ITEMS);
+  if (hb > (u64) ctx->n_cus * 8) hb = (u64) ctx->n_cus * 8;
+  hipLaunchKernelGGL (k_radix_hist, dim3 ((unsigned) hb), dim3 (HIST_NT), 0, st, words, n, passes, ghist);
+  hipLaunchKernelGGL (k_radix_bases, dim3 (passes), dim3 (256), 0, st, ghist);
+  u64 *src = words, *dst = tmp;
   for (uint32_t p = 0; p < passes; p++) {
-    const uint32_t shift = 8 * p;
-    hipLaunchKernelGGL (k_radix_hist, dim3 (n_blocks), dim3 (RADIX_NT), 0, st, src, n, shift, hist, n_blocks);
-    hipLaunchKernelGGL (k_radix_scan_rows, dim3 (256), dim3 (1024), 0, st, hist, n_blocks, totals);
-    hipLaunchKernelGGL (k_radix_scan_totals, dim3 (1), dim3 (64), 0, st, totals);
-    hipLaunchKernelGGL (k_radix_scatter, dim3 (n_blocks), dim3 (RADIX_NT), 0, st, src, dst, n, shift, hist, totals, n_blocks);
+    hipLaunchKernelGGL (k_radix_scatter, dim3 ((unsigned) tiles), dim3 (RADIX_NT), 0, st, src, dst, n, p, ghist, state, tickets + p);
     u64 *const t = src;
     src = dst;
     dst = t;
   }
-  hipError_t e = hipGetLastError ();
-  if (e == hipSuccess && src != words) e = hipMemcpyAsync (words, src, (size_t) n * 8, hipMemcpyDeviceToDevice, st);
+  if (e == hipSuccess) e = hipGetLastError ();
   if (e == hipSuccess) e = hipStreamSynchronize (st);
-  hipFree (hist);
-  hipFree (totals);
+  hipFree (ws);
   if (e != hipSuccess) return gt4hip_fail (ctx, GT4HIP_EHIP, "gt4hip_sort_words: %s", hipGetErrorString (e));
+  *result = src;
   return GT4HIP_OK;
 }
 
@@ -276,7 +384,13 @@ extern "C" int gt4hip_sort_words (gt4hip_context *ctx, void *device_words, uint6
   if (n_words < 2) return GT4HIP_OK;
   u64 *tmp = NULL;
   if (gt4hip_dev_alloc (ctx, (void **) &tmp, (size_t) n_words * 8) != hipSuccess) return gt4hip_fail (ctx, GT4HIP_ENOMEM, "gt4hip_sort_words: %llu bytes of scratch", (unsigned long long) n_words * 8);
-  const int rc = radix_sort_device (ctx, (u64 *) device_words, tmp, n_words, word_length);
+  u64 *res = NULL;
+  int rc = radix_sort_device (ctx, (u64 *) device_words, tmp, n_words, word_length, &res);
+  if (!rc && res != (u64 *) device_words) {
+    hipError_t e = hipMemcpyAsync (device_words, res, (size_t) n_words * 8, hipMemcpyDeviceToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize (ctx->stream);
+    if (e != hipSuccess) rc = gt4hip_fail (ctx, GT4HIP_EHIP, "gt4hip_sort_words: %s", hipGetErrorString (e));
+  }
   hipFree (tmp);
   return rc;
 }
@@ -333,9 +447,11 @@ extern "C" int gt4hip_device_words_to_list (gt4hip_context *ctx, void *device_wo
   if (gt4hip_dev_alloc (ctx, (void **) &tmp, (size_t) n_words * 8) != hipSuccess)
     return gt4hip_fail (ctx, GT4HIP_ENOMEM, "gt4hip_device_words_to_list: %llu bytes of scratch", (unsigned long long) n_words * 8);
   hipEventRecord (ctx->ev[0], ctx->stream);
-  int rc = radix_sort_device (ctx, (u64 *) device_words, tmp, n_words, word_length);
+  u64 *res = NULL;
+  int rc = radix_sort_device (ctx, (u64 *) device_words, tmp, n_words, word_length, &res);
   hipEventRecord (ctx->ev[1], ctx->stream);
-  if (!rc) rc = fold_sorted_words (ctx, (const u64 *) device_words, tmp, n_words, word_length, out);
+  /* (the words are the caller's scratch from here on: sorted in place or not, they are folded from wherever the last pass left them) */
+  if (!rc) rc = fold_sorted_words (ctx, res, res == tmp ? (u64 *) device_words : tmp, n_words, word_length, out);
   hipEventRecord (ctx->ev[2], ctx->stream);
   hipStreamSynchronize (ctx->stream);
   float ms = 0;

@@ -262,14 +262,16 @@ int gt4hip_comm_gatherv (gt4hip_comm *comm, const gt4hip_list *local, const uint
 
 /* Sorts n_words packed 64-bit k-mer words (device memory) ascending, in place: the reference's
  * wordtable_sort (src/word-table.c:217-231; hybridInPlaceRadixSort256, src/utils.c:127-198) as an LSD
- * radix sort over the 2 * word_length significant bits.  At most 2^32 - 1 words per call. */
+ * radix sort over the 2 * word_length significant bits (8-bit digits; one histogram kernel, then one
+ * chained-scan scatter kernel per digit).  Needs n_words * 8 bytes of scratch + 2 KB per 8192 words. */
 int gt4hip_sort_words (gt4hip_context *ctx, void *device_words, uint64_t n_words, uint32_t word_length);
 /* Sort + wordtable_find_frequencies (src/word-table.c:233-260): host words (any order, repeats
  * allowed) -> a new list of (word, number of occurrences) records, ascending -- what glistmaker writes
  * to its temporary lists before gt4_write_union collates them (src/glistmaker.c:914-924, :333, :814). */
 int gt4hip_words_to_list (gt4hip_context *ctx, const uint64_t *host_words, uint64_t n_words, uint32_t word_length,
                           gt4hip_list **out);
-/* The same for words already in device memory (sorted in place, then folded). */
+/* The same for words already in device memory.  The words are scratch from the call on: their buffer
+ * holds the sorted words or the last pass's input afterwards, whichever the number of passes leaves. */
 int gt4hip_device_words_to_list (gt4hip_context *ctx, void *device_words, uint64_t n_words, uint32_t word_length,
                                  gt4hip_list **out);
 

@@ -1,17 +1,17 @@
-"""Experiment driver (not product): throughput of gt4hip_words_to_list (sort + fold) on random words."""
-import os, sys, time
-import numpy as np
+"""Experiment driver (not product): gt4hip_device_words_to_list on random words; prints sort and fold times.
+usage: exp_sort.py [n words] [k]"""
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
 from genometester4_amd import capi
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 200_000_000
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000_000
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 25
-rng = np.random.default_rng(1)
-words = rng.integers(0, 1 << (2 * k if k < 32 else 63), size=n, dtype=np.uint64)
-words[::7] = words[::7][0]  # a heavy hitter
 ctx = capi.Context(0)
-for rep in range(3):
-    t0 = time.perf_counter()
-    lst = ctx.words_to_list(words, k)
-    dt = time.perf_counter() - t0
-    print("rep %d: %d words k=%d -> %d distinct in %.3f s (%.1f M words/s, upload included)" % (rep, n, k, lst.n_words, dt, n / dt / 1e6), flush=True)
+g = torch.Generator(device="cuda"); g.manual_seed(1)
+pristine = torch.randint(0, 1 << min(2 * k, 62), (n,), dtype=torch.int64, device="cuda", generator=g)
+work = torch.empty_like(pristine)
+for rep in range(int(os.environ.get("REPS", "3"))):
+    work.copy_(pristine); torch.cuda.synchronize()
+    lst = ctx.device_words_to_list(work.data_ptr(), n, k)
+    print("n", n, "k", k, "sort ms %.2f fold ms %.2f" % (ctx.get_counter("sort_us") / 1000.0, ctx.get_counter("fold_us") / 1000.0), "records", lst.n_words, "sorted", lst.is_sorted(), "sum", lst.sum_counts() == n, flush=True)
     lst.free()
