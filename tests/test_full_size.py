@@ -212,3 +212,28 @@ def test_config3_eight_way_union_full_size(ctx):
     finally:
         ctx.set_option("kway", 1)
     assert (nw3, tot3) == (nw2, tot2)
+
+
+def test_sort_and_fold_beyond_2_pow_32_words(ctx):
+    """N2 at a size the 32-bit version refused: 2^32 + 10^6 random k=16 words (32 significant bits, four
+    radix passes) -> sorted (word, occurrences) list.  Checked: ascending, the occurrences add up to the
+    number of words, and every record with a word below 2^17 against numpy on exactly those words
+    (wordtable_sort + wordtable_find_frequencies, reference src/word-table.c:217-260)."""
+    import torch
+    n, k = (1 << 32) + 1_000_000, 16
+    g = torch.Generator(device="cuda")
+    g.manual_seed(99)
+    words = torch.randint(0, 1 << 32, (n,), dtype=torch.int64, device="cuda", generator=g)
+    step = 1 << 30  # (torch's masked select does not take 2^32 elements at once)
+    low = np.concatenate([(lambda c: c[c < (1 << 17)].cpu().numpy())(words[i:i + step]) for i in range(0, n, step)]).astype(np.uint64)
+    lst = ctx.device_words_to_list(words.data_ptr(), n, k)
+    del words
+    torch.cuda.empty_cache()
+    assert lst.is_sorted()
+    assert lst.sum_counts() == n
+    exp_keys, exp_counts = np.unique(low, return_counts=True)
+    m = lst.lower_bound(1 << 17)
+    assert m == len(exp_keys)
+    got = lst.download_range(0, m)
+    assert (got["key"] == exp_keys).all() and (got["count"] == exp_counts.astype(np.uint32)).all()
+    lst.free()
