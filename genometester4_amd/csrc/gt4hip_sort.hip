@@ -15,8 +15,9 @@
  *                       behind the earlier tiles by a chained scan over per-(tile, digit) state words
  *                       (aggregate published early, look-back four tiles per round trip); the tile leaves
  *                       LDS in runs of one digit
- *   K10 k_fold_*        heads of the runs of equal words (word differs from its left neighbour) ->
- *                       their positions, compacted in order; count = distance to the next head
+ *   K10 k_fold_count    runs of equal words that start in each 8192-word tile (a word differs from its left
+ *                       neighbour) -> runs before the tile, by a chained scan (one state word per tile)
+ *       k_fold_records  record = (first word of the run, distance to the next run's start)
  *
  * LSD order (least significant digit first, every pass stable), ceil (2k / 8) passes, two buffers.
  * An HBM-bound streaming sort: 16 bytes moved per word and pass, 8 more once for the histograms.
@@ -35,6 +36,11 @@ namespace gt4 {
 namespace {
 
 typedef u32 u32x2 __attribute__ ((ext_vector_type (2)));
+
+__device__ __forceinline__ u64 readlane_u64 (u64 v, int l)
+{
+  return (u64) (u32) __builtin_amdgcn_readlane ((int) (u32) v, l) | ((u64) (u32) __builtin_amdgcn_readlane ((int) (u32) (v >> 32), l) << 32);
+}
 
 /* ---- radix sort: one histogram kernel for all passes, then one scatter kernel per pass */
 
@@ -242,92 +248,153 @@ __global__ __launch_bounds__ (RADIX_NT, GT4_RADIX_WAVES) void k_radix_scatter (c
 
 /* ---- folding equal words */
 
-constexpr int FOLD_NT = 256;
-constexpr int FOLD_ITEMS = 8;
+constexpr int FOLD_NT = 512;
+constexpr int FOLD_ITEMS = 16;
 constexpr int FOLD_TILE = FOLD_NT * FOLD_ITEMS;
+constexpr int FOLD_NW = FOLD_NT / WAVE;
+constexpr int FOLD_STRETCH = FOLD_ITEMS * WAVE; /* consecutive words of one wavefront */
 
-__device__ __forceinline__ bool is_head (const u64 *__restrict__ w, u64 i, u64 n) { return i < n && (i == 0 || w[i] != w[i - 1]); }
-
-__global__ __launch_bounds__ (FOLD_NT) void k_fold_count (const u64 *__restrict__ w, u64 n, u64 *__restrict__ block_heads)
+/* A tile's words, 64 consecutive ones per wavefront and round (as the scatter kernel reads them), and
+ * which of them start a run: bit r of the result = word r of this lane differs from the word before it
+ * (the previous lane's, the previous round's last lane's, or -- first word of the wavefront -- the one
+ * in memory before it; word 0 of all starts a run). */
+__device__ __forceinline__ u32 fold_heads (const u64 *__restrict__ w, u64 n, u64 base, u32 nv, int lane, int wid, u64 (&word)[FOLD_ITEMS])
 {
-  __shared__ u32 ws[FOLD_NT / WAVE];
-  u32 c = 0;
-  const u64 base = (u64) blockIdx.x * FOLD_TILE;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc ((void *) (w + base), 0, (int) (8 * nv), 0x00020000);
 #pragma unroll
-  for (int r = 0; r < FOLD_ITEMS; r++) c += is_head (w, base + (u64) r * FOLD_NT + threadIdx.x, n) ? 1u : 0u;
-  const u32 s = dpp_wave_sum_u32 (c);
-  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
-  __syncthreads ();
-  if (threadIdx.x == 0) {
-    u32 t = 0;
-    for (int i = 0; i < FOLD_NT / WAVE; i++) t += ws[i];
-    block_heads[blockIdx.x] = t;
+  for (int r = 0; r < FOLD_ITEMS; r++) {
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64 (rs, 8 * lane, 8 * WAVE * (wid * FOLD_ITEMS + r), 0);
+    word[r] = (u64) v.x | ((u64) v.y << 32);
   }
+  const u64 first = base + (u64) wid * FOLD_STRETCH;
+  u64 before = 0; /* (uniform) */
+  if (first > 0 && first < n) before = w[first - 1];
+  u32 flags = 0;
+#pragma unroll
+  for (int r = 0; r < FOLD_ITEMS; r++) {
+    const u32 q = (u32) (wid * FOLD_ITEMS + r) * WAVE + (u32) lane;
+    const u32 plo = (u32) __shfl_up ((u32) word[r], 1, WAVE), phi = (u32) __shfl_up ((u32) (word[r] >> 32), 1, WAVE);
+    u64 prev = (u64) plo | ((u64) phi << 32);
+    if (lane == 0) prev = r ? readlane_u64 (word[r ? r - 1 : 0], WAVE - 1) : before;
+    const bool head = q < nv && (base + q == 0 || word[r] != prev);
+    flags |= head ? 1u << r : 0u;
+  }
+  return flags;
 }
 
-/* exclusive prefix of block_heads in place (one block walks the array), total to *total */
-__global__ __launch_bounds__ (1024) void k_fold_scan (u64 *__restrict__ block_heads, u64 n_blocks, u64 *total)
+/* Pass 1: runs that start in each tile -> the number of runs before the tile (chained scan over one
+ * state word per tile: a whole wavefront looks back, 64 tiles per round trip); tiles by ticket. */
+__global__ __launch_bounds__ (FOLD_NT) void k_fold_count (const u64 *__restrict__ w, u64 n, u64 *__restrict__ state, u64 *__restrict__ tile_excl, u64 tiles, u32 *__restrict__ ticket,
+                                                        u64 *__restrict__ total)
 {
-  __shared__ u64 wsum[16];
-  __shared__ u64 carry_s;
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  if (threadIdx.x == 0) carry_s = 0;
-  __syncthreads ();
-  for (u64 b0 = 0; b0 < n_blocks; b0 += 1024) {
-    const u64 i = b0 + threadIdx.x;
-    const u64 v = i < n_blocks ? block_heads[i] : 0;
-    const u64 incl = wave_inclusive_scan (v, lane);
-    if (lane == 63) wsum[wid] = incl;
-    __syncthreads ();
-    u64 before = 0, all = 0;
-    for (int w = 0; w < 16; w++) {
-      const u64 s = wsum[w];
-      before += w < wid ? s : 0;
-      all += s;
-    }
-    const u64 c = carry_s;
-    if (i < n_blocks) block_heads[i] = c + before + incl - v;
-    __syncthreads ();
-    if (threadIdx.x == 0) carry_s = c + all;
-    __syncthreads ();
-  }
-  if (threadIdx.x == 0) *total = carry_s;
-}
-
-/* position of every head, compacted in order (row-major over the block's rounds: ascending index) */
-__global__ __launch_bounds__ (FOLD_NT) void k_fold_positions (const u64 *__restrict__ w, u64 n, const u64 *__restrict__ block_heads, u64 *__restrict__ head_pos)
-{
-  constexpr int NW = FOLD_NT / WAVE;
-  __shared__ u32 cnt[FOLD_ITEMS * NW];
+  __shared__ u32 ws[FOLD_NW];
+  __shared__ u32 tile_s;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const u64 base = (u64) blockIdx.x * FOLD_TILE;
-  u64 masks[FOLD_ITEMS];
-#pragma unroll
-  for (int r = 0; r < FOLD_ITEMS; r++) {
-    masks[r] = __builtin_amdgcn_ballot_w64 (is_head (w, base + (u64) r * FOLD_NT + tid, n));
-    if (lane == 0) cnt[r * NW + wid] = (u32) __popcll (masks[r]);
-  }
+  if (tid == 0) tile_s = atomicAdd (ticket, 1u);
   __syncthreads ();
-  const u64 out0 = block_heads[blockIdx.x];
-#pragma unroll
-  for (int r = 0; r < FOLD_ITEMS; r++) {
-    u32 before = 0;
-    for (int q = 0; q < r * NW + wid; q++) before += cnt[q];
-    if ((masks[r] >> lane) & 1ull) head_pos[out0 + before + (u32) __popcll (masks[r] & ((1ull << lane) - 1ull))] = base + (u64) r * FOLD_NT + tid;
+  const u64 tile = tile_s;
+  const u64 base = tile * FOLD_TILE;
+  const u32 nv = n - base < (u64) FOLD_TILE ? (u32) (n - base) : (u32) FOLD_TILE;
+  u64 word[FOLD_ITEMS];
+  const u32 flags = fold_heads (w, n, base, nv, lane, wid, word);
+  const u32 c = dpp_wave_sum_u32 ((u32) __popc (flags));
+  if (lane == 0) ws[wid] = c;
+  __syncthreads ();
+  if (wid != 0) return;
+  u32 cnt = 0;
+  for (int i = 0; i < FOLD_NW; i++) cnt += ws[i];
+  if (lane == 0) __hip_atomic_store (&state[tile], (tile == 0 ? RADIX_PREFIX : RADIX_AGG) | (u64) cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  u64 excl = 0;
+  for (u64 j = tile; j > 0;) {
+    const bool in = j >= (u64) (1 + lane);
+    u64 v;
+    u64 pm, need; /* lanes whose tile's state is a PREFIX; lanes up to the nearest of them */
+    do {
+      v = in ? __hip_atomic_load (&state[j - 1 - lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : RADIX_PREFIX;
+      pm = __builtin_amdgcn_ballot_w64 ((v & RADIX_PREFIX) != 0);
+      need = pm ? (2ull << __builtin_ctzll (pm)) - 1ull : ~0ull;
+    } while (__builtin_amdgcn_ballot_w64 ((v >> 62) == 0) & need);
+    excl += wave_sum (((need >> lane) & 1ull) ? (v & RADIX_VALUE) : 0ull);
+    if (pm) break;
+    j = j > (u64) WAVE ? j - WAVE : 0;
+  }
+  if (lane == 0) {
+    if (tile) __hip_atomic_store (&state[tile], RADIX_PREFIX | (excl + cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    tile_excl[tile] = excl;
+    if (tile + 1 == tiles) {
+      tile_excl[tiles] = excl + cnt;
+      *total = excl + cnt;
+    }
   }
 }
 
-/* record j = (word at head j, distance to head j + 1); the count is stored in 32 bits as the
- * reference does (`freqs[wi] = count`, src/word-table.c:245-251) */
-__global__ void k_fold_records (const u64 *__restrict__ w, u64 n, const u64 *__restrict__ head_pos, u64 n_heads, u32 *__restrict__ rec)
+/* Pass 2: record j = (word at the start of run j, length of the run).  The length is the distance to
+ * the next start: in the same 64 words, in the wavefront's later rounds, in the later wavefronts -- or
+ * behind the tile, found by wavefront 0 (tiles without a start are skipped by their counts).  The count
+ * is stored in 32 bits as the reference does (`freqs[wi] = count`, src/word-table.c:245-251). */
+__global__ __launch_bounds__ (FOLD_NT) void k_fold_records (const u64 *__restrict__ w, u64 n, const u64 *__restrict__ tile_excl, u64 tiles, u32 *__restrict__ rec)
 {
-  const u64 step = (u64) gridDim.x * blockDim.x;
-  for (u64 j = (u64) blockIdx.x * blockDim.x + threadIdx.x; j < n_heads; j += step) {
-    const u64 p = head_pos[j], q = j + 1 < n_heads ? head_pos[j + 1] : n;
-    const u64 key = w[p];
-    rec[3 * j] = (u32) key;
-    rec[3 * j + 1] = (u32) (key >> 32);
-    rec[3 * j + 2] = (u32) (q - p);
+  __shared__ u32 wcount[FOLD_NW];
+  __shared__ u32 wfirst[FOLD_NW]; /* first start in the wavefront's words (position in the tile), or FOLD_TILE */
+  __shared__ u64 next_s;          /* first start behind the tile */
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const u64 tile = blockIdx.x;
+  const u64 base = tile * FOLD_TILE;
+  const u32 nv = n - base < (u64) FOLD_TILE ? (u32) (n - base) : (u32) FOLD_TILE;
+  u64 word[FOLD_ITEMS];
+  const u32 flags = fold_heads (w, n, base, nv, lane, wid, word);
+  u32 mine = 0, first = (u32) FOLD_TILE;
+#pragma unroll
+  for (int r = FOLD_ITEMS - 1; r >= 0; r--) {
+    const u64 m = __builtin_amdgcn_ballot_w64 ((flags >> r) & 1u);
+    mine += (u32) __popcll (m);
+    if (m) first = (u32) (wid * FOLD_ITEMS + r) * WAVE + (u32) __builtin_ctzll (m);
+  }
+  if (lane == 0) {
+    wcount[wid] = mine;
+    wfirst[wid] = first;
+  }
+  if (wid == 0) {
+    /* the first start behind the tile: tiles without one are skipped, the first tile with one is
+     * searched 64 words at a time */
+    u64 u = tile + 1;
+    while (u < tiles && tile_excl[u + 1] == tile_excl[u]) u++;
+    u64 nx = n;
+    if (u < tiles) {
+      for (u64 i = u * FOLD_TILE;; i += WAVE) {
+        const u64 at = i + lane;
+        const bool head = at < n && w[at] != w[at - 1]; /* (at >= FOLD_TILE here) */
+        const u64 m = __builtin_amdgcn_ballot_w64 (head);
+        if (m) {
+          nx = i + (u64) __builtin_ctzll (m);
+          break;
+        }
+      }
+    }
+    if (lane == 0) next_s = nx;
+  }
+  __syncthreads ();
+  u32 rank = 0; /* starts in the earlier wavefronts */
+  for (int i = 0; i < wid; i++) rank += wcount[i];
+  u64 nh = next_s; /* the first start behind this wavefront's words */
+  for (int i = FOLD_NW - 1; i > wid; i--) nh = wfirst[i] < (u32) FOLD_TILE ? base + wfirst[i] : nh;
+  const u64 out0 = tile_excl[tile] + rank;
+  u32 running = mine;
+#pragma unroll
+  for (int r = FOLD_ITEMS - 1; r >= 0; r--) {
+    const u64 m = __builtin_amdgcn_ballot_w64 ((flags >> r) & 1u);
+    if (!m) continue; /* uniform */
+    running -= (u32) __popcll (m);
+    const u64 pos0 = base + (u64) (wid * FOLD_ITEMS + r) * WAVE;
+    if ((flags >> r) & 1u) {
+      const u64 above = lane == WAVE - 1 ? 0ull : m >> (lane + 1);
+      const u64 next = above ? pos0 + (u64) lane + 1ull + (u64) __builtin_ctzll (above) : nh;
+      const u64 j = out0 + running + __builtin_amdgcn_mbcnt_hi ((u32) (m >> 32), __builtin_amdgcn_mbcnt_lo ((u32) m, 0u));
+      rec[3 * j] = (u32) word[r];
+      rec[3 * j + 1] = (u32) (word[r] >> 32);
+      rec[3 * j + 2] = (u32) (next - (pos0 + (u64) lane));
+    }
+    nh = pos0 + (u64) __builtin_ctzll (m);
   }
 }
 
@@ -395,38 +462,35 @@ extern "C" int gt4hip_sort_words (gt4hip_context *ctx, void *device_words, uint6
   return rc;
 }
 
-/* sorted device words -> list of (word, occurrences); `tmp` holds n_words u64 of scratch */
-static int fold_sorted_words (gt4hip_context *ctx, const u64 *words, u64 *tmp, uint64_t n_words, uint32_t word_length, gt4hip_list **out)
+/* sorted device words -> list of (word, occurrences) */
+static int fold_sorted_words (gt4hip_context *ctx, const u64 *words, uint64_t n_words, uint32_t word_length, gt4hip_list **out)
 {
   hipStream_t st = ctx->stream;
   int rc = GT4HIP_OK;
   gt4hip_list *l = NULL;
   hipError_t e;
-  /* block head counts, then head positions */
-  const uint64_t n_blocks = (n_words + FOLD_TILE - 1) / FOLD_TILE;
-  u64 *block_heads = NULL;
-  if (gt4hip_dev_alloc (ctx, (void **) &block_heads, (size_t) (n_blocks + 1) * 8) != hipSuccess) rc = gt4hip_fail (ctx, GT4HIP_ENOMEM, "gt4hip_words_to_list: workspace");
-  if (!rc) {
-    hipLaunchKernelGGL (k_fold_count, dim3 ((unsigned) n_blocks), dim3 (FOLD_NT), 0, st, words, n_words, block_heads);
-    hipLaunchKernelGGL (k_fold_scan, dim3 (1), dim3 (1024), 0, st, block_heads, n_blocks, ctx->scratch);
-    hipLaunchKernelGGL (k_fold_positions, dim3 ((unsigned) n_blocks), dim3 (FOLD_NT), 0, st, words, n_words, block_heads, tmp);
-    e = hipMemcpyAsync (ctx->scratch_host, ctx->scratch, 8, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize (st);
-    if (e != hipSuccess) rc = gt4hip_fail (ctx, GT4HIP_EHIP, "gt4hip_words_to_list: %s", hipGetErrorString (e));
-  }
+  const uint64_t tiles = (n_words + FOLD_TILE - 1) / FOLD_TILE;
+  if (tiles >= (1ull << 32)) return gt4hip_fail (ctx, GT4HIP_EINVAL, "gt4hip_words_to_list: %llu words", (unsigned long long) n_words);
+  /* workspace: ticket, tile states, runs before every tile (+ the total) */
+  char *ws = NULL;
+  const size_t bytes = 64 + (size_t) tiles * 8 + (size_t) (tiles + 1) * 8;
+  if (gt4hip_dev_alloc (ctx, (void **) &ws, bytes) != hipSuccess) return gt4hip_fail (ctx, GT4HIP_ENOMEM, "gt4hip_words_to_list: workspace");
+  u64 *state = (u64 *) (ws + 64), *tile_excl = state + tiles;
+  e = hipMemsetAsync (ws, 0, 64 + (size_t) tiles * 8, st);
+  hipLaunchKernelGGL (k_fold_count, dim3 ((unsigned) tiles), dim3 (FOLD_NT), 0, st, words, n_words, state, tile_excl, tiles, (u32 *) ws, ctx->scratch);
+  if (e == hipSuccess) e = hipMemcpyAsync (ctx->scratch_host, ctx->scratch, 8, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize (st);
+  if (e != hipSuccess) rc = gt4hip_fail (ctx, GT4HIP_EHIP, "gt4hip_words_to_list: %s", hipGetErrorString (e));
   if (!rc) {
     const uint64_t n_heads = ctx->scratch_host[0];
     rc = gt4hip_list_new (ctx, n_heads, word_length, &l);
     if (!rc) {
-      u64 g = (n_heads + 255) / 256;
-      if (g > 8192) g = 8192;
-      if (g < 1) g = 1;
-      hipLaunchKernelGGL (k_fold_records, dim3 ((unsigned) g), dim3 (256), 0, st, words, n_words, tmp, n_heads, (u32 *) l->dev);
+      hipLaunchKernelGGL (k_fold_records, dim3 ((unsigned) tiles), dim3 (FOLD_NT), 0, st, words, n_words, tile_excl, tiles, (u32 *) l->dev);
       e = hipStreamSynchronize (st);
       if (e != hipSuccess) rc = gt4hip_fail (ctx, GT4HIP_EHIP, "gt4hip_words_to_list: %s", hipGetErrorString (e));
     }
   }
-  if (block_heads) hipFree (block_heads);
+  hipFree (ws);
   if (rc) {
     if (l) gt4hip_list_free (l);
     return rc;
@@ -451,7 +515,7 @@ extern "C" int gt4hip_device_words_to_list (gt4hip_context *ctx, void *device_wo
   int rc = radix_sort_device (ctx, (u64 *) device_words, tmp, n_words, word_length, &res);
   hipEventRecord (ctx->ev[1], ctx->stream);
   /* (the words are the caller's scratch from here on: sorted in place or not, they are folded from wherever the last pass left them) */
-  if (!rc) rc = fold_sorted_words (ctx, res, res == tmp ? (u64 *) device_words : tmp, n_words, word_length, out);
+  if (!rc) rc = fold_sorted_words (ctx, res, n_words, word_length, out);
   hipEventRecord (ctx->ev[2], ctx->stream);
   hipStreamSynchronize (ctx->stream);
   float ms = 0;

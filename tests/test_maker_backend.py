@@ -66,6 +66,21 @@ def test_sort_and_fold_against_numpy(ctx, n, k):
     assert lst.is_sorted()
 
 
+@pytest.mark.parametrize("runs", [[70000], [1, 8191, 8192, 8193, 1, 49157, 1, 1], [8192, 8192, 8192], [8191, 1, 8192, 1, 1, 8190, 3], [63, 1, 64, 65, 1023, 1, 1025, 30000, 2]])
+def test_fold_runs_across_wavefronts_and_tiles(ctx, runs):
+    """Runs of equal words that end exactly at, one before and one behind the 64-word rounds, the
+    1024-word stretches of a wavefront and the 8192-word tiles of the fold kernels, runs that cover whole
+    tiles (tiles without a start), a single run (wordtable_find_frequencies, src/word-table.c:233-260)."""
+    rng = np.random.default_rng(len(runs))
+    keys = np.sort(rng.choice(1 << 40, size=len(runs), replace=False).astype(np.uint64))
+    words = np.repeat(keys, runs)
+    rng.shuffle(words)
+    lst = ctx.words_to_list(words, 20)
+    got = lst.download()
+    assert got["key"].tolist() == keys.tolist()
+    assert got["count"].tolist() == runs
+
+
 def test_empty_input_gives_an_empty_list(ctx):
     lst = ctx.words_to_list(np.zeros(0, dtype=np.uint64), 16)
     assert lst.n_words == 0
