@@ -1058,7 +1058,34 @@ extern "C" int gt4hip_union_table (gt4hip_context *ctx, const gt4hip_list *const
   } stamp = { ctx, t_begin };
   memset (table, 0, sizeof *table);
   table->n_lists = n_lists;
-  /* all distinct keys ascending = N-way union with nothing filtered out (count >= 0) */
+  /* up to eight non-empty lists: two launches of the N-way tile kernel write keys and counts directly */
+  if (ctx->kway_enabled) {
+    const gt4hip_list *work[8];
+    uint32_t cols[8], k = 0;
+    bool fits = true;
+    for (uint32_t j = 0; j < n_lists && fits; j++) {
+      if (!lists[j]) return GT4HIP_EINVAL;
+      if (!lists[j]->n_words) continue;
+      if (k == 8 || lists[j]->word_length != lists[0]->word_length) fits = false;
+      else {
+        work[k] = lists[j];
+        cols[k++] = j;
+      }
+    }
+    if (fits && k >= 2) {
+      HIPCHK (ctx, hipSetDevice (ctx->device));
+      int used = 0;
+      const int rc = gt4hip_nway_table (ctx, work, k, cols, table, &used);
+      if (rc) return rc;
+      if (used) {
+        ctx->kway_calls++;
+        return GT4HIP_OK;
+      }
+      memset (table, 0, sizeof *table);
+      table->n_lists = n_lists;
+    }
+  }
+  /* otherwise: all distinct keys ascending = N-way union with nothing filtered out (count >= 0), then a merge per column */
   gt4hip_multi_result u;
   memset (&u, 0, sizeof u);
   int rc = gt4hip_union_multi (ctx, lists, n_lists, 0, GT4HIP_RULE_MAX, 0, 0, &u);

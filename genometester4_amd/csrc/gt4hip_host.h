@@ -77,6 +77,7 @@ void gt4hip_io_destroy (gt4hip_context *ctx);
 int gt4hip_nway_union (gt4hip_context *ctx, const gt4hip_list *const lists[], uint32_t k, uint32_t rule, uint32_t cutoff, uint32_t ovr,
                        uint32_t filter, bool count_only, gt4hip_list *out, uint64_t *n_words, uint64_t *total_count, double *device_ms,
                        int *used);
+int gt4hip_nway_table (gt4hip_context *ctx, const gt4hip_list *const lists[], uint32_t k, const uint32_t cols[], gt4hip_count_table *table, int *used);
 int gt4hip_io_download (gt4hip_context *ctx, const void *dev, void *host, size_t bytes);
 
 #define HIPCHK(ctx, call)                                                                               \

@@ -66,7 +66,8 @@ constexpr int NWAY_PSTRIDE = 10;  /* u64 per tile boundary in the partition tabl
 constexpr int NWAY_LIMIT = GT4_NWAY_LIMIT;    /* keys per bucket the bucket walks handle */
 constexpr int NWAY_TRY0 = GT4_NWAY_TRY0;     /* ... that the interpolation's buckets may hold before the tile is bucketed by a pivot run instead */
 
-enum : int { NWAY_COUNT = 0, NWAY_UNION = 1, NWAY_DUPS = 2 };
+enum : int { NWAY_COUNT = 0, NWAY_UNION = 1, NWAY_DUPS = 2, NWAY_TABLE = 3 };
+__host__ __device__ constexpr bool nway_staged (int mode) { return mode == NWAY_UNION || mode == NWAY_DUPS; } /* kept records leave through the staging area */
 
 struct NwayParams {
   const u32 *list[NWAY_MAX];
@@ -81,6 +82,16 @@ struct NwayParams {
   u32 dynamic;         /* tiles by ticket (ctl->ticket) instead of round-robin */
   u32 force_fallback;  /* tests: 1 every tile takes the search path, 2 every tile is bucketed by its pivot run */
   u32 scan_group;      /* the scanner workgroup as summers + chainer (launches with very many rows) */
+  /* NWAY_COUNT with tile_totals: every tile's number of distinct keys -> tile_totals[tile].
+   * NWAY_TABLE (the count table of glistquery's multi-list dump, src/set-operations.c:131-183): row r of the
+   * table is the r-th distinct key; tile_base[tile] = rows before the tile (from a counting launch over the
+   * same partition); list i's count of the key goes to table_counts[r * table_cols + table_col[i]]. */
+  u32 *tile_totals;
+  const u64 *tile_base;
+  u64 *table_keys;
+  u32 *table_counts;
+  u32 table_cols;
+  u32 table_col[NWAY_MAX];
 };
 
 /* ------------------------------------------------------------------ K5 / K6: samples and tile boundaries */
@@ -230,6 +241,34 @@ __global__ void k_nway_check (const u64 *__restrict__ part, u32 num_tiles, u32 c
   if (slots * WAVE > cap || !mono) atomicOr (flag, 1u);
 }
 
+/* rows before every tile = exclusive prefix of the tiles' distinct keys (one workgroup walks the array) */
+__global__ __launch_bounds__ (1024) void k_nway_tile_bases (const u32 *__restrict__ totals, u64 tiles, u64 *__restrict__ bases)
+{
+  __shared__ u64 wsum[16];
+  __shared__ u64 carry_s;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads ();
+  for (u64 b0 = 0; b0 < tiles; b0 += 1024) {
+    const u64 i = b0 + threadIdx.x;
+    const u64 v = i < tiles ? totals[i] : 0;
+    const u64 incl = wave_inclusive_scan (v, lane);
+    if (lane == 63) wsum[wid] = incl;
+    __syncthreads ();
+    u64 before = 0, all = 0;
+    for (int w = 0; w < 16; w++) {
+      const u64 x = wsum[w];
+      before += w < wid ? x : 0;
+      all += x;
+    }
+    const u64 c = carry_s;
+    if (i < tiles) bases[i] = c + before + incl - v;
+    __syncthreads ();
+    if (threadIdx.x == 0) carry_s = c + all;
+    __syncthreads ();
+  }
+}
+
 /* ------------------------------------------------------------------ K7: the tile kernel */
 
 #ifndef GT4_NWAY_SVPRIO
@@ -283,12 +322,13 @@ struct NwayShared {
   alignas (16) u64 g[GSZ];                 /* keys grouped by bucket; all-ones wherever no key is */
   alignas (16) u32 cnt[NB / 2 + 4];        /* 16-bit bucket counters, then bucket starts, in pairs (+ the total) */
   alignas (16) u32 live[(CAPS + 3) / 4];   /* one byte per position: a key was stored there */
-  alignas (16) u32 stage[MODE == NWAY_COUNT ? 4 : 3 * CAP + 4]; /* the kept records, packed, written out during the NEXT tile */
+  alignas (16) u32 stage[nway_staged (MODE) ? 3 * CAP + 4 : 4]; /* the kept records, packed, written out during the NEXT tile */
   u32 wtot[NW], wmax[NW], wkept[NW];
   /* the tiles of this iteration, the next one (being fetched) and the one after (being described),
    * three deep: one 64-record wave slot per wave-instruction */
   u64 slot_addr[3][NCH];
   u32 slot_cnt[3][NCH];
+  u32 slot_run[3][NCH];                    /* (NWAY_TABLE) the list a slot's records come from */
   u32 tab_pbase[3][NWAY_MAX];              /* first position of each run */
   u32 tab_len[3][NWAY_MAX];
   /* tile number (0xffffffff: none), records, wave slots, shift | direct << 8, multiplier, smallest
@@ -414,6 +454,7 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
     u64 v = 0;
     if (tile < ntl && lane < 2 * NWAY_PSTRIDE)
       v = __hip_atomic_load (&part[(u64) tile * NWAY_PSTRIDE + (u64) lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (MODE == NWAY_TABLE && tile < ntl && lane == 2 * NWAY_PSTRIDE) v = p.tile_base[tile];
     return v;
   };
   /* the slot table of `tile` (partition entries in `row`, one per lane) into table tb: branch-free
@@ -449,12 +490,14 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
     if (lane < NCH) {
       sh.slot_cnt[tb][lane] = in ? (len_r - first < (u32) WAVE ? len_r - first : (u32) WAVE) : 0u;
       sh.slot_addr[tb][lane] = lb_r + 12ull * (s_r + first);
+      if (MODE == NWAY_TABLE) sh.slot_run[tb][lane] = run;
     }
     u64 base = 0;
     if (MODE == NWAY_DUPS) {
 #pragma unroll
       for (int q = 0; q < NWAY_MAX; q++) base += (u32) q < p.k ? readlane_u64 (row, q) : 0ull;
     }
+    if (MODE == NWAY_TABLE) base = readlane_u64 (row, 2 * NWAY_PSTRIDE);
     const u32 lo_lo = (u32) __builtin_amdgcn_readlane ((int) rlo, NWAY_MAX), lo_hi = (u32) __builtin_amdgcn_readlane ((int) rhi, NWAY_MAX);
     const u32 bk_lo = (u32) __builtin_amdgcn_readlane ((int) rlo, NWAY_MAX + 1), bk_hi = (u32) __builtin_amdgcn_readlane ((int) rhi, NWAY_MAX + 1);
     u32 h = tile;
@@ -849,6 +892,7 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
         if (!(ba[k] >> 31)) continue;
         u32 q = nway_skew (pos[k]);
         if (MODE == NWAY_DUPS) q = nway_skew (pos[k] + atomicAdd (&sh.s.scnt[q], 1u)); /* equal sample keys: one position each */
+        else if (MODE == NWAY_TABLE) { /* (counts go to the table, below) */ }
         else if (p.rule == 1u) atomicAdd (&sh.s.scnt[q], cnt[k]);
         else if (p.rule == 4u) atomicMax (&sh.s.scnt[q], cnt[k]);
         sh.s.skey[q] = key[k];
@@ -860,7 +904,7 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
      * ahead from the entries asked for one iteration ago, the ticket drawn then, new requests -- and
      * the previous tile leaves its staging area as soon as the chain has its offset: only this
      * wavefront ever waits for the chain, and not before everybody else stands at B6 */
-    bool wo_done = !(MODE != NWAY_COUNT && pend);
+    bool wo_done = !(nway_staged (MODE) && pend);
     auto write_out = [&] (u64 excl_bytes) {
       const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc ((void *) (reinterpret_cast<char *> (out) + excl_bytes), 0, (int) (12 * pend_tot), 0x00020000);
       const u32 chunks = (3 * pend_tot + 3) >> 2;
@@ -926,10 +970,10 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
         const bool on = lds_load<unsigned char> (lds_offset (&sh.live[0]) + q) != 0;
         okey[i] = lds_load<u64> (lds_offset (&sh.s.skey[0]) + 8u * q);
         u32 f = lds_load<u32> (lds_offset (&sh.s.scnt[0]) + 4u * q);
-        if (MODE == NWAY_DUPS) f = 0;
+        if (MODE == NWAY_DUPS || MODE == NWAY_TABLE) f = 0;
         else if (p.rule == 7u) f = p.count_override;
         ocnt[i] = f;
-        const bool keep = on & (MODE == NWAY_DUPS || p.filter == FILTER_RAW || f >= p.cutoff);
+        const bool keep = on & (MODE == NWAY_DUPS || MODE == NWAY_TABLE || p.filter == FILTER_RAW || f >= p.cutoff);
         keep_bits |= keep ? 1u << i : 0u;
         acc_sum += keep ? f : 0u;
         kpre[i] = wave_kept;
@@ -950,7 +994,8 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
       if (MODE == NWAY_UNION && service) {
         if (lane == 0) publish_u32 (&agg[cur], AGG_READY | tile_total);
       }
-      if (MODE != NWAY_COUNT && wave_kept) {
+      if (MODE == NWAY_COUNT && tid == 0 && p.tile_totals) p.tile_totals[cur] = tile_total;
+      if (nway_staged (MODE) && wave_kept) {
 #pragma unroll
         for (int i = 0; i < RPT; i++) {
           const bool keep = (keep_bits >> i) & 1u;
@@ -963,8 +1008,35 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
           }
         }
       }
+      if (MODE == NWAY_TABLE) {
+        /* the key column, and every position's row (over the ordered tile's counts, which this mode
+         * does not fold) for the records to find */
+        if (wave_kept) {
+#pragma unroll
+          for (int i = 0; i < RPT; i++) {
+            const bool keep = (keep_bits >> i) & 1u;
+            const u64 m = __builtin_amdgcn_ballot_w64 (keep);
+            const u32 slot = wbase + kpre[i] + __builtin_amdgcn_mbcnt_hi ((u32) (m >> 32), __builtin_amdgcn_mbcnt_lo ((u32) m, 0u));
+            if (keep) {
+              p.table_keys[out_base + slot] = okey[i];
+              sh.s.scnt[nway_skew ((u32) (wid * RPT + i) * WAVE + (u32) lane)] = slot;
+            }
+          }
+        }
+        __syncthreads ();
+        if (has_rec) {
+#pragma unroll
+          for (int k = 0; k < RPT; k++) {
+            if (!(ba[k] >> 31)) continue;
+            const u32 col = p.table_col[uniform32 (sh.slot_run[tb][wid * RPT + k])];
+            const u64 row = out_base + sh.s.scnt[nway_skew (pos[k])];
+            p.table_counts[row * p.table_cols + col] = cnt[k];
+          }
+        }
+        __syncthreads (); /* (the rows lie where the next tile's counts are zeroed) */
+      }
     }
-    pend = MODE != NWAY_COUNT;
+    pend = nway_staged (MODE);
     pend_tot = tile_total;
     pend_tile = cur;
     pend_base = out_base;
@@ -982,7 +1054,7 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
     for (int i = 0; i < 24; i++) atomicAdd (&ctl->phase_cycles[i], ph[i]);
 #endif
   /* drain: the last tile is still staged */
-  if (MODE != NWAY_COUNT && pend) {
+  if (nway_staged (MODE) && pend) {
     __syncthreads ();
     if (MODE == NWAY_UNION && wid == 0) {
       const u64 x = resolve_offset (agg, carry, pend_tile, lane, 0, 0, ctl, spin_limit);
@@ -991,7 +1063,7 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
     __syncthreads ();
     write_out_tile<NT> (out, MODE == NWAY_UNION ? uniform64 (sh.excl) : pend_base, pend_tot, sh.stage, tid);
   }
-  if (MODE != NWAY_DUPS) {
+  if (MODE != NWAY_DUPS && MODE != NWAY_TABLE) {
     const u64 v = wave_sum (acc_sum);
     if (lane == 0 && v) atomicAdd (&ctl->total_count[0], v);
     if (tid == 0 && blk_cnt) atomicAdd (&ctl->n_words[0], blk_cnt);
@@ -1014,17 +1086,19 @@ hipError_t launch_nway_mode (hipStream_t s, int mode, int grid, const NwayParams
 {
   if (mode == NWAY_DUPS) return launch_nway<NWAY_DUPS> (s, grid, p, part, out, desc, ctl);
   if (mode == NWAY_COUNT) return launch_nway<NWAY_COUNT> (s, grid, p, part, out, desc, ctl);
+  if (mode == NWAY_TABLE) return launch_nway<NWAY_TABLE> (s, grid, p, part, out, desc, ctl);
   return launch_nway<NWAY_UNION> (s, grid, p, part, out, desc, ctl);
 }
 
 int nway_blocks_per_cu (int mode)
 {
-  static int cache[3] = { 0, 0, 0 };
+  static int cache[4] = { 0, 0, 0, 0 };
   if (!cache[mode]) {
     int n = 0;
     hipError_t e;
     if (mode == NWAY_DUPS) e = hipOccupancyMaxActiveBlocksPerMultiprocessor (&n, k_nway_merge<NWAY_NT, NWAY_RPT, NWAY_NBF, NWAY_DUPS>, NWAY_NT, 0);
     else if (mode == NWAY_COUNT) e = hipOccupancyMaxActiveBlocksPerMultiprocessor (&n, k_nway_merge<NWAY_NT, NWAY_RPT, NWAY_NBF, NWAY_COUNT>, NWAY_NT, 0);
+    else if (mode == NWAY_TABLE) e = hipOccupancyMaxActiveBlocksPerMultiprocessor (&n, k_nway_merge<NWAY_NT, NWAY_RPT, NWAY_NBF, NWAY_TABLE>, NWAY_NT, 0);
     else e = hipOccupancyMaxActiveBlocksPerMultiprocessor (&n, k_nway_merge<NWAY_NT, NWAY_RPT, NWAY_NBF, NWAY_UNION>, NWAY_NT, 0);
     if (e != hipSuccess || n < 1) n = 1;
     const int by_regs = nway_waves_per_simd (NWAY_NT) * 4 / (NWAY_NT / 64);
@@ -1089,12 +1163,9 @@ void nway_samples_per_tile (u32 k, u32 *first_try, u32 *sure)
 
 }  // namespace
 
-/* N-way union of 3..8 non-empty lists in one pass.  *used = 0 when the call must take the pairwise
- * tree instead (the single-pass chain gave up on a shared device).  `out`: capacity >= sum of the
- * lists (unless count_only). */
-int gt4hip_nway_union (gt4hip_context *ctx, const gt4hip_list *const lists[], uint32_t k, uint32_t rule, uint32_t cutoff, uint32_t ovr,
-                       uint32_t filter, bool count_only, gt4hip_list *out, uint64_t *n_words, uint64_t *total_count, double *device_ms,
-                       int *used)
+static int nway_run (gt4hip_context *ctx, const gt4hip_list *const lists[], uint32_t k, uint32_t rule, uint32_t cutoff, uint32_t ovr,
+                     uint32_t filter, bool count_only, gt4hip_list *out, uint64_t *n_words, uint64_t *total_count, double *device_ms,
+                     int *used, gt4hip_count_table *table, const uint32_t *cols)
 {
   *used = 0;
   if (k < 2 || k > NWAY_MAX) return GT4HIP_OK;
@@ -1194,7 +1265,7 @@ int gt4hip_nway_union (gt4hip_context *ctx, const gt4hip_list *const lists[], ui
     lv.p.filter = filter;
     lv.p.spin_limit = ctx->spin_limit;
     lv.p.force_fallback = ctx->kway_vt == 99 ? 1u : (ctx->kway_vt == 98 ? 2u : 0u); /* option "kway_vt" = 99 / 98: every tile takes the search path / the pivot-run buckets (tests) */
-    const int mode = l > 0 ? NWAY_DUPS : (count_only ? NWAY_COUNT : NWAY_UNION);
+    const int mode = l > 0 ? NWAY_DUPS : (count_only || table ? NWAY_COUNT : NWAY_UNION);
     lv.p.scan_group = ctx->scan_group > 0 ? 1u : (ctx->scan_group < 0 ? 0u : (tiles > (48000ull << 6) ? 1u : 0u));
     lv.p.dynamic = ctx->dynamic > 0 ? 1u : (ctx->dynamic < 0 ? 0u : (mode == NWAY_UNION ? 1u : 0u));
     u32 *dst = NULL;
@@ -1213,6 +1284,10 @@ int gt4hip_nway_union (gt4hip_context *ctx, const gt4hip_list *const lists[], ui
       if ((u64) grid > tiles + 1) grid = (int) tiles + 1;
     } else if ((u64) grid > tiles) {
       grid = (int) tiles;
+    }
+    if (l == 0 && table) { /* the tiles' distinct keys, then the rows before every tile, behind each other in the descriptor area */
+      if ((rc = nway_grow (ctx, (void **) &ctx->desc, &ctx->desc_bytes, (size_t) tiles * 4 + 16 + (size_t) tiles * 8))) break;
+      lv.p.tile_totals = (u32 *) ctx->desc;
     }
     hipMemsetAsync (ctx->ctl, 0, sizeof (PairControl), st);
     if (l == 0) hipEventRecord (ctx->ev[1], st);
@@ -1252,6 +1327,38 @@ int gt4hip_nway_union (gt4hip_context *ctx, const gt4hip_list *const lists[], ui
 #endif
       *n_words = ctx->ctl_host->n_words[0];
       *total_count = ctx->ctl_host->total_count[0];
+      if (table) {
+        /* second launch over the same partition: key column and counts, every tile at its rows */
+        const u64 rows = *n_words;
+        u64 *bases = (u64 *) ((char *) ctx->desc + (((size_t) tiles * 4 + 15) & ~(size_t) 15));
+        table->n_keys = rows;
+        if (rows) {
+          if (gt4hip_dev_alloc (ctx, &table->device_keys, (size_t) rows * 8) != hipSuccess ||
+              gt4hip_dev_alloc (ctx, &table->device_counts, (size_t) rows * table->n_lists * 4) != hipSuccess) {
+            rc = gt4hip_fail (ctx, GT4HIP_ENOMEM, "count table allocation failed (%llu keys x %u lists)", (unsigned long long) rows, table->n_lists);
+            break;
+          }
+          hipMemsetAsync (table->device_counts, 0, (size_t) rows * table->n_lists * 4, st);
+          hipLaunchKernelGGL (k_nway_tile_bases, dim3 (1), dim3 (1024), 0, st, (const u32 *) ctx->desc, tiles, bases);
+          lv.p.tile_totals = NULL;
+          lv.p.tile_base = bases;
+          lv.p.table_keys = (u64 *) table->device_keys;
+          lv.p.table_counts = (u32 *) table->device_counts;
+          lv.p.table_cols = table->n_lists;
+          for (uint32_t i = 0; i < k; i++) lv.p.table_col[i] = cols[i];
+          lv.p.dynamic = 0;
+          int g2 = ctx->n_cus * nway_blocks_per_cu (NWAY_TABLE);
+          if ((u64) g2 > tiles) g2 = (int) tiles;
+          hipMemsetAsync (ctx->ctl, 0, sizeof (PairControl), st);
+          e = launch_nway_mode (st, NWAY_TABLE, g2, lv.p, (const u64 *) ctx->kway_part, NULL, (u64 *) ctx->desc, ctx->ctl);
+          if (e == hipSuccess) e = hipMemcpyAsync (ctx->ctl_host, ctx->ctl, sizeof (PairControl), hipMemcpyDeviceToHost, st);
+          if (e == hipSuccess) e = hipStreamSynchronize (st);
+          if (e != hipSuccess || ctx->ctl_host->error) {
+            rc = gt4hip_fail (ctx, e != hipSuccess ? GT4HIP_EHIP : GT4HIP_EINTERNAL, "count table kernel failed: %s (flags 0x%x)", hipGetErrorString (e), ctx->ctl_host->error);
+            break;
+          }
+        }
+      }
       float ms = 0;
       if (hipEventElapsedTime (&ms, ctx->ev[0], ctx->ev[3]) == hipSuccess) *device_ms = ms;
       if (hipEventElapsedTime (&ms, ctx->ev[1], ctx->ev[2]) == hipSuccess) ctx->nway_kernel_ms = ms;
@@ -1261,5 +1368,33 @@ int gt4hip_nway_union (gt4hip_context *ctx, const gt4hip_list *const lists[], ui
   }
   if (merged) gt4hip_list_free (merged);
   cleanup ();
+  return rc;
+}
+
+/* N-way union of 2..8 non-empty lists in one pass.  *used = 0 when the call must take the pairwise
+ * tree instead (the single-pass chain gave up on a shared device).  `out`: capacity >= sum of the
+ * lists (unless count_only). */
+int gt4hip_nway_union (gt4hip_context *ctx, const gt4hip_list *const lists[], uint32_t k, uint32_t rule, uint32_t cutoff, uint32_t ovr,
+                       uint32_t filter, bool count_only, gt4hip_list *out, uint64_t *n_words, uint64_t *total_count, double *device_ms,
+                       int *used)
+{
+  return nway_run (ctx, lists, k, rule, cutoff, ovr, filter, count_only, out, n_words, total_count, device_ms, used, NULL, NULL);
+}
+
+/* The count table of 2..8 non-empty lists (all their distinct keys ascending; column cols[i] = list i's
+ * count of the key, 0 where it has none) by two launches of the tile kernel over one partition: distinct
+ * keys per tile, then keys and counts written at every tile's rows.  table->n_lists columns (those no list
+ * is given for stay 0).  *used = 0: nothing was done, the caller builds the table by merges. */
+int gt4hip_nway_table (gt4hip_context *ctx, const gt4hip_list *const lists[], uint32_t k, const uint32_t cols[], gt4hip_count_table *table, int *used)
+{
+  uint64_t n = 0, t = 0;
+  double ms = 0;
+  const int rc = nway_run (ctx, lists, k, 1, 0, 0, FILTER_RAW, true, NULL, &n, &t, &ms, used, table, cols);
+  if (rc || !*used) {
+    if (table->device_keys) hipFree (table->device_keys);
+    if (table->device_counts) hipFree (table->device_counts);
+    table->device_keys = table->device_counts = NULL;
+    table->n_keys = 0;
+  }
   return rc;
 }

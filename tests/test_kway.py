@@ -259,3 +259,64 @@ def test_device_shards_world_of_one_with_rccl_gather(ctx):
         assert (n, total) == (n_o, t_o) and res.download().tobytes() == r_o.tobytes()
     finally:
         sh.close()
+
+
+def _check_table(ctx, lists, k=20, expect_kway=True):
+    """gt4hip_union_table (glistquery's multi-list dump, reference src/set-operations.c:131-183) by the
+    tile kernel (two launches: distinct keys per tile, then keys and counts at every tile's rows) against
+    numpy -- keys = sorted union of all lists, column j = list j's count of the key, 0 where absent -- and
+    against the table built by merges (option kway = 0)."""
+    dev = [ctx.upload(x, k) for x in lists]
+    before = ctx.get_counter("kway_calls")
+    tk, tc = ctx.union_table(dev)
+    if expect_kway and 2 <= sum(len(x) > 0 for x in lists) <= 8:
+        assert ctx.get_counter("kway_calls") == before + 1
+    uni = np.unique(np.concatenate([x["key"] for x in lists])) if lists else np.zeros(0, dtype=np.uint64)
+    assert tk.tobytes() == uni.tobytes()
+    for j, x in enumerate(lists):
+        col = np.zeros(len(uni), dtype=np.uint32)
+        col[np.searchsorted(uni, x["key"])] = x["count"]
+        assert tc[:, j].tobytes() == col.tobytes(), "column %d" % j
+    ctx.set_option("kway", 0)
+    try:
+        mk, mc = ctx.union_table(dev)
+    finally:
+        ctx.set_option("kway", 1)
+    assert mk.tobytes() == tk.tobytes() and mc.tobytes() == tc.tobytes()
+    for d in dev:
+        d.free()
+
+
+@pytest.mark.parametrize("n_lists", [2, 3, 6, 8])
+@pytest.mark.parametrize("universe", [1, 700, 6145, 200001, 3_000_000])
+def test_count_table_by_the_tile_kernel(ctx, n_lists, universe):
+    rng = np.random.default_rng(31 * n_lists + universe)
+    _check_table(ctx, _random_lists(rng, n_lists, universe))
+
+
+def test_count_table_with_empty_members_identical_lists_and_more_than_eight(ctx):
+    rng = np.random.default_rng(77)
+    lists = _random_lists(rng, 5, 50000)
+    empty = U.make_records(np.zeros(0, dtype=np.uint64), np.zeros(0, dtype=np.uint32))
+    _check_table(ctx, [lists[0], empty, lists[1], lists[2], empty, lists[3]])          # columns of empty lists stay 0
+    _check_table(ctx, [lists[0], lists[0].copy(), lists[0].copy(), lists[1]])          # equal keys in several lists
+    _check_table(ctx, [lists[0], empty], expect_kway=False)                            # one non-empty list: by merges
+    _check_table(ctx, _random_lists(rng, 11, 30000), expect_kway=False)                # more than eight: by merges
+
+
+def test_count_table_of_clustered_keys(ctx):
+    """tiles that are bucketed by their pivot run or take the search path (see test_clustered_keys)"""
+    rng = np.random.default_rng(5)
+    base = np.sort(rng.choice(1 << 20, size=3000, replace=False).astype(np.uint64)) << np.uint64(40)
+    keys = np.unique((base[:, None] + np.arange(40, dtype=np.uint64)[None, :]).ravel())
+    lists = []
+    for j in range(6):
+        m = rng.random(len(keys)) < 0.5
+        lists.append(U.make_records(keys[m], rng.integers(1, 9, size=int(m.sum()), dtype=np.uint32)))
+    _check_table(ctx, lists, k=32)
+    for vt in (98, 99):
+        ctx.set_option("kway_vt", vt)
+        try:
+            _check_table(ctx, lists[:4], k=32)
+        finally:
+            ctx.set_option("kway_vt", 0)
