@@ -121,6 +121,7 @@ extern "C" void gt4hip_destroy (gt4hip_context *ctx)
   }
   if (ctx->part) hipFree (ctx->part);
   if (ctx->kway_part) hipFree (ctx->kway_part);
+  if (ctx->kway_cnt) hipFree (ctx->kway_cnt);
   if (ctx->desc) hipFree (ctx->desc);
   if (ctx->block_sums) hipFree (ctx->block_sums);
   if (ctx->ctl) hipFree (ctx->ctl);

@@ -44,6 +44,8 @@ struct gt4hip_context {
   /* N-way tile kernel (gt4hip_nway.hip) */
   uint64_t *kway_part;       /* tile boundaries, [tiles + 1][8] */
   size_t kway_part_bytes;
+  void *kway_cnt;            /* samples of every list per bracket of 64 tiles */
+  size_t kway_cnt_bytes;
   int kway_enabled;          /* option "kway": 0 = always the pairwise tree */
   int64_t kway_g;            /* option "kway_g": samples per tile (0 = automatic) */
   int64_t kway_vt;           /* option "kway_vt": positions per thread in a merge pass, at least (0 = default) */

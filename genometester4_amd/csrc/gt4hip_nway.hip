@@ -226,6 +226,205 @@ __global__ void k_nway_partition (NwayParams p, const u32 *__restrict__ merged, 
   part[t * NWAY_PSTRIDE + i] = v;
 }
 
+/* ---- The same table from SAMPLE COUNTS (every level but the topmost).  The merged samples carry the
+ * list they came from (NWAY_DUPS stores it in the count word), so the number c of list i's samples in
+ * front of a boundary is a prefix count -- and the boundary's cut in list i lies in the S records
+ * behind sample c (or, when a sample EQUAL to the boundary key was merged behind it, in the next S):
+ * seven probes inside one 1.5 KB stretch instead of a binary search over the whole bracket.
+ *   k_nway_sample_counts   per bracket of 64 tiles: samples of every list
+ *   k_nway_bracket_bases   exclusive prefix over the brackets (one wavefront per list)
+ *   k_nway_partition_rows  one wavefront per bracket, one lane per tile: counts of the tile's own samples
+ *                          (and whether they are clustered: see k_nway_partition), prefix over the lanes,
+ *                          eight short searches, the tile's key range and bucket constants */
+constexpr u32 NWAY_BRACKET = 64;
+
+__global__ __launch_bounds__ (256) void k_nway_sample_counts (const u32 *__restrict__ merged, u64 m_total, u32 G, u64 n_brackets, u32 *__restrict__ cnt)
+{
+  const int lane = threadIdx.x & 63;
+  const u64 br = (u64) blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (br >= n_brackets) return;
+  const u64 first = br * NWAY_BRACKET * G, end = first + (u64) NWAY_BRACKET * G < m_total ? first + (u64) NWAY_BRACKET * G : m_total;
+  u64 c0 = 0, c1 = 0; /* 16-bit fields: lists 0..3, 4..7 (a bracket has at most 64 * 32 samples) */
+  for (u64 j = first + lane; j < end; j += WAVE) {
+    const u32 id = merged[3 * j + 2];
+    const u64 one = 1ull << (16 * (id & 3u));
+    c0 += id < 4u ? one : 0ull;
+    c1 += id < 4u ? 0ull : one;
+  }
+  c0 = wave_sum (c0);
+  c1 = wave_sum (c1);
+  if (lane < NWAY_MAX) cnt[br * NWAY_MAX + lane] = (u32) (((lane < 4 ? c0 : c1) >> (16 * (lane & 3))) & 0xffffu);
+}
+
+__global__ __launch_bounds__ (64 * NWAY_MAX) void k_nway_bracket_bases (u32 *__restrict__ cnt, u64 n_brackets)
+{
+  const int lane = threadIdx.x & 63, list = threadIdx.x >> 6;
+  u64 carry = 0;
+  for (u64 b0 = 0; b0 < n_brackets; b0 += WAVE) {
+    const u64 b = b0 + lane;
+    const u64 v = b < n_brackets ? cnt[b * NWAY_MAX + list] : 0u;
+    const u64 incl = wave_inclusive_scan (v, lane);
+    if (b < n_brackets) cnt[b * NWAY_MAX + list] = (u32) (carry + incl - v);
+    carry += (u64) (u32) __builtin_amdgcn_readlane ((int) (u32) incl, WAVE - 1) | ((u64) (u32) __builtin_amdgcn_readlane ((int) (u32) (incl >> 32), WAVE - 1) << 32);
+  }
+}
+
+constexpr u32 NWAY_G_MAX = 32; /* samples per tile the bracket's LDS copy has room for */
+
+__global__ __launch_bounds__ (64) void k_nway_partition_rows (NwayParams p, const u32 *__restrict__ merged, u64 m_total, u32 G, u32 n_buckets, const u32 *__restrict__ bases,
+                                                           u64 *__restrict__ part)
+{
+  __shared__ u32x4 smp4[NWAY_BRACKET * NWAY_G_MAX * 3 / 4]; /* the bracket's samples: read once, 16 bytes per lane and instruction */
+  const u32 *const smp = reinterpret_cast<const u32 *> (smp4);
+  const int lane = threadIdx.x;
+  const u64 br = blockIdx.x;
+  const u64 t = br * NWAY_BRACKET + lane;
+  {
+    const u64 f = br * NWAY_BRACKET * G;
+    const u64 cnt = f >= m_total ? 0 : (m_total - f < (u64) NWAY_BRACKET * G ? m_total - f : (u64) NWAY_BRACKET * G);
+    const u32 quads = (u32) ((3 * cnt + 3) / 4); /* (the list's allocation is a multiple of 16 bytes and f * 12 is one too) */
+    const u32x4 *src = reinterpret_cast<const u32x4 *> (merged + 3 * f);
+    for (u32 i = lane; i < quads; i += WAVE) smp4[i] = src[i];
+    __syncthreads ();
+  }
+  const u64 nt = p.num_tiles;
+  const bool row = t <= nt;
+  /* boundary keys in front of this tile and behind it */
+  const bool has_x = row && t > 0 && t < nt, has_y = row && t + 1 < nt;
+  const u64 x = has_x ? nway_boundary_key (merged, m_total, G, p.num_tiles, t) : 0ull;
+  const u64 y = has_y ? nway_boundary_key (merged, m_total, G, p.num_tiles, t + 1) : 0ull;
+  /* the tile's key range and bucket function (as k_nway_partition) */
+  u64 lo_key = 0, bk = 0;
+  u32 sh = 0, mul = 0;
+  bool direct = false;
+  const bool tile = row && t < nt;
+  u64 c0 = 0, c1 = 0; /* the tile's own samples per list: 16-bit fields, lists 0..3 and 4..7 */
+  if (tile) {
+    u64 lo, hi;
+    if (t == 0) {
+      lo = ~0ull;
+      for (u32 j = 0; j < p.k; j++)
+        if (p.n[j]) {
+          const u64 f = load_key (p.list[j], 0);
+          lo = f < lo ? f : lo;
+        }
+    } else {
+      lo = x + 1ull;
+    }
+    if (t + 1 == nt) {
+      hi = 0;
+      for (u32 j = 0; j < p.k; j++)
+        if (p.n[j]) {
+          const u64 l = load_key (p.list[j], p.n[j] - 1);
+          hi = l > hi ? l : hi;
+        }
+    } else {
+      hi = y;
+    }
+    const u64 D = hi >= lo ? hi - lo : 0ull;
+    const u32 bl = D ? 64u - (u32) __builtin_clzll (D) : 0u;
+    sh = bl > 32u ? bl - 32u : 0u;
+    const u32 vmax = (u32) (D >> sh);
+    direct = vmax < n_buckets;
+    mul = direct ? 0u : (u32) (((u64) n_buckets << 32) / ((u64) vmax + 1ull));
+    lo_key = lo;
+    bk = (u64) sh | (direct ? 1ull << 8 : (u64) mul << 32);
+    /* the tile's own samples: counts per list, and whether the interpolation will work on them */
+    const u64 first = t * (u64) G, end = first >= m_total ? first : (first + G < m_total ? first + G : m_total);
+    u32 prev = 0xffffffffu, same = 0, cnt = 0;
+    u64 prev_key = 0;
+    bool have_prev = false;
+    for (u64 j0 = first; j0 < end; j0 += 8) { /* (eight samples asked for at once) */
+      u64 sk[8];
+      u32 sid[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const u32 j = (u32) ((j0 + u < end ? j0 + u : end - 1) - br * NWAY_BRACKET * G);
+        sk[u] = (u64) smp[3 * j] | ((u64) smp[3 * j + 1] << 32);
+        sid[u] = smp[3 * j + 2];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        if (j0 + u >= end) continue;
+        const u64 s = sk[u];
+        const u64 one = 1ull << (16 * (sid[u] & 3u));
+        c0 += sid[u] < 4u ? one : 0ull;
+        c1 += sid[u] < 4u ? 0ull : one;
+        if (s < lo || s > hi || (have_prev && s == prev_key)) continue; /* (equal keys of different lists share a bucket by right) */
+        prev_key = s;
+        have_prev = true;
+        const u32 vv = (u32) ((s - lo) >> sh);
+        const u32 b = direct ? vv : __umulhi (vv, mul);
+        same += b == prev ? 1u : 0u;
+        prev = b;
+        cnt++;
+      }
+    }
+    if (t + 1 < nt && cnt >= 8 && 2 * same > cnt) bk |= 1ull << 9;
+  }
+  /* samples in front of the tile = the bracket's base + the earlier lanes' (every lane takes part) */
+  c0 = wave_inclusive_scan (c0, lane) - c0;
+  c1 = wave_inclusive_scan (c1, lane) - c1;
+  if (tile) {
+    /* the eight searches in step: every round asks for one key of every list */
+    u64 a[NWAY_MAX], h[NWAY_MAX];
+    bool need[NWAY_MAX]; /* the stretch that holds the cut is not found yet */
+#pragma unroll
+    for (int i = 0; i < NWAY_MAX; i++) {
+      const u64 c = (u32) i < p.k && t > 0 ? (u64) bases[br * NWAY_MAX + i] + (((i < 4 ? c0 : c1) >> (16 * (i & 3))) & 0xffffu) : 0ull;
+      a[i] = h[i] = c * NWAY_SAMPLE;
+      need[i] = (u32) i < p.k && t > 0;
+    }
+    for (int round = 0; round < 3; round++) { /* (a sample equal to the boundary key merged behind it: one stretch further; the list's tail: one more) */
+      u64 e[NWAY_MAX], kk[NWAY_MAX];
+#pragma unroll
+      for (int i = 0; i < NWAY_MAX; i++) {
+        e[i] = a[i] + NWAY_SAMPLE < p.n[i] ? a[i] + NWAY_SAMPLE : p.n[i];
+        kk[i] = need[i] && e[i] > a[i] ? load_key (p.list[i], e[i] - 1) : 0ull;
+      }
+#pragma unroll
+      for (int i = 0; i < NWAY_MAX; i++) {
+        if (!need[i]) continue;
+        if (e[i] == a[i]) { /* the list ends here */
+          h[i] = a[i];
+          need[i] = false;
+        } else if (kk[i] <= x) { /* the whole stretch belongs to earlier tiles */
+          a[i] = h[i] = e[i];
+        } else {
+          h[i] = e[i] - 1;
+          need[i] = false;
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NWAY_MAX; i++)
+      if (need[i]) h[i] = p.n[i]; /* (cannot happen: keys are unique inside a list; searched in full all the same) */
+    for (;;) {
+      bool any = false;
+      u64 km[NWAY_MAX];
+#pragma unroll
+      for (int i = 0; i < NWAY_MAX; i++) km[i] = a[i] < h[i] ? load_key (p.list[i], (a[i] + h[i]) >> 1) : 0ull;
+#pragma unroll
+      for (int i = 0; i < NWAY_MAX; i++) {
+        if (a[i] >= h[i]) continue;
+        const u64 mid = (a[i] + h[i]) >> 1;
+        if (km[i] <= x) a[i] = mid + 1;
+        else h[i] = mid;
+        any |= a[i] < h[i];
+      }
+      if (!any) break;
+    }
+#pragma unroll
+    for (int i = 0; i < NWAY_MAX; i++) part[t * NWAY_PSTRIDE + i] = (u32) i < p.k && t > 0 ? a[i] : 0ull;
+    part[t * NWAY_PSTRIDE + NWAY_MAX] = lo_key;
+    part[t * NWAY_PSTRIDE + NWAY_MAX + 1] = bk;
+  } else if (row) { /* t == num_tiles: the lists' ends */
+    for (u32 i = 0; i < NWAY_MAX; i++) part[t * NWAY_PSTRIDE + i] = i < p.k ? p.n[i] : 0ull;
+    part[t * NWAY_PSTRIDE + NWAY_MAX] = 0;
+    part[t * NWAY_PSTRIDE + NWAY_MAX + 1] = 0;
+  }
+}
+
 /* a tile fits when its records fit the position space with every run rounded up to whole wavefronts */
 __global__ void k_nway_check (const u64 *__restrict__ part, u32 num_tiles, u32 cap, u32 *flag)
 {
@@ -328,7 +527,7 @@ struct NwayShared {
    * three deep: one 64-record wave slot per wave-instruction */
   u64 slot_addr[3][NCH];
   u32 slot_cnt[3][NCH];
-  u32 slot_run[3][NCH];                    /* (NWAY_TABLE) the list a slot's records come from */
+  u32 slot_run[3][NCH];                    /* (NWAY_TABLE, NWAY_DUPS) the list a slot's records come from */
   u32 tab_pbase[3][NWAY_MAX];              /* first position of each run */
   u32 tab_len[3][NWAY_MAX];
   /* tile number (0xffffffff: none), records, wave slots, shift | direct << 8, multiplier, smallest
@@ -490,7 +689,7 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
     if (lane < NCH) {
       sh.slot_cnt[tb][lane] = in ? (len_r - first < (u32) WAVE ? len_r - first : (u32) WAVE) : 0u;
       sh.slot_addr[tb][lane] = lb_r + 12ull * (s_r + first);
-      if (MODE == NWAY_TABLE) sh.slot_run[tb][lane] = run;
+      if (MODE == NWAY_TABLE || MODE == NWAY_DUPS) sh.slot_run[tb][lane] = run;
     }
     u64 base = 0;
     if (MODE == NWAY_DUPS) {
@@ -896,7 +1095,7 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
         else if (p.rule == 1u) atomicAdd (&sh.s.scnt[q], cnt[k]);
         else if (p.rule == 4u) atomicMax (&sh.s.scnt[q], cnt[k]);
         sh.s.skey[q] = key[k];
-        reinterpret_cast<unsigned char *> (sh.live)[q] = 1;
+        reinterpret_cast<unsigned char *> (sh.live)[q] = MODE == NWAY_DUPS ? (unsigned char) (1u + uniform32 (sh.slot_run[tb][wid * RPT + k])) : (unsigned char) 1;
       }
     }
     PHASE_STAMP (9);
@@ -967,10 +1166,12 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
 #pragma unroll
       for (int i = 0; i < RPT; i++) {
         const u32 q = nway_skew ((u32) (wid * RPT + i) * WAVE + (u32) lane);
-        const bool on = lds_load<unsigned char> (lds_offset (&sh.live[0]) + q) != 0;
+        const u32 lv = lds_load<unsigned char> (lds_offset (&sh.live[0]) + q);
+        const bool on = lv != 0;
         okey[i] = lds_load<u64> (lds_offset (&sh.s.skey[0]) + 8u * q);
         u32 f = lds_load<u32> (lds_offset (&sh.s.scnt[0]) + 4u * q);
-        if (MODE == NWAY_DUPS || MODE == NWAY_TABLE) f = 0;
+        if (MODE == NWAY_DUPS) f = lv - 1u; /* a merged sample keeps the list it came from: the partition counts them */
+        else if (MODE == NWAY_TABLE) f = 0;
         else if (p.rule == 7u) f = p.count_override;
         ocnt[i] = f;
         const bool keep = on & (MODE == NWAY_DUPS || MODE == NWAY_TABLE || p.filter == FILTER_RAW || f >= p.cutoff);
@@ -1232,9 +1433,19 @@ static int nway_run (gt4hip_context *ctx, const gt4hip_list *const lists[], uint
       lv.p.num_tiles = (u32) tiles;
       if ((rc = nway_grow (ctx, (void **) &ctx->kway_part, &ctx->kway_part_bytes, (size_t) (tiles + 1) * NWAY_PSTRIDE * 8))) break;
       const u64 threads = (tiles + 1) * NWAY_PSTRIDE;
-      for (int pass = 0; pass < 2; pass++)
-        hipLaunchKernelGGL (k_nway_partition, dim3 ((unsigned) ((threads + 255) / 256)), dim3 (256), 0, st, lv.p, merged ? (const u32 *) merged->dev : NULL,
-                            m_total, G, (u32) (NWAY_NBF * NWAY_CAP), (u64 *) ctx->kway_part, pass);
+      if (merged && ctx->kway_vt != 97 && G <= NWAY_G_MAX) {
+        /* from the merged samples' list numbers (option "kway_vt" = 97 keeps the searches over whole brackets: tests) */
+        const u64 n_br = (tiles + 1 + NWAY_BRACKET - 1) / NWAY_BRACKET;
+        if ((rc = nway_grow (ctx, (void **) &ctx->kway_cnt, &ctx->kway_cnt_bytes, (size_t) n_br * NWAY_MAX * 4))) break;
+        hipLaunchKernelGGL (k_nway_sample_counts, dim3 ((unsigned) ((n_br + 3) / 4)), dim3 (256), 0, st, (const u32 *) merged->dev, m_total, G, n_br, (u32 *) ctx->kway_cnt);
+        hipLaunchKernelGGL (k_nway_bracket_bases, dim3 (1), dim3 (64 * NWAY_MAX), 0, st, (u32 *) ctx->kway_cnt, n_br);
+        hipLaunchKernelGGL (k_nway_partition_rows, dim3 ((unsigned) n_br), dim3 (64), 0, st, lv.p, (const u32 *) merged->dev, m_total, G, (u32) (NWAY_NBF * NWAY_CAP),
+                            (const u32 *) ctx->kway_cnt, (u64 *) ctx->kway_part);
+      } else {
+        for (int pass = 0; pass < 2; pass++)
+          hipLaunchKernelGGL (k_nway_partition, dim3 ((unsigned) ((threads + 255) / 256)), dim3 (256), 0, st, lv.p, merged ? (const u32 *) merged->dev : NULL,
+                              m_total, G, (u32) (NWAY_NBF * NWAY_CAP), (u64 *) ctx->kway_part, pass);
+      }
       hipMemsetAsync (ctx->scratch, 0, 64, st);
       hipLaunchKernelGGL (k_nway_check, dim3 ((unsigned) ((tiles + 255) / 256)), dim3 (256), 0, st, (const u64 *) ctx->kway_part, (u32) tiles, (u32) NWAY_CAP,
                           (u32 *) ctx->scratch);

@@ -320,3 +320,19 @@ def test_count_table_of_clustered_keys(ctx):
             _check_table(ctx, lists[:4], k=32)
         finally:
             ctx.set_option("kway_vt", 0)
+
+
+@pytest.mark.parametrize("n_lists", [3, 8])
+def test_partition_by_bracket_searches_gives_the_same_tiles_result(ctx, n_lists):
+    """The tile boundaries come from the merged samples' list numbers (prefix counts + a search inside
+    one sample stretch); option kway_vt = 97 keeps the older partition (binary searches over brackets of
+    64 tiles).  Both against the oracle, on lists with many equal keys (ties at the boundaries: a sample
+    equal to the boundary key merged behind it)."""
+    rng = np.random.default_rng(97 + n_lists)
+    lists = _random_lists(rng, n_lists, 400000, k_bits=19)  # dense: most keys are in several lists
+    _check(ctx, lists, rule=1, cutoff=2)
+    ctx.set_option("kway_vt", 97)
+    try:
+        _check(ctx, lists, rule=1, cutoff=2)
+    finally:
+        ctx.set_option("kway_vt", 0)
