@@ -65,7 +65,9 @@ fetch, fpath = pmc("fetch", "FETCH_SIZE")
 write, wpath = pmc("write", "WRITE_SIZE")
 if fetch and write:
     # dominant kernel = the merge kernel instantiation with the most fetched bytes in total
-    cand = [k for k in fetch if k.startswith("k_pair_merge") or k.startswith("k_nway")]
+    cand = [k for k in fetch if k.startswith("k_pair_merge") or k.startswith("k_nway") or k.startswith("k_radix")]
+    if workload == "sort":
+        cand = [k for k in cand if k.startswith("k_radix")]
     dom = max(cand, key=lambda k: sum(fetch[k].values()))
     fv = list(fetch[dom].values())
     wv = list(write.get(dom, {}).values())
