@@ -327,7 +327,8 @@ def bench_sort(args, ctx, capi):
            "ms_per_step": statistics.mean(wall) * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "u64 words", "data": "synthetic",
            "config": {"workload": "sort + fold of %d random k=%d words (a quarter drawn from a pool of %d) -> %d-record list" % (n, k, max(1, n // 64), n_out),
-                      "words": n, "word_length": k, "radix_passes": passes, "output_records": n_out, "device": ctx.device_info()},
+                      "words": n, "word_length": k, "radix_passes": passes, "output_records": n_out, "device": ctx.device_info(),
+                      "wall_ms_per_step": [round(w * 1e3, 2) for w in wall]},
            "roofline": {"bound": "hbm", "kernel": "k_radix_hist + k_radix_scatter x %d passes" % passes, "achieved": alg / (s_ms * 1e-3) / 1e9,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                         "algorithmic_bytes_per_launch": alg, "kernel_ms_avg": s_ms, "fold_ms_avg": statistics.mean(fold_ms),
@@ -375,7 +376,8 @@ def bench_table(args, ctx, capi):
            "ms_per_step": statistics.mean(wall) * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "u64 keys + u32 counts", "data": "synthetic",
            "config": {"workload": "count table of %d lists x %d k=%d entries -> %d keys x %d counts" % (nl, n, k, n_keys, nl),
-                      "lists": nl, "entries_per_list": n, "keys": n_keys, "device": ctx.device_info()},
+                      "lists": nl, "entries_per_list": n, "keys": n_keys, "device": ctx.device_info(),
+                      "wall_ms_per_step": [round(w * 1e3, 2) for w in wall]},
            "roofline": {"bound": "hbm", "kernel": "k_nway_merge<count> + k_nway_merge<table>" if nl <= 8 else "k_nway_merge (the keys) + %d x (k_pair_merge union + k_extract_column)" % nl,
                         "achieved": alg / (t_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         "traffic": None, "algorithmic_bytes_per_launch": alg, "kernel_ms_avg": t_ms,

@@ -38,7 +38,7 @@ class MultiResult(C.Structure):
 
 class CountTable(C.Structure):
     _fields_ = [("n_keys", C.c_uint64), ("n_lists", C.c_uint32), ("device_keys", C.c_void_p),
-                ("device_counts", C.c_void_p)]
+                ("device_counts", C.c_void_p), ("owner", C.c_void_p * 2)]
 
 
 # every symbol include/gt4hip.h declares (checked by tests/test_capi_symbols.py)

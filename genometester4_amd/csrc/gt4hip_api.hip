@@ -1037,16 +1037,35 @@ static int table_column_by_union (gt4hip_context *ctx, const gt4hip_list *keys, 
   return GT4HIP_OK;
 }
 
-static int table_alloc (gt4hip_context *ctx, gt4hip_count_table *table, uint64_t n, uint32_t n_lists)
+/* Device memory that comes from the context's block pool and goes back to it (big hipMalloc / hipFree
+ * pairs per call stall for a second every few calls on this driver): a list object owns the block. */
+int gt4hip_block_alloc (gt4hip_context *ctx, size_t bytes, void **dev, void **owner)
 {
-  hipError_t e = gt4hip_dev_alloc (ctx, &table->device_keys, (size_t) n * 8);
-  if (e == hipSuccess) e = gt4hip_dev_alloc (ctx, &table->device_counts, (size_t) n * n_lists * 4);
-  if (e != hipSuccess) {
+  gt4hip_list *l = NULL;
+  const int rc = gt4hip_list_new (ctx, bytes / GT4HIP_RECORD_BYTES + 1, 1, &l);
+  if (rc) return rc;
+  *dev = l->dev;
+  *owner = l;
+  return GT4HIP_OK;
+}
+
+void gt4hip_block_free (void *owner)
+{
+  if (owner) gt4hip_list_free ((gt4hip_list *) owner);
+}
+
+int gt4hip_table_alloc (gt4hip_context *ctx, gt4hip_count_table *table, uint64_t n, uint32_t n_lists)
+{
+  int rc = gt4hip_block_alloc (ctx, (size_t) n * 8, &table->device_keys, &table->owner[0]);
+  if (!rc) rc = gt4hip_block_alloc (ctx, (size_t) n * n_lists * 4, &table->device_counts, &table->owner[1]);
+  if (rc) {
     gt4hip_table_free (table);
-    return gt4hip_fail (ctx, GT4HIP_ENOMEM, "count table allocation failed: %s", hipGetErrorString (e));
+    return gt4hip_fail (ctx, GT4HIP_ENOMEM, "count table allocation failed (%llu keys x %u lists)", (unsigned long long) n, n_lists);
   }
   return GT4HIP_OK;
 }
+
+static int table_alloc (gt4hip_context *ctx, gt4hip_count_table *table, uint64_t n, uint32_t n_lists) { return gt4hip_table_alloc (ctx, table, n, n_lists); }
 
 extern "C" int gt4hip_union_table (gt4hip_context *ctx, const gt4hip_list *const lists[], uint32_t n_lists, gt4hip_count_table *table)
 {
@@ -1176,8 +1195,11 @@ extern "C" int gt4hip_table_download (gt4hip_context *ctx, const gt4hip_count_ta
 extern "C" void gt4hip_table_free (gt4hip_count_table *t)
 {
   if (!t) return;
-  if (t->device_keys) hipFree (t->device_keys);
-  if (t->device_counts) hipFree (t->device_counts);
+  if (t->owner[0]) gt4hip_block_free (t->owner[0]);
+  else if (t->device_keys) hipFree (t->device_keys);
+  if (t->owner[1]) gt4hip_block_free (t->owner[1]);
+  else if (t->device_counts) hipFree (t->device_counts);
   t->device_keys = t->device_counts = NULL;
+  t->owner[0] = t->owner[1] = NULL;
   t->n_keys = 0;
 }

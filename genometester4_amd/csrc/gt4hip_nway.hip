@@ -1544,11 +1544,8 @@ static int nway_run (gt4hip_context *ctx, const gt4hip_list *const lists[], uint
         u64 *bases = (u64 *) ((char *) ctx->desc + (((size_t) tiles * 4 + 15) & ~(size_t) 15));
         table->n_keys = rows;
         if (rows) {
-          if (gt4hip_dev_alloc (ctx, &table->device_keys, (size_t) rows * 8) != hipSuccess ||
-              gt4hip_dev_alloc (ctx, &table->device_counts, (size_t) rows * table->n_lists * 4) != hipSuccess) {
-            rc = gt4hip_fail (ctx, GT4HIP_ENOMEM, "count table allocation failed (%llu keys x %u lists)", (unsigned long long) rows, table->n_lists);
-            break;
-          }
+          if ((rc = gt4hip_table_alloc (ctx, table, rows, table->n_lists))) break;
+          table->n_keys = rows;
           hipMemsetAsync (table->device_counts, 0, (size_t) rows * table->n_lists * 4, st);
           hipLaunchKernelGGL (k_nway_tile_bases, dim3 (1), dim3 (1024), 0, st, (const u32 *) ctx->desc, tiles, bases);
           lv.p.tile_totals = NULL;
@@ -1601,11 +1598,6 @@ int gt4hip_nway_table (gt4hip_context *ctx, const gt4hip_list *const lists[], ui
   uint64_t n = 0, t = 0;
   double ms = 0;
   const int rc = nway_run (ctx, lists, k, 1, 0, 0, FILTER_RAW, true, NULL, &n, &t, &ms, used, table, cols);
-  if (rc || !*used) {
-    if (table->device_keys) hipFree (table->device_keys);
-    if (table->device_counts) hipFree (table->device_counts);
-    table->device_keys = table->device_counts = NULL;
-    table->n_keys = 0;
-  }
+  if (rc || !*used) gt4hip_table_free (table);
   return rc;
 }

@@ -418,7 +418,8 @@ static int radix_sort_device (gt4hip_context *ctx, u64 *words, u64 *tmp, uint64_
   /* workspace: digit bases of every pass, a ticket per pass, the tile states */
   const size_t head = (size_t) RADIX_MAX_PASSES * 256 * 8 + 64;
   char *ws = NULL;
-  if (gt4hip_dev_alloc (ctx, (void **) &ws, head + (size_t) tiles * 256 * 8) != hipSuccess)
+  void *ws_owner = NULL;
+  if (gt4hip_block_alloc (ctx, head + (size_t) tiles * 256 * 8, (void **) &ws, &ws_owner))
     return gt4hip_fail (ctx, GT4HIP_ENOMEM, "gt4hip_sort_words: workspace of %llu bytes", (unsigned long long) (head + tiles * 256 * 8));
   u64 *ghist = (u64 *) ws;
   u32 *tickets = (u32 *) (ws + (size_t) RADIX_MAX_PASSES * 256 * 8);
@@ -438,7 +439,7 @@ static int radix_sort_device (gt4hip_context *ctx, u64 *words, u64 *tmp, uint64_
   }
   if (e == hipSuccess) e = hipGetLastError ();
   if (e == hipSuccess) e = hipStreamSynchronize (st);
-  hipFree (ws);
+  gt4hip_block_free (ws_owner);
   if (e != hipSuccess) return gt4hip_fail (ctx, GT4HIP_EHIP, "gt4hip_sort_words: %s", hipGetErrorString (e));
   *result = src;
   return GT4HIP_OK;
@@ -450,7 +451,8 @@ extern "C" int gt4hip_sort_words (gt4hip_context *ctx, void *device_words, uint6
   HIPCHK (ctx, hipSetDevice (ctx->device));
   if (n_words < 2) return GT4HIP_OK;
   u64 *tmp = NULL;
-  if (gt4hip_dev_alloc (ctx, (void **) &tmp, (size_t) n_words * 8) != hipSuccess) return gt4hip_fail (ctx, GT4HIP_ENOMEM, "gt4hip_sort_words: %llu bytes of scratch", (unsigned long long) n_words * 8);
+  void *tmp_owner = NULL;
+  if (gt4hip_block_alloc (ctx, (size_t) n_words * 8, (void **) &tmp, &tmp_owner)) return gt4hip_fail (ctx, GT4HIP_ENOMEM, "gt4hip_sort_words: %llu bytes of scratch", (unsigned long long) n_words * 8);
   u64 *res = NULL;
   int rc = radix_sort_device (ctx, (u64 *) device_words, tmp, n_words, word_length, &res);
   if (!rc && res != (u64 *) device_words) {
@@ -458,7 +460,7 @@ extern "C" int gt4hip_sort_words (gt4hip_context *ctx, void *device_words, uint6
     if (e == hipSuccess) e = hipStreamSynchronize (ctx->stream);
     if (e != hipSuccess) rc = gt4hip_fail (ctx, GT4HIP_EHIP, "gt4hip_sort_words: %s", hipGetErrorString (e));
   }
-  hipFree (tmp);
+  gt4hip_block_free (tmp_owner);
   return rc;
 }
 
@@ -473,8 +475,9 @@ static int fold_sorted_words (gt4hip_context *ctx, const u64 *words, uint64_t n_
   if (tiles >= (1ull << 32)) return gt4hip_fail (ctx, GT4HIP_EINVAL, "gt4hip_words_to_list: %llu words", (unsigned long long) n_words);
   /* workspace: ticket, tile states, runs before every tile (+ the total) */
   char *ws = NULL;
+  void *ws_owner = NULL;
   const size_t bytes = 64 + (size_t) tiles * 8 + (size_t) (tiles + 1) * 8;
-  if (gt4hip_dev_alloc (ctx, (void **) &ws, bytes) != hipSuccess) return gt4hip_fail (ctx, GT4HIP_ENOMEM, "gt4hip_words_to_list: workspace");
+  if (gt4hip_block_alloc (ctx, bytes, (void **) &ws, &ws_owner)) return gt4hip_fail (ctx, GT4HIP_ENOMEM, "gt4hip_words_to_list: workspace");
   u64 *state = (u64 *) (ws + 64), *tile_excl = state + tiles;
   e = hipMemsetAsync (ws, 0, 64 + (size_t) tiles * 8, st);
   hipLaunchKernelGGL (k_fold_count, dim3 ((unsigned) tiles), dim3 (FOLD_NT), 0, st, words, n_words, state, tile_excl, tiles, (u32 *) ws, ctx->scratch);
@@ -490,7 +493,7 @@ static int fold_sorted_words (gt4hip_context *ctx, const u64 *words, uint64_t n_
       if (e != hipSuccess) rc = gt4hip_fail (ctx, GT4HIP_EHIP, "gt4hip_words_to_list: %s", hipGetErrorString (e));
     }
   }
-  hipFree (ws);
+  gt4hip_block_free (ws_owner);
   if (rc) {
     if (l) gt4hip_list_free (l);
     return rc;
@@ -508,7 +511,8 @@ extern "C" int gt4hip_device_words_to_list (gt4hip_context *ctx, void *device_wo
   *out = NULL;
   if (!n_words) return gt4hip_list_new (ctx, 0, word_length, out);
   u64 *tmp = NULL;
-  if (gt4hip_dev_alloc (ctx, (void **) &tmp, (size_t) n_words * 8) != hipSuccess)
+  void *tmp_owner = NULL;
+  if (gt4hip_block_alloc (ctx, (size_t) n_words * 8, (void **) &tmp, &tmp_owner))
     return gt4hip_fail (ctx, GT4HIP_ENOMEM, "gt4hip_device_words_to_list: %llu bytes of scratch", (unsigned long long) n_words * 8);
   hipEventRecord (ctx->ev[0], ctx->stream);
   u64 *res = NULL;
@@ -521,7 +525,7 @@ extern "C" int gt4hip_device_words_to_list (gt4hip_context *ctx, void *device_wo
   float ms = 0;
   if (hipEventElapsedTime (&ms, ctx->ev[0], ctx->ev[1]) == hipSuccess) ctx->sort_ms = ms;
   if (hipEventElapsedTime (&ms, ctx->ev[1], ctx->ev[2]) == hipSuccess) ctx->fold_ms = ms;
-  hipFree (tmp);
+  gt4hip_block_free (tmp_owner);
   return rc;
 }
 

@@ -212,6 +212,7 @@ typedef struct {
   uint32_t n_lists;
   void *device_keys;
   void *device_counts;
+  void *owner[2]; /* library-private: the pooled device blocks behind the two arrays */
 } gt4hip_count_table;
 int gt4hip_union_table (gt4hip_context *ctx, const gt4hip_list *const lists[], uint32_t n_lists,
                         gt4hip_count_table *table);
