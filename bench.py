@@ -261,6 +261,27 @@ def bench_union8(args, ctx, capi, rank, local_rank, world):
         box = [None] * world
         dist.all_gather_object(box, per_rank[0])
         per_rank = box
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # the oracle's union_multi (reference src/glistcompare.c:545-591, one thread) on a key window of all
+        # eight lists; the GPU's totals for the same window must agree
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as O
+        m = min(n8, args.cpu_sample // 32)
+        last_key, _ = full[0].get_word(m - 1)
+        cuts = [l.lower_bound(last_key + 1) for l in full]
+        host = [l.download_range(0, c) for l, c in zip(full, cuts)]
+        t0c = time.perf_counter()
+        rc_o, n_o, t_o, _ = O.union_multi(host, 1, 0, 1)
+        dtc = time.perf_counter() - t0c
+        dev = [ctx.upload(h, args.k) for h in host]
+        rc_g, n_g, t_g, o_g = ctx.union_multi(dev)
+        cpu = ({"value": sum(len(h) for h in host) / dtc, "unit": "k-mers/s", "cores": 1, "host_nproc": os.cpu_count(), "kind": "port",
+                "sample": "oracle/gt4_oracle.c union_multi over the first %d records of list 0 and the same key range of the other seven (%d records), one thread" % (m, sum(len(h) for h in host))},
+               bool(rc_o == 0 and rc_g == 0 and (n_g, t_g) == (n_o, t_o)))
+        o_g.free()
+        for d in dev:
+            d.free()
     if rank == 0:
         n_in = 8 * n8
         print(json.dumps({
@@ -275,6 +296,7 @@ def bench_union8(args, ctx, capi, rank, local_rank, world):
                        "merge_only_ms_per_step": merge_only / args.steps * 1e3,
                        "gathered_bytes_per_step": 12 * (n_out - totals[0][0]) if world > 1 else 0},
             "roofline": union8_roofline(ctx, n_local_in // 8, totals[0][0], statistics.mean(dev_ms), statistics.mean(ker_ms), n8),
+            **({"cpu_baseline": cpu[0], "verified": cpu[1]} if cpu else {}),
         }), flush=True)
     sh.close()
     if world > 1:
