@@ -300,8 +300,12 @@ int gt4hip_synchronize (gt4hip_context *ctx);
  *   "pool_cap_mb" = n  most the pool may hold (default: half of the device memory); every device
  *                      allocation that fails gives the pooled blocks back and retries
  *   "grid" = n         workgroups of the merge kernel (0: one per resident slot)
- *   "kway" = 1         N-way unions by the one-pass tile kernel (gt4hip_kway.hip) instead of the
- *                      pairwise tree; "kway_g" / "kway_vt": its samples per tile / positions per thread
+ *   "kway" = 0 / 1 / 2 N-way unions of three and more lists by the pairwise tree of the pair kernel / by
+ *                      the one-pass tile kernel (gt4hip_nway.hip; the default) / two-list unions of the
+ *                      N-way entry points by the tile kernel too; count tables follow the same switch.
+ *                      "kway_g": samples per tile of its first partition attempt; "kway_vt" (tests):
+ *                      97 tile boundaries by searches over whole brackets, 98 every tile bucketed by
+ *                      its pivot run, 99 every tile on the search path
  *   "spin_limit" = n   bound of the single-pass kernel's inter-workgroup waits (0: default, ~seconds)
  *   "dynamic" = 1 / -1 tiles of the single-pass kernel always / never dealt by a ticket counter
  *                      (0: automatic -- the record-writing kernels except a complement alone)
@@ -310,8 +314,10 @@ int gt4hip_synchronize (gt4hip_context *ctx);
 int gt4hip_set_option (gt4hip_context *ctx, const char *name, int64_t value);
 /* Diagnostic counters of a context.  "single_pass_fallbacks": calls whose single-pass merge gave up a
  * bounded wait (a worker not resident: shared device) and were rerun on the two-pass path;
- * "kway_calls" / "kway_overflows": N-way unions done by the one-pass kernel / sent back to the tree
- * because a tile would not fit LDS. */
+ * "kway_calls" / "kway_overflows": N-way unions (and count tables) done by the one-pass tile kernel /
+ * partitions repeated with fewer samples per tile because a tile would not have fit LDS;
+ * "nway_kernel_us", "nway_tiles": the last N-way call's tile kernel; "sort_us", "fold_us", "table_us":
+ * the last gt4hip_device_words_to_list / gt4hip_union_table call. */
 int gt4hip_get_counter (gt4hip_context *ctx, const char *name, uint64_t *value);
 
 #ifdef __cplusplus
