@@ -343,6 +343,7 @@ def bench_sort(args, ctx, capi):
             assert lst.is_sorted()
         lst.free()
     s_ms = statistics.mean(sort_ms)
+    sort_traffic, sort_traffic_source = load_traffic("sort", n)
     alg = 16 * passes * n  # SURVEY / VERDICT: 16 bytes moved per word and pass (read + write)
     res = {"metric": "k-mer words sorted and folded/sec (glistmaker table step), k=%d, words resident in HBM" % k,
            "value": n / statistics.mean(wall), "unit": "words/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -352,7 +353,8 @@ def bench_sort(args, ctx, capi):
                       "words": n, "word_length": k, "radix_passes": passes, "output_records": n_out, "device": ctx.device_info(),
                       "wall_ms_per_step": [round(w * 1e3, 2) for w in wall]},
            "roofline": {"bound": "hbm", "kernel": "k_radix_hist + k_radix_scatter x %d passes" % passes, "achieved": alg / (s_ms * 1e-3) / 1e9,
-                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "traffic": sort_traffic, "traffic_source": sort_traffic_source, "traffic_note": "per launch of k_radix_scatter = one pass (16 B x words algorithmic)",
                         "algorithmic_bytes_per_launch": alg, "kernel_ms_avg": s_ms, "fold_ms_avg": statistics.mean(fold_ms),
                         "note": "achieved = 16 B x passes x words / time of the sort (HIP events: histogram kernel + passes); the histogram kernel reads the words once more (8 B per word, once)"}}
     if not args.no_cpu_baseline:
@@ -392,6 +394,7 @@ def bench_table(args, ctx, capi):
             wall.append(time.perf_counter() - t0)
             tab.append(ctx.get_counter("table_us") / 1000.0)
     t_ms = statistics.mean(tab)
+    table_traffic, table_traffic_source = load_traffic("table", n)
     alg = 12 * nl * n + (8 + 4 * nl) * n_keys
     res = {"metric": "k-mers tabulated/sec (glistquery multi-list dump: per-key counts of %d lists), lists resident in HBM" % nl,
            "value": nl * n / statistics.mean(wall), "unit": "k-mers/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -402,7 +405,8 @@ def bench_table(args, ctx, capi):
                       "wall_ms_per_step": [round(w * 1e3, 2) for w in wall]},
            "roofline": {"bound": "hbm", "kernel": "k_nway_merge<count> + k_nway_merge<table>" if nl <= 8 else "k_nway_merge (the keys) + %d x (k_pair_merge union + k_extract_column)" % nl,
                         "achieved": alg / (t_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                        "traffic": None, "algorithmic_bytes_per_launch": alg, "kernel_ms_avg": t_ms,
+                        "traffic": table_traffic, "traffic_source": table_traffic_source, "traffic_note": "the table launch of the tile kernel alone (the counting launch reads the records once more)",
+                        "algorithmic_bytes_per_launch": alg, "kernel_ms_avg": t_ms,
                         "note": "algorithmic = every input record read once + the table written once; achieved is over the whole call (sampling, partition, both launches of the tile kernel: the records are read twice)"}}
     if not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
