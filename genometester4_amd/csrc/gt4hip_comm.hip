@@ -37,7 +37,7 @@ struct Rccl {
 };
 
 Rccl g_rccl;
-char g_comm_err[256] = "";
+thread_local char g_comm_err[256] = "";
 
 const Rccl *rccl ()
 {
