@@ -308,13 +308,13 @@ def bench_union8(args, ctx, capi, rank, local_rank, world):
 def bench_sort(args, ctx, capi):
     """SURVEY 8f N2 (glistmaker's table step): --ns random k-mer words in HBM -> sorted (word, occurrences)
     list (wordtable_sort + wordtable_find_frequencies, reference src/word-table.c:217-260 on top of
-    src/utils.c:127-198), by gt4hip_device_words_to_list: LSD radix sort, 8-bit digits (one histogram kernel for all passes,
+    src/utils.c:127-198), by gt4hip_device_words_to_list: LSD radix sort, 8- and 9-bit digits (one histogram kernel for all passes,
     one chained-scan scatter kernel per pass), then the fold."""
     import numpy as np
     import torch
     n, k = args.ns, args.k
     bits = 64 if k >= 32 else 2 * k
-    passes = (bits + 7) // 8
+    passes = (bits + 8) // 9  # 8- and 9-bit digits: as gt4hip_sort.hip plans them (k = 25: 9 + 9 + 8 + 8 + 8 + 8)
     g = torch.Generator(device="cuda")
     g.manual_seed(1234)
     # repeats as a genome has them: a quarter of the words drawn from a small pool, the rest uniform

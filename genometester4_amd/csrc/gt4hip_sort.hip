@@ -7,10 +7,10 @@
  * on top of hybridInPlaceRadixSort256 (src/utils.c:127-198: in-place MSD radix sort, 8-bit digits,
  * insertion sort below 32 words; only the digits below 2 * wordlength bits are visited).
  *
- *   K8 k_radix_hist     ONE read of the words: how many carry each value of every pass's 8-bit digit
+ *   K8 k_radix_hist     ONE read of the words: how many carry each value of every pass's 8- or 9-bit digit
  *      k_radix_bases    exclusive prefix over the digits = where each digit's words start, per pass
  *   K9 k_radix_scatter  one launch per pass, one 8192-word tile per workgroup (by ticket): stable ranks inside
- *                       a wavefront by eight ballots (lanes with the same digit find each other) on top of
+ *                       a wavefront by one ballot per digit bit (lanes with the same digit find each other) on top of
  *                       per-wavefront digit counters in LDS; the tile sorted by digit in LDS; where it goes
  *                       behind the earlier tiles by a chained scan over per-(tile, digit) state words
  *                       (aggregate published early, look-back four tiles per round trip); the tile leaves
@@ -19,9 +19,10 @@
  *                       neighbour) -> runs before the tile, by a chained scan (one state word per tile)
  *       k_fold_records  record = (first word of the run, distance to the next run's start)
  *
- * LSD order (least significant digit first, every pass stable), ceil (2k / 8) passes, two buffers.
+ * LSD order (least significant digit first, every pass stable), ceil (2k / 9) passes of 8 or 9 bits,
+ * two buffers.
  * An HBM-bound streaming sort: 16 bytes moved per word and pass, 8 more once for the histograms.
- * Measured (1e9 random 50-bit words, MI355X): 36.3 ms; the first version of this file (a histogram
+ * Measured (1e9 random 50-bit words, MI355X): 31.9 ms in six passes (36.1 in seven of 8 bits); the first version of this file (a histogram
  * kernel per pass, words scattered 8 bytes at a time) took 100.6 ms, rocprim::radix_sort_keys 40.5 ms
  * (profiles/round3/r3_sort_experiments.log).
  */
@@ -58,6 +59,9 @@ constexpr int RADIX_MAX_PASSES = 8;
 #ifndef GT4_RADIX_WAVES
 #define GT4_RADIX_WAVES 4 /* wavefronts per SIMD the scatter kernel's registers must leave room for: two workgroups per CU */
 #endif
+#ifndef GT4_RADIX_NINE
+#define GT4_RADIX_NINE 1 /* 0: eight bits in every pass */
+#endif
 #ifndef GT4_RADIX_LOOK
 #define GT4_RADIX_LOOK 4
 #endif
@@ -72,11 +76,20 @@ constexpr u64 RADIX_AGG = 1ull << 62, RADIX_PREFIX = 2ull << 62;
 constexpr u64 RADIX_VALUE = (1ull << 56) - 1;
 __device__ __forceinline__ u64 radix_tag (u32 pass) { return (u64) (pass + 1) << 56; }
 
+constexpr int RADIX_MAX_DIGITS = 512; /* a pass takes 8 or 9 bits: ceil (bits / 9) passes, as many 9-bit ones as it takes */
+
+struct RadixPlan {
+  u32 passes;
+  u32 shift[RADIX_MAX_PASSES];
+  u32 bits[RADIX_MAX_PASSES];
+};
+
 /* all passes' digit counts in one read of the words: LDS counters per block, flushed by global atomics */
-__global__ __launch_bounds__ (HIST_NT) void k_radix_hist (const u64 *__restrict__ in, u64 n, u32 passes, u64 *__restrict__ ghist)
+__global__ __launch_bounds__ (HIST_NT) void k_radix_hist (const u64 *__restrict__ in, u64 n, RadixPlan plan, u64 *__restrict__ ghist)
 {
-  __shared__ u32 h[RADIX_MAX_PASSES][256];
-  for (u32 p = 0; p < passes; p++) h[p][threadIdx.x] = 0;
+  __shared__ u32 h[RADIX_MAX_PASSES][RADIX_MAX_DIGITS];
+  for (u32 p = 0; p < plan.passes; p++)
+    for (u32 d = threadIdx.x; d < (u32) RADIX_MAX_DIGITS; d += HIST_NT) h[p][d] = 0;
   __syncthreads ();
   const u64 chunk = (u64) HIST_NT * HIST_ITEMS;
   for (u64 base = (u64) blockIdx.x * chunk; base < n; base += (u64) gridDim.x * chunk) {
@@ -89,19 +102,20 @@ __global__ __launch_bounds__ (HIST_NT) void k_radix_hist (const u64 *__restrict_
 #pragma unroll
     for (int r = 0; r < HIST_ITEMS; r++) {
       if (base + (u64) r * HIST_NT + threadIdx.x < n)
-        for (u32 p = 0; p < passes; p++) atomicAdd (&h[p][(u32) (w[r] >> (8 * p)) & 255u], 1u);
+        for (u32 p = 0; p < plan.passes; p++) atomicAdd (&h[p][(u32) (w[r] >> plan.shift[p]) & ((1u << plan.bits[p]) - 1u)], 1u);
     }
   }
   __syncthreads ();
-  for (u32 p = 0; p < passes; p++)
-    if (h[p][threadIdx.x]) atomicAdd ((unsigned long long *) &ghist[p * 256 + threadIdx.x], (unsigned long long) h[p][threadIdx.x]);
+  for (u32 p = 0; p < plan.passes; p++)
+    for (u32 d = threadIdx.x; d < (1u << plan.bits[p]); d += HIST_NT)
+      if (h[p][d]) atomicAdd ((unsigned long long *) &ghist[p * RADIX_MAX_DIGITS + d], (unsigned long long) h[p][d]);
 }
 
 /* per pass: where the words of every digit start (exclusive prefix over the digits); block = pass */
-__global__ __launch_bounds__ (256) void k_radix_bases (u64 *__restrict__ ghist)
+__global__ __launch_bounds__ (RADIX_MAX_DIGITS) void k_radix_bases (u64 *__restrict__ ghist)
 {
-  __shared__ u64 ws[4];
-  u64 *row = ghist + (u64) blockIdx.x * 256;
+  __shared__ u64 ws[RADIX_MAX_DIGITS / WAVE];
+  u64 *row = ghist + (u64) blockIdx.x * RADIX_MAX_DIGITS;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const u64 v = row[threadIdx.x];
   const u64 incl = wave_inclusive_scan (v, lane);
@@ -112,31 +126,35 @@ __global__ __launch_bounds__ (256) void k_radix_bases (u64 *__restrict__ ghist)
   row[threadIdx.x] = before + incl - v;
 }
 
-/* One pass: tile t's words go behind everything the earlier tiles hold of the same digit, in the order
- * they came (stable).  Tiles are taken by ticket, so a tile's predecessors have all started.
- *   1. a wavefront owns RADIX_ITEMS * 64 consecutive words, read 64 at a time; the lanes holding the same
- *      digit find each other with eight ballots; the wavefront's private digit counters (LDS) give every
- *      word its rank among the wavefront's words of that digit;
- *   2. digit totals of the tile -> published (AGG); prefix over wavefronts and digits = every word's
- *      place in the tile sorted by digit; the words go there (LDS);
- *   3. 256 threads look back, one per digit, over the earlier tiles' states until they meet a PREFIX;
- *      the tile's own PREFIX is published;
- *   4. the tile leaves LDS in digit order: runs of one digit go to consecutive addresses. */
-__global__ __launch_bounds__ (RADIX_NT, GT4_RADIX_WAVES) void k_radix_scatter (const u64 *__restrict__ in, u64 *__restrict__ out, u64 n, u32 pass, const u64 *__restrict__ gbase,
+/* One pass over a digit of B = 8 or 9 bits: tile t's words go behind everything the earlier tiles hold of
+ * the same digit, in the order they came (stable).  Tiles are taken by ticket, so a tile's predecessors have
+ * all STARTED (a wait may only point at workgroups that run: the last workgroups of a launch are not
+ * dispatched while earlier ones occupy the CUs they are bound for).
+ *   1. a wavefront owns RADIX_ITEMS * 64 consecutive words, read 64 at a time; the tile's digit totals are
+ *      counted at once (LDS atomics) and published (AGG);
+ *   2. the lanes holding the same digit find each other with B ballots; the wavefront's private digit
+ *      counters (LDS, 16 bits) give every word its rank among the wavefront's words of that digit;
+ *   3. prefix over wavefronts and digits = every word's place in the tile sorted by digit; the words go
+ *      there (LDS);
+ *   4. one thread per digit looks back over the earlier tiles' states (RADIX_LOOK per round trip) until it
+ *      meets a PREFIX; the tile's own PREFIX is published;
+ *   5. the tile leaves LDS in digit order: runs of one digit go to consecutive addresses. */
+template <int B>
+__global__ __launch_bounds__ (RADIX_NT, GT4_RADIX_WAVES) void k_radix_scatter (const u64 *__restrict__ in, u64 *__restrict__ out, u64 n, u32 pass, u32 shift, const u64 *__restrict__ gbase,
                                                                               u64 *__restrict__ state, u32 *__restrict__ ticket)
 {
+  constexpr int ND = 1 << B, NDW = ND / WAVE; /* digits; wavefronts that own one digit per lane */
+  static_assert (ND <= RADIX_NT && ND <= RADIX_MAX_DIGITS && RADIX_TILE <= 65535, "a digit per thread; 16-bit places");
   __shared__ u64 keys[RADIX_TILE];
-  __shared__ u32 wcnt[RADIX_NW][256]; /* per wavefront: words of each digit so far; later: where the wavefront's words of the digit start in the sorted tile */
-  __shared__ u32 hcnt[256];          /* words of each digit in the tile */
-  __shared__ u64 gofs[256];          /* address of the tile's first word of each digit in `out`, minus its place in the sorted tile */
-  __shared__ u32 wtot[4];
+  __shared__ unsigned short wcnt[RADIX_NW][ND]; /* per wavefront: words of each digit so far; later: where the wavefront's words of the digit start in the sorted tile */
+  __shared__ u32 hcnt[ND];          /* words of each digit in the tile */
+  __shared__ u64 gofs[ND];          /* address of the tile's first word of each digit in `out`, minus its place in the sorted tile */
+  __shared__ u32 wtot[NDW];
   __shared__ u32 tile_s;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const u32 shift = 8 * pass;
   if (tid == 0) tile_s = atomicAdd (ticket, 1u);
-#pragma unroll
-  for (int i = tid; i < RADIX_NW * 256; i += RADIX_NT) (&wcnt[0][0])[i] = 0;
-  if (tid < 256) hcnt[tid] = 0;
+  for (int i = tid; i < RADIX_NW * ND / 2; i += RADIX_NT) reinterpret_cast<u32 *> (&wcnt[0][0])[i] = 0;
+  if (tid < ND) hcnt[tid] = 0;
   __syncthreads ();
   const u64 tile = tile_s;
   const u64 base = tile * RADIX_TILE;
@@ -151,28 +169,28 @@ __global__ __launch_bounds__ (RADIX_NT, GT4_RADIX_WAVES) void k_radix_scatter (c
       key[r] = (u64) v.x | ((u64) v.y << 32);
     }
   }
-  /* what the tile holds of every digit, as early as it can be known (LDS atomics; the stable ranks
-   * below take several times as long): the later tiles look back for it */
+  /* what the tile holds of every digit, as early as it can be known (the stable ranks below take several
+   * times as long): the later tiles look back for it */
 #pragma unroll
   for (int r = 0; r < RADIX_ITEMS; r++) {
     const u32 q = (u32) (wid * RADIX_ITEMS + r) * WAVE + (u32) lane;
-    if (q < nv) atomicAdd (&hcnt[(u32) (key[r] >> shift) & 255u], 1u);
+    if (q < nv) atomicAdd (&hcnt[(u32) (key[r] >> shift) & (u32) (ND - 1)], 1u);
   }
   __syncthreads ();
   u32 cnt_d = 0;
-  if (tid < 256) {
+  if (tid < ND) {
     cnt_d = hcnt[tid];
-    __hip_atomic_store (&state[tile * 256 + tid], (tile == 0 ? RADIX_PREFIX : RADIX_AGG) | radix_tag (pass) | (u64) cnt_d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store (&state[tile * ND + tid], (tile == 0 ? RADIX_PREFIX : RADIX_AGG) | radix_tag (pass) | (u64) cnt_d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   u32 rk[RADIX_ITEMS / 2]; /* 16 bits each */
 #pragma unroll
   for (int r = 0; r < RADIX_ITEMS; r++) {
     const u32 q = (u32) (wid * RADIX_ITEMS + r) * WAVE + (u32) lane;
     const bool valid = q < nv;
-    const u32 d = (u32) (key[r] >> shift) & 255u;
+    const u32 d = (u32) (key[r] >> shift) & (u32) (ND - 1);
     u64 m = __builtin_amdgcn_ballot_w64 (valid);
 #pragma unroll
-    for (int b = 0; b < 8; b++) {
+    for (int b = 0; b < B; b++) {
       const u64 bal = __builtin_amdgcn_ballot_w64 ((d >> b) & 1u);
       m &= ((d >> b) & 1u) ? bal : ~bal;
     }
@@ -180,24 +198,24 @@ __global__ __launch_bounds__ (RADIX_NT, GT4_RADIX_WAVES) void k_radix_scatter (c
     /* every lane of the group reads the counter, then its first lane adds the group (LDS executes a
      * wavefront's accesses in order) */
     const u32 old = valid ? wcnt[wid][d] : 0u;
-    if (valid && below == 0) wcnt[wid][d] = old + (u32) __popcll (m);
+    if (valid && below == 0) wcnt[wid][d] = (unsigned short) (old + (u32) __popcll (m));
     rk[r / 2] = (r & 1) ? rk[r / 2] | ((old + below) << 16) : old + below;
   }
   /* digit d = tid: its first place in the sorted tile */
   u32 ls = 0;
-  if (tid < 256) {
+  if (tid < ND) {
     const u32 incl = dpp_inclusive_scan_u32 (cnt_d);
     if (lane == 63) wtot[wid] = incl;
     ls = incl - cnt_d;
   }
   __syncthreads ();
-  if (tid < 256) {
+  if (tid < ND) {
     for (int w = 0; w < wid; w++) ls += wtot[w];
     u32 run = ls;
 #pragma unroll
     for (int w = 0; w < RADIX_NW; w++) { /* -> where wavefront w's words of the digit start */
       const u32 c = wcnt[w][tid];
-      wcnt[w][tid] = run;
+      wcnt[w][tid] = (unsigned short) run;
       run += c;
     }
   }
@@ -206,11 +224,11 @@ __global__ __launch_bounds__ (RADIX_NT, GT4_RADIX_WAVES) void k_radix_scatter (c
 #pragma unroll
   for (int r = 0; r < RADIX_ITEMS; r++) {
     const u32 q = (u32) (wid * RADIX_ITEMS + r) * WAVE + (u32) lane;
-    const u32 d = (u32) (key[r] >> shift) & 255u;
-    if (q < nv) keys[wcnt[wid][d] + ((rk[r / 2] >> (16 * (r & 1))) & 0xffffu)] = key[r];
+    const u32 d = (u32) (key[r] >> shift) & (u32) (ND - 1);
+    if (q < nv) keys[(u32) wcnt[wid][d] + ((rk[r / 2] >> (16 * (r & 1))) & 0xffffu)] = key[r];
   }
   /* look back: what the earlier tiles hold of digit tid */
-  if (tid < 256) {
+  if (tid < ND) {
     u64 excl = 0;
     if (tile > 0) {
       /* RADIX_LOOK earlier tiles per round trip: the states are asked for together and summed in order
@@ -222,18 +240,18 @@ __global__ __launch_bounds__ (RADIX_NT, GT4_RADIX_WAVES) void k_radix_scatter (c
         u64 v[RADIX_LOOK];
 #pragma unroll
         for (int i = 0; i < RADIX_LOOK; i++)
-          v[i] = j >= (u64) (1 + i) ? __hip_atomic_load (&state[(j - 1 - i) * 256 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (RADIX_PREFIX | radix_tag (pass));
+          v[i] = j >= (u64) (1 + i) ? __hip_atomic_load (&state[(j - 1 - i) * ND + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (RADIX_PREFIX | radix_tag (pass));
 #pragma unroll
         for (int i = 0; i < RADIX_LOOK; i++) {
           if (done) continue;
-          while (!ready (v[i])) v[i] = __hip_atomic_load (&state[(j - 1 - i) * 256 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          while (!ready (v[i])) v[i] = __hip_atomic_load (&state[(j - 1 - i) * ND + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           excl += v[i] & RADIX_VALUE;
           done = (v[i] & RADIX_PREFIX) != 0;
         }
       }
-      __hip_atomic_store (&state[tile * 256 + tid], RADIX_PREFIX | radix_tag (pass) | (excl + cnt_d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store (&state[tile * ND + tid], RADIX_PREFIX | radix_tag (pass) | (excl + cnt_d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    gofs[tid] = gbase[pass * 256 + tid] + excl - ls;
+    gofs[tid] = gbase[pass * RADIX_MAX_DIGITS + tid] + excl - ls;
   }
   __syncthreads ();
 #pragma unroll
@@ -241,7 +259,7 @@ __global__ __launch_bounds__ (RADIX_NT, GT4_RADIX_WAVES) void k_radix_scatter (c
     const u32 q = (u32) r * RADIX_NT + (u32) tid;
     if (q < nv) {
       const u64 k = keys[q];
-      out[gofs[(u32) (k >> shift) & 255u] + q] = k;
+      out[gofs[(u32) (k >> shift) & (u32) (ND - 1)] + q] = k;
     }
   }
 }
@@ -412,27 +430,43 @@ static int radix_sort_device (gt4hip_context *ctx, u64 *words, u64 *tmp, uint64_
   if (n < 2) return GT4HIP_OK;
   if (n >= RADIX_VALUE) return gt4hip_fail (ctx, GT4HIP_EINVAL, "gt4hip_sort_words: %llu words", (unsigned long long) n);
   const uint32_t bits = word_length >= 32 ? 64 : 2 * word_length;
-  const uint32_t passes = (bits + 7) / 8;
+  /* ceil (bits / 9) passes; as many of them take 9 bits as it takes to cover the word, the others 8
+   * (k = 25: 50 bits = 9 + 9 + 8 + 8 + 8 + 8, six passes instead of seven) */
+  RadixPlan plan;
+  memset (&plan, 0, sizeof plan);
+  plan.passes = GT4_RADIX_NINE ? (bits + 8) / 9 : (bits + 7) / 8;
+  {
+    const uint32_t nine = bits > 8 * plan.passes ? bits - 8 * plan.passes : 0;
+    uint32_t at = 0;
+    for (uint32_t p = 0; p < plan.passes; p++) {
+      plan.shift[p] = at;
+      plan.bits[p] = p < nine ? 9 : 8;
+      at += plan.bits[p];
+    }
+  }
+  const uint32_t passes = plan.passes;
   const uint64_t tiles = (n + RADIX_TILE - 1) / RADIX_TILE;
   if (tiles >= (1ull << 32)) return gt4hip_fail (ctx, GT4HIP_EINVAL, "gt4hip_sort_words: %llu words", (unsigned long long) n);
   /* workspace: digit bases of every pass, a ticket per pass, the tile states */
-  const size_t head = (size_t) RADIX_MAX_PASSES * 256 * 8 + 64;
+  const size_t head = (size_t) RADIX_MAX_PASSES * RADIX_MAX_DIGITS * 8 + 64;
+  const size_t state_bytes = (size_t) tiles * RADIX_MAX_DIGITS * 8;
   char *ws = NULL;
   void *ws_owner = NULL;
-  if (gt4hip_block_alloc (ctx, head + (size_t) tiles * 256 * 8, (void **) &ws, &ws_owner))
-    return gt4hip_fail (ctx, GT4HIP_ENOMEM, "gt4hip_sort_words: workspace of %llu bytes", (unsigned long long) (head + tiles * 256 * 8));
+  if (gt4hip_block_alloc (ctx, head + state_bytes, (void **) &ws, &ws_owner))
+    return gt4hip_fail (ctx, GT4HIP_ENOMEM, "gt4hip_sort_words: workspace of %llu bytes", (unsigned long long) (head + state_bytes));
   u64 *ghist = (u64 *) ws;
-  u32 *tickets = (u32 *) (ws + (size_t) RADIX_MAX_PASSES * 256 * 8);
+  u32 *tickets = (u32 *) (ws + (size_t) RADIX_MAX_PASSES * RADIX_MAX_DIGITS * 8);
   u64 *state = (u64 *) (ws + head);
   hipStream_t st = ctx->stream;
-  hipError_t e = hipMemsetAsync (ws, 0, head + (size_t) tiles * 256 * 8, st);
+  hipError_t e = hipMemsetAsync (ws, 0, head + state_bytes, st);
   u64 hb = (n + (u64) HIST_NT * HIST_ITEMS - 1) / ((u64) HIST_NT * HIST_ITEMS);
   if (hb > (u64) ctx->n_cus * 8) hb = (u64) ctx->n_cus * 8;
-  hipLaunchKernelGGL (k_radix_hist, dim3 ((unsigned) hb), dim3 (HIST_NT), 0, st, words, n, passes, ghist);
-  hipLaunchKernelGGL (k_radix_bases, dim3 (passes), dim3 (256), 0, st, ghist);
+  hipLaunchKernelGGL (k_radix_hist, dim3 ((unsigned) hb), dim3 (HIST_NT), 0, st, words, n, plan, ghist);
+  hipLaunchKernelGGL (k_radix_bases, dim3 (passes), dim3 (RADIX_MAX_DIGITS), 0, st, ghist);
   u64 *src = words, *dst = tmp;
   for (uint32_t p = 0; p < passes; p++) {
-    hipLaunchKernelGGL (k_radix_scatter, dim3 ((unsigned) tiles), dim3 (RADIX_NT), 0, st, src, dst, n, p, ghist, state, tickets + p);
+    if (plan.bits[p] == 9) hipLaunchKernelGGL (k_radix_scatter<9>, dim3 ((unsigned) tiles), dim3 (RADIX_NT), 0, st, src, dst, n, p, plan.shift[p], ghist, state, tickets + p);
+    else hipLaunchKernelGGL (k_radix_scatter<8>, dim3 ((unsigned) tiles), dim3 (RADIX_NT), 0, st, src, dst, n, p, plan.shift[p], ghist, state, tickets + p);
     u64 *const t = src;
     src = dst;
     dst = t;

@@ -263,7 +263,7 @@ int gt4hip_comm_gatherv (gt4hip_comm *comm, const gt4hip_list *local, const uint
 
 /* Sorts n_words packed 64-bit k-mer words (device memory) ascending, in place: the reference's
  * wordtable_sort (src/word-table.c:217-231; hybridInPlaceRadixSort256, src/utils.c:127-198) as an LSD
- * radix sort over the 2 * word_length significant bits (8-bit digits; one histogram kernel, then one
+ * radix sort over the 2 * word_length significant bits (8- and 9-bit digits; one histogram kernel, then one
  * chained-scan scatter kernel per digit).  Needs n_words * 8 bytes of scratch + 2 KB per 8192 words. */
 int gt4hip_sort_words (gt4hip_context *ctx, void *device_words, uint64_t n_words, uint32_t word_length);
 /* Sort + wordtable_find_frequencies (src/word-table.c:233-260): host words (any order, repeats

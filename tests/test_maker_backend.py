@@ -46,7 +46,8 @@ def test_words_to_list_reproduces_the_reference_glistmaker_list(ctx, k):
     assert out.download().tobytes() == ref[h["list_start"]:]
 
 
-@pytest.mark.parametrize("n,k", [(1, 16), (2, 16), (255, 3), (2048, 8), (2049, 20), (100003, 13), (3_000_000, 25), (1_500_000, 32)])
+@pytest.mark.parametrize("n,k", [(1, 16), (2, 16), (255, 3), (2048, 8), (2049, 20), (100003, 13), (3_000_000, 25), (1_500_000, 32),
+                                 (50_000, 26), (100_003, 27), (100_003, 29), (200_000, 31), (9000, 5)])  # 9-bit digits: some, all, all but one pass
 def test_sort_and_fold_against_numpy(ctx, n, k):
     rng = np.random.default_rng(n + k)
     space = (1 << 64) if k == 32 else (1 << (2 * k))
