@@ -293,6 +293,8 @@ __global__ __launch_bounds__ (64) void k_nway_partition_rows (NwayParams p, cons
   const bool has_x = row && t > 0 && t < nt, has_y = row && t + 1 < nt;
   const u64 x = has_x ? nway_boundary_key (merged, m_total, G, p.num_tiles, t) : 0ull;
   const u64 y = has_y ? nway_boundary_key (merged, m_total, G, p.num_tiles, t + 1) : 0ull;
+  /* the list the boundary sample came from: its cut is behind that very sample, no search */
+  const u32 x_list = has_x ? merged[3 * (t == nt - 1 ? m_total - 1 : t * (u64) G - 1) + 2] : 0xffffffffu;
   /* the tile's key range and bucket function (as k_nway_partition) */
   u64 lo_key = 0, bk = 0;
   u32 sh = 0, mul = 0;
@@ -373,7 +375,7 @@ __global__ __launch_bounds__ (64) void k_nway_partition_rows (NwayParams p, cons
     for (int i = 0; i < NWAY_MAX; i++) {
       const u64 c = (u32) i < p.k && t > 0 ? (u64) bases[br * NWAY_MAX + i] + (((i < 4 ? c0 : c1) >> (16 * (i & 3))) & 0xffffu) : 0ull;
       a[i] = h[i] = c * NWAY_SAMPLE;
-      need[i] = (u32) i < p.k && t > 0;
+      need[i] = (u32) i < p.k && t > 0 && (u32) i != x_list; /* (c counts the boundary sample itself: c * S is one behind it) */
     }
     for (int round = 0; round < 3; round++) { /* (a sample equal to the boundary key merged behind it: one stretch further; the list's tail: one more) */
       u64 e[NWAY_MAX], kk[NWAY_MAX];
