@@ -1095,7 +1095,7 @@ extern "C" int gt4hip_union_table (gt4hip_context *ctx, const gt4hip_list *const
     if (fits && k >= 2) {
       HIPCHK (ctx, hipSetDevice (ctx->device));
       int used = 0;
-      const int rc = gt4hip_nway_table (ctx, work, k, cols, table, &used);
+      const int rc = gt4hip_nway_table (ctx, work, k, cols, table, 0, 0, &used);
       if (rc) return rc;
       if (used) {
         ctx->kway_calls++;
@@ -1149,6 +1149,32 @@ extern "C" int gt4hip_probe_table_ex (gt4hip_context *ctx, const gt4hip_list *co
   table->n_keys = n;
   if (!n) return GT4HIP_OK;
   HIPCHK (ctx, hipSetDevice (ctx->device));
+  /* up to eight non-empty lists (the base first): one launch of the N-way tile kernel */
+  if (ctx->kway_enabled) {
+    const gt4hip_list *work[8];
+    uint32_t cols[8], k = 0;
+    bool fits = true;
+    for (uint32_t j = 0; j < n_lists && fits; j++) {
+      if (j && !lists[j]->n_words) continue;
+      if (k == 8 || lists[j]->word_length != base->word_length) fits = false;
+      else {
+        work[k] = lists[j];
+        cols[k++] = j;
+      }
+    }
+    if (fits && k >= 2) {
+      int used = 0;
+      const int rc = gt4hip_nway_table (ctx, work, k, cols, table, 1, presence, &used);
+      if (rc) return rc;
+      if (used) {
+        ctx->kway_calls++;
+        return GT4HIP_OK;
+      }
+      memset (table, 0, sizeof *table);
+      table->n_lists = n_lists;
+      table->n_keys = n;
+    }
+  }
   gt4hip_list *tmp = NULL, *inter = NULL;
   int rc = table_alloc (ctx, table, n, n_lists);
   if (!rc) rc = gt4hip_list_new (ctx, 2 * n, base->word_length, &tmp);

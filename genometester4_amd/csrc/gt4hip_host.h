@@ -82,7 +82,8 @@ int gt4hip_nway_union (gt4hip_context *ctx, const gt4hip_list *const lists[], ui
 int gt4hip_block_alloc (gt4hip_context *ctx, size_t bytes, void **dev, void **owner);
 void gt4hip_block_free (void *owner);
 int gt4hip_table_alloc (gt4hip_context *ctx, gt4hip_count_table *table, uint64_t n, uint32_t n_lists);
-int gt4hip_nway_table (gt4hip_context *ctx, const gt4hip_list *const lists[], uint32_t k, const uint32_t cols[], gt4hip_count_table *table, int *used);
+int gt4hip_nway_table (gt4hip_context *ctx, const gt4hip_list *const lists[], uint32_t k, const uint32_t cols[], gt4hip_count_table *table, int probe,
+                       int presence, int *used);
 int gt4hip_io_download (gt4hip_context *ctx, const void *dev, void *host, size_t bytes);
 
 #define HIPCHK(ctx, call)                                                                               \

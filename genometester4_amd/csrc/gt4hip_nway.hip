@@ -66,7 +66,7 @@ constexpr int NWAY_PSTRIDE = 10;  /* u64 per tile boundary in the partition tabl
 constexpr int NWAY_LIMIT = GT4_NWAY_LIMIT;    /* keys per bucket the bucket walks handle */
 constexpr int NWAY_TRY0 = GT4_NWAY_TRY0;     /* ... that the interpolation's buckets may hold before the tile is bucketed by a pivot run instead */
 
-enum : int { NWAY_COUNT = 0, NWAY_UNION = 1, NWAY_DUPS = 2, NWAY_TABLE = 3 };
+enum : int { NWAY_COUNT = 0, NWAY_UNION = 1, NWAY_DUPS = 2, NWAY_TABLE = 3, NWAY_PROBE = 4 };
 __host__ __device__ constexpr bool nway_staged (int mode) { return mode == NWAY_UNION || mode == NWAY_DUPS; } /* kept records leave through the staging area */
 
 struct NwayParams {
@@ -85,7 +85,11 @@ struct NwayParams {
   /* NWAY_COUNT with tile_totals: every tile's number of distinct keys -> tile_totals[tile].
    * NWAY_TABLE (the count table of glistquery's multi-list dump, src/set-operations.c:131-183): row r of the
    * table is the r-th distinct key; tile_base[tile] = rows before the tile (from a counting launch over the
-   * same partition); list i's count of the key goes to table_counts[r * table_cols + table_col[i]]. */
+   * same partition); list i's count of the key goes to table_counts[r * table_cols + table_col[i]].
+   * NWAY_PROBE (the table restricted to the keys of list 0: gt4_is_union, search_lists_multi; src/set-operations.c:
+   * 185-228, src/glistquery.c:776-812): row r is record r of list 0 -- no counting launch, no ordered pass: list 0's
+   * records leave their index at their position, every record of the same key finds it there.  rule NUMBER:
+   * count_override instead of the count (membership). */
   u32 *tile_totals;
   const u64 *tile_base;
   u64 *table_keys;
@@ -529,7 +533,7 @@ struct NwayShared {
    * three deep: one 64-record wave slot per wave-instruction */
   u64 slot_addr[3][NCH];
   u32 slot_cnt[3][NCH];
-  u32 slot_run[3][NCH];                    /* (NWAY_TABLE, NWAY_DUPS) the list a slot's records come from */
+  u32 slot_run[3][NCH];                    /* (NWAY_TABLE, NWAY_PROBE, NWAY_DUPS) the list a slot's records come from */
   u32 tab_pbase[3][NWAY_MAX];              /* first position of each run */
   u32 tab_len[3][NWAY_MAX];
   /* tile number (0xffffffff: none), records, wave slots, shift | direct << 8, multiplier, smallest
@@ -691,7 +695,7 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
     if (lane < NCH) {
       sh.slot_cnt[tb][lane] = in ? (len_r - first < (u32) WAVE ? len_r - first : (u32) WAVE) : 0u;
       sh.slot_addr[tb][lane] = lb_r + 12ull * (s_r + first);
-      if (MODE == NWAY_TABLE || MODE == NWAY_DUPS) sh.slot_run[tb][lane] = run;
+      if (MODE == NWAY_TABLE || MODE == NWAY_PROBE || MODE == NWAY_DUPS) sh.slot_run[tb][lane] = run;
     }
     u64 base = 0;
     if (MODE == NWAY_DUPS) {
@@ -699,6 +703,7 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
       for (int q = 0; q < NWAY_MAX; q++) base += (u32) q < p.k ? readlane_u64 (row, q) : 0ull;
     }
     if (MODE == NWAY_TABLE) base = readlane_u64 (row, 2 * NWAY_PSTRIDE);
+    if (MODE == NWAY_PROBE) base = readlane_u64 (row, 0); /* the tile's first record of list 0 = its first row */
     const u32 lo_lo = (u32) __builtin_amdgcn_readlane ((int) rlo, NWAY_MAX), lo_hi = (u32) __builtin_amdgcn_readlane ((int) rhi, NWAY_MAX);
     const u32 bk_lo = (u32) __builtin_amdgcn_readlane ((int) rlo, NWAY_MAX + 1), bk_hi = (u32) __builtin_amdgcn_readlane ((int) rhi, NWAY_MAX + 1);
     u32 h = tile;
@@ -1094,6 +1099,15 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
         u32 q = nway_skew (pos[k]);
         if (MODE == NWAY_DUPS) q = nway_skew (pos[k] + atomicAdd (&sh.s.scnt[q], 1u)); /* equal sample keys: one position each */
         else if (MODE == NWAY_TABLE) { /* (counts go to the table, below) */ }
+        else if (MODE == NWAY_PROBE) {
+          /* a record of list 0 (the first run: its slots are the tile's first) leaves its index + 1 */
+          if (uniform32 (sh.slot_run[tb][wid * RPT + k]) == 0u) {
+            const u32 idx = (u32) (wid * RPT + k) * WAVE + (u32) lane;
+            sh.s.scnt[q] = idx + 1u;
+            p.table_keys[out_base + idx] = key[k];
+          }
+          continue;
+        }
         else if (p.rule == 1u) atomicAdd (&sh.s.scnt[q], cnt[k]);
         else if (p.rule == 4u) atomicMax (&sh.s.scnt[q], cnt[k]);
         sh.s.skey[q] = key[k];
@@ -1164,7 +1178,16 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
       ocnt[i] = 0;
       kpre[i] = 0;
     }
-    if (has_pos) {
+    if (MODE == NWAY_PROBE && has_rec) {
+      /* (behind B5: every record of list 0 has left its index) */
+#pragma unroll
+      for (int k = 0; k < RPT; k++) {
+        if (!(ba[k] >> 31)) continue;
+        const u32 r = sh.s.scnt[nway_skew (pos[k])];
+        if (r) p.table_counts[(out_base + r - 1u) * p.table_cols + p.table_col[uniform32 (sh.slot_run[tb][wid * RPT + k])]] = p.rule == 7u ? p.count_override : cnt[k];
+      }
+    }
+    if (MODE != NWAY_PROBE && has_pos) {
 #pragma unroll
       for (int i = 0; i < RPT; i++) {
         const u32 q = nway_skew ((u32) (wid * RPT + i) * WAVE + (u32) lane);
@@ -1266,7 +1289,7 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
     __syncthreads ();
     write_out_tile<NT> (out, MODE == NWAY_UNION ? uniform64 (sh.excl) : pend_base, pend_tot, sh.stage, tid);
   }
-  if (MODE != NWAY_DUPS && MODE != NWAY_TABLE) {
+  if (MODE != NWAY_DUPS && MODE != NWAY_TABLE && MODE != NWAY_PROBE) {
     const u64 v = wave_sum (acc_sum);
     if (lane == 0 && v) atomicAdd (&ctl->total_count[0], v);
     if (tid == 0 && blk_cnt) atomicAdd (&ctl->n_words[0], blk_cnt);
@@ -1290,18 +1313,20 @@ hipError_t launch_nway_mode (hipStream_t s, int mode, int grid, const NwayParams
   if (mode == NWAY_DUPS) return launch_nway<NWAY_DUPS> (s, grid, p, part, out, desc, ctl);
   if (mode == NWAY_COUNT) return launch_nway<NWAY_COUNT> (s, grid, p, part, out, desc, ctl);
   if (mode == NWAY_TABLE) return launch_nway<NWAY_TABLE> (s, grid, p, part, out, desc, ctl);
+  if (mode == NWAY_PROBE) return launch_nway<NWAY_PROBE> (s, grid, p, part, out, desc, ctl);
   return launch_nway<NWAY_UNION> (s, grid, p, part, out, desc, ctl);
 }
 
 int nway_blocks_per_cu (int mode)
 {
-  static int cache[4] = { 0, 0, 0, 0 };
+  static int cache[5] = { 0, 0, 0, 0, 0 };
   if (!cache[mode]) {
     int n = 0;
     hipError_t e;
     if (mode == NWAY_DUPS) e = hipOccupancyMaxActiveBlocksPerMultiprocessor (&n, k_nway_merge<NWAY_NT, NWAY_RPT, NWAY_NBF, NWAY_DUPS>, NWAY_NT, 0);
     else if (mode == NWAY_COUNT) e = hipOccupancyMaxActiveBlocksPerMultiprocessor (&n, k_nway_merge<NWAY_NT, NWAY_RPT, NWAY_NBF, NWAY_COUNT>, NWAY_NT, 0);
     else if (mode == NWAY_TABLE) e = hipOccupancyMaxActiveBlocksPerMultiprocessor (&n, k_nway_merge<NWAY_NT, NWAY_RPT, NWAY_NBF, NWAY_TABLE>, NWAY_NT, 0);
+    else if (mode == NWAY_PROBE) e = hipOccupancyMaxActiveBlocksPerMultiprocessor (&n, k_nway_merge<NWAY_NT, NWAY_RPT, NWAY_NBF, NWAY_PROBE>, NWAY_NT, 0);
     else e = hipOccupancyMaxActiveBlocksPerMultiprocessor (&n, k_nway_merge<NWAY_NT, NWAY_RPT, NWAY_NBF, NWAY_UNION>, NWAY_NT, 0);
     if (e != hipSuccess || n < 1) n = 1;
     const int by_regs = nway_waves_per_simd (NWAY_NT) * 4 / (NWAY_NT / 64);
@@ -1368,7 +1393,7 @@ void nway_samples_per_tile (u32 k, u32 *first_try, u32 *sure)
 
 static int nway_run (gt4hip_context *ctx, const gt4hip_list *const lists[], uint32_t k, uint32_t rule, uint32_t cutoff, uint32_t ovr,
                      uint32_t filter, bool count_only, gt4hip_list *out, uint64_t *n_words, uint64_t *total_count, double *device_ms,
-                     int *used, gt4hip_count_table *table, const uint32_t *cols)
+                     int *used, gt4hip_count_table *table, const uint32_t *cols, bool probe)
 {
   *used = 0;
   if (k < 2 || k > NWAY_MAX) return GT4HIP_OK;
@@ -1478,7 +1503,7 @@ static int nway_run (gt4hip_context *ctx, const gt4hip_list *const lists[], uint
     lv.p.filter = filter;
     lv.p.spin_limit = ctx->spin_limit;
     lv.p.force_fallback = ctx->kway_vt == 99 ? 1u : (ctx->kway_vt == 98 ? 2u : 0u); /* option "kway_vt" = 99 / 98: every tile takes the search path / the pivot-run buckets (tests) */
-    const int mode = l > 0 ? NWAY_DUPS : (count_only || table ? NWAY_COUNT : NWAY_UNION);
+    const int mode = l > 0 ? NWAY_DUPS : (table && probe ? NWAY_PROBE : (count_only || table ? NWAY_COUNT : NWAY_UNION));
     lv.p.scan_group = ctx->scan_group > 0 ? 1u : (ctx->scan_group < 0 ? 0u : (tiles > (48000ull << 6) ? 1u : 0u));
     lv.p.dynamic = ctx->dynamic > 0 ? 1u : (ctx->dynamic < 0 ? 0u : (mode == NWAY_UNION ? 1u : 0u));
     u32 *dst = NULL;
@@ -1498,7 +1523,15 @@ static int nway_run (gt4hip_context *ctx, const gt4hip_list *const lists[], uint
     } else if ((u64) grid > tiles) {
       grid = (int) tiles;
     }
-    if (l == 0 && table) { /* the tiles' distinct keys, then the rows before every tile, behind each other in the descriptor area */
+    if (l == 0 && table && probe) { /* rows = the records of list 0: the table exists before the launch */
+      if ((rc = gt4hip_table_alloc (ctx, table, lists[0]->n_words, table->n_lists))) break;
+      table->n_keys = lists[0]->n_words;
+      hipMemsetAsync (table->device_counts, 0, (size_t) table->n_keys * table->n_lists * 4, st);
+      lv.p.table_keys = (u64 *) table->device_keys;
+      lv.p.table_counts = (u32 *) table->device_counts;
+      lv.p.table_cols = table->n_lists;
+      for (uint32_t i = 0; i < k; i++) lv.p.table_col[i] = cols[i];
+    } else if (l == 0 && table) { /* the tiles' distinct keys, then the rows before every tile, behind each other in the descriptor area */
       if ((rc = nway_grow (ctx, (void **) &ctx->desc, &ctx->desc_bytes, (size_t) tiles * 4 + 16 + (size_t) tiles * 8))) break;
       lv.p.tile_totals = (u32 *) ctx->desc;
     }
@@ -1540,7 +1573,7 @@ static int nway_run (gt4hip_context *ctx, const gt4hip_list *const lists[], uint
 #endif
       *n_words = ctx->ctl_host->n_words[0];
       *total_count = ctx->ctl_host->total_count[0];
-      if (table) {
+      if (table && !probe) {
         /* second launch over the same partition: key column and counts, every tile at its rows */
         const u64 rows = *n_words;
         u64 *bases = (u64 *) ((char *) ctx->desc + (((size_t) tiles * 4 + 15) & ~(size_t) 15));
@@ -1588,18 +1621,20 @@ int gt4hip_nway_union (gt4hip_context *ctx, const gt4hip_list *const lists[], ui
                        uint32_t filter, bool count_only, gt4hip_list *out, uint64_t *n_words, uint64_t *total_count, double *device_ms,
                        int *used)
 {
-  return nway_run (ctx, lists, k, rule, cutoff, ovr, filter, count_only, out, n_words, total_count, device_ms, used, NULL, NULL);
+  return nway_run (ctx, lists, k, rule, cutoff, ovr, filter, count_only, out, n_words, total_count, device_ms, used, NULL, NULL, false);
 }
 
 /* The count table of 2..8 non-empty lists (all their distinct keys ascending; column cols[i] = list i's
  * count of the key, 0 where it has none) by two launches of the tile kernel over one partition: distinct
  * keys per tile, then keys and counts written at every tile's rows.  table->n_lists columns (those no list
  * is given for stay 0).  *used = 0: nothing was done, the caller builds the table by merges. */
-int gt4hip_nway_table (gt4hip_context *ctx, const gt4hip_list *const lists[], uint32_t k, const uint32_t cols[], gt4hip_count_table *table, int *used)
+int gt4hip_nway_table (gt4hip_context *ctx, const gt4hip_list *const lists[], uint32_t k, const uint32_t cols[], gt4hip_count_table *table, int probe,
+                       int presence, int *used)
 {
+  /* probe: rows = the records of lists[0] (which must be the first, non-empty); presence: 1 instead of the count */
   uint64_t n = 0, t = 0;
   double ms = 0;
-  const int rc = nway_run (ctx, lists, k, 1, 0, 0, FILTER_RAW, true, NULL, &n, &t, &ms, used, table, cols);
+  const int rc = nway_run (ctx, lists, k, probe && presence ? 7 : 1, 0, 1, FILTER_RAW, true, NULL, &n, &t, &ms, used, table, cols, probe != 0);
   if (rc || !*used) gt4hip_table_free (table);
   return rc;
 }

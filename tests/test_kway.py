@@ -283,6 +283,33 @@ def _check_table(ctx, lists, k=20, expect_kway=True):
     finally:
         ctx.set_option("kway", 1)
     assert mk.tobytes() == tk.tobytes() and mc.tobytes() == tc.tobytes()
+    # the tables restricted to the keys of list 0 (gt4_is_union / search_lists_multi; reference
+    # src/set-operations.c:185-228, src/glistquery.c:776-812): counts, and membership (a list may hold a key with count 0)
+    if len(lists) and len(lists[0]):
+        before = ctx.get_counter("kway_calls")
+        pk, pc = ctx.union_table(dev, probe=True)
+        pk2, pp = ctx.union_table(dev, probe=True, presence=True)
+        if expect_kway and 2 <= 1 + sum(len(x) > 0 for x in lists[1:]) <= 8:
+            assert ctx.get_counter("kway_calls") == before + 2
+        assert pk.tobytes() == lists[0]["key"].tobytes() == pk2.tobytes()
+        for j, x in enumerate(lists):
+            if len(x):
+                idx = np.searchsorted(x["key"], lists[0]["key"])
+                idx[idx == len(x)] = 0
+                hit = x["key"][idx] == lists[0]["key"]
+                cnt = np.where(hit, x["count"][idx], 0).astype(np.uint32)
+            else:
+                hit = np.zeros(len(lists[0]), dtype=bool)
+                cnt = np.zeros(len(lists[0]), dtype=np.uint32)
+            assert pp[:, j].tobytes() == hit.astype(np.uint32).tobytes(), "membership column %d" % j
+            assert pc[:, j].tobytes() == cnt.tobytes(), "probe column %d" % j
+        ctx.set_option("kway", 0)
+        try:
+            qk, qc = ctx.union_table(dev, probe=True)
+            _, qp = ctx.union_table(dev, probe=True, presence=True)
+        finally:
+            ctx.set_option("kway", 1)
+        assert qk.tobytes() == pk.tobytes() and qc.tobytes() == pc.tobytes() and qp.tobytes() == pp.tobytes()
     for d in dev:
         d.free()
 
