@@ -237,3 +237,68 @@ def test_sort_and_fold_beyond_2_pow_32_words(ctx):
     got = lst.download_range(0, m)
     assert (got["key"] == exp_keys).all() and (got["count"] == exp_counts.astype(np.uint32)).all()
     lst.free()
+
+
+def test_count_tables_at_bench_size(ctx):
+    """N3 at the size bench.py --workload table runs: six 1e8-entry k=25 lists (even lists share one key
+    set).  The union table (4e8 rows x 6) and the table restricted to the keys of list 0, by the N-way tile
+    kernel: row count and key column against the N-way union's own output, every column against
+    searchsorted on key windows of the lists (gt4_union / gt4_is_union rows, reference
+    src/set-operations.c:131-183, :185-228); the merge path (option kway = 0) gives the same bytes on the windows."""
+    from genometester4_amd import capi
+    import ctypes as C
+    n, nl = 100_000_000, 6
+    lists = []
+    for j in range(nl):
+        lst = ctx.alloc(n, 25)
+        shared = j % 2 == 0
+        ctx.generate_ex(lst, n, 7 if shared else 100 + j, 50 + j, 8, 16, 0 if shared else 1 + j)
+        lists.append(lst)
+    rc, nw, tot, uni = ctx.union_multi(lists, 0, 4, 1)  # every key kept
+    assert rc == 0
+    arr = (C.c_void_p * nl)(*[l.h for l in lists])
+
+    def rows(table, first, count):
+        keys = np.empty(count, dtype=np.uint64)
+        counts = np.empty((count, nl), dtype=np.uint32)
+        assert capi.lib().gt4hip_table_download(ctx.h, C.byref(table), first, count, keys.ctypes.data, counts.ctypes.data) == 0
+        return keys, counts
+
+    def column(lst, keys):
+        """list `lst`'s counts of `keys` (ascending), 0 where absent, and membership"""
+        f, e = lst.lower_bound(int(keys[0])), lst.lower_bound(int(keys[-1]) + 1) if int(keys[-1]) + 1 < (1 << 64) else lst.n_words
+        recs = lst.download_range(f, e - f)
+        if not len(recs):
+            return np.zeros(len(keys), dtype=np.uint32), np.zeros(len(keys), dtype=bool)
+        idx = np.searchsorted(recs["key"], keys)
+        idx[idx == len(recs)] = 0
+        hit = recs["key"][idx] == keys
+        return np.where(hit, recs["count"][idx], 0).astype(np.uint32), hit
+
+    W = 200_000
+    for kway in (1, 0):
+        ctx.set_option("kway", kway)
+        try:
+            t = capi.CountTable()
+            assert capi.lib().gt4hip_union_table(ctx.h, arr, nl, C.byref(t)) == 0
+            assert t.n_keys == nw
+            for first in (0, nw // 2, nw - W):
+                keys, counts = rows(t, first, W)
+                assert keys.tobytes() == uni.download_range(first, W)["key"].tobytes()
+                for j, lst in enumerate(lists):
+                    assert counts[:, j].tobytes() == column(lst, keys)[0].tobytes(), "union table, list %d, rows from %d" % (j, first)
+            capi.lib().gt4hip_table_free(C.byref(t))
+            for presence in (0, 1):
+                t = capi.CountTable()
+                assert capi.lib().gt4hip_probe_table_ex(ctx.h, arr, nl, presence, C.byref(t)) == 0
+                assert t.n_keys == n
+                for first in (0, n // 3, n - W):
+                    keys, counts = rows(t, first, W)
+                    assert keys.tobytes() == lists[0].download_range(first, W)["key"].tobytes()
+                    for j, lst in enumerate(lists):
+                        c, hit = column(lst, keys)
+                        exp = hit.astype(np.uint32) if presence else c
+                        assert counts[:, j].tobytes() == exp.tobytes(), "probe table (presence %d), list %d, rows from %d" % (presence, j, first)
+                capi.lib().gt4hip_table_free(C.byref(t))
+        finally:
+            ctx.set_option("kway", 1)
