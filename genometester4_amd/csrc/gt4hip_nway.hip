@@ -543,7 +543,10 @@ struct NwayShared {
   u32 tick;
 };
 
-__host__ __device__ constexpr int nway_waves_per_simd (int nt) { return nt >= 1024 ? 4 : (nt >= 512 ? 4 : 4); }
+#ifndef GT4_NWAY_WAVES
+#define GT4_NWAY_WAVES 4
+#endif
+__host__ __device__ constexpr int nway_waves_per_simd (int nt) { return GT4_NWAY_WAVES; }
 
 __device__ __forceinline__ u32 nway_skew (u32 i) { return i + (i >> 5); }
 

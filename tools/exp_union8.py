@@ -6,6 +6,9 @@ from genometester4_amd import capi
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 500_000_000
 nl = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 ctx = capi.Context(0)
+for opt in ("scan_group", "dynamic", "spin_limit"):
+    if os.environ.get(opt.upper()):
+        ctx.set_option(opt, int(os.environ[opt.upper()]))
 lists = []
 for j in range(nl):
     l = ctx.alloc(n, 25)
