@@ -329,6 +329,11 @@ def test_count_table_with_empty_members_identical_lists_and_more_than_eight(ctx)
     _check_table(ctx, [lists[0], lists[0].copy(), lists[0].copy(), lists[1]])          # equal keys in several lists
     _check_table(ctx, [lists[0], empty], expect_kway=False)                            # one non-empty list: by merges
     _check_table(ctx, _random_lists(rng, 11, 30000), expect_kway=False)                # more than eight: by merges
+    # keys 0 and 2^64 - 1 (the all-ones filler of the bucket walks is a legal k = 32 key)
+    edge = [U.make_records(np.array([0, 5, (1 << 64) - 1], dtype=np.uint64), np.array([3, 0, 7], dtype=np.uint32)),
+            U.make_records(np.array([5, (1 << 63), (1 << 64) - 1], dtype=np.uint64), np.array([1, 2, 0], dtype=np.uint32)),
+            U.make_records(np.array([(1 << 64) - 1], dtype=np.uint64), np.array([9], dtype=np.uint32))]
+    _check_table(ctx, edge, k=32)
 
 
 def test_count_table_of_clustered_keys(ctx):
