@@ -27,18 +27,28 @@
  *      chained scan of tile totals (gt4hip_device.h) has published by then.
  *
  * The interpolation is only a heuristic for SPEED: a tile whose keys cluster (a bucket with more than
- * NWAY_LIMIT keys) takes a bounded fallback -- the records go back to LDS as sorted runs and every
- * record adds up its lower bounds in all the runs (binary searches) -- and continues at step 4.
+ * NWAY_TRY0 keys) is bucketed again by rank in its longest run (NWAY_LIMIT), and one that defeats that
+ * too takes a bounded fallback -- the records go back to LDS as sorted runs and every record adds up
+ * its lower bounds in all the runs (binary searches) -- and continues at step 4.
  *
- *   K5 k_nway_sample     every S-th key of every list -> "sample lists" (1/S of the data)
- *   K6 k_nway_partition  tile boundaries: the merged samples' every G-th key, located in every list
- *                        by binary search (all records with a key <= the boundary key go left), plus
- *                        the tile's key range and interpolation constants;
- *      k_nway_check      no tile may exceed the LDS capacity (else the host retries with fewer samples
- *                        per tile, down to the number for which it cannot happen)
- *   K7 k_nway_merge      the tile kernel; NWAY_DUPS keeps every record (it is how the sample lists
- *                        themselves are merged, one level up: the recursion ends when a level fits
- *                        one tile), NWAY_UNION / NWAY_COUNT fold equal keys and apply the rule.
+ * The same tile kernel also builds glistquery's count tables (gt4_union / gt4_is_union /
+ * search_lists_multi: src/set-operations.c:131-228, src/glistquery.c:776-812): NWAY_COUNT with per-tile
+ * totals + NWAY_TABLE (all distinct keys, a column per list), NWAY_PROBE (the keys of list 0).
+ *
+ *   K5 k_nway_sample          every S-th key of every list -> "sample lists" (1/S of the data)
+ *   K6 k_nway_sample_counts,  tile boundaries: the merged samples' every G-th key; a merged sample carries its
+ *      k_nway_bracket_bases,  list, so the samples of list i in front of a boundary are a prefix count and the
+ *      k_nway_partition_rows  cut lies in the S records behind them (all records with a key <= the boundary key
+ *                             go left), plus the tile's key range, interpolation constants and whether its samples
+ *                             look clustered; k_nway_partition: the same by searches over brackets of 64 tiles (the
+ *                             topmost level, which has no merged samples; option "kway_vt" = 97)
+ *      k_nway_check           no tile may exceed the LDS capacity (else the host retries with fewer samples
+ *                             per tile, down to the number for which it cannot happen)
+ *   K7 k_nway_merge           the tile kernel; NWAY_DUPS keeps every record and remembers its list (it is how the
+ *                             sample lists themselves are merged, one level up: the recursion ends when a level
+ *                             fits one tile), NWAY_UNION / NWAY_COUNT fold equal keys and apply the rule,
+ *                             NWAY_TABLE / NWAY_PROBE write count tables
+ *      k_nway_tile_bases      rows before every tile (count tables)
  */
 #include "gt4hip_device.h"
 #include "gt4hip_host.h"
