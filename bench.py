@@ -6,10 +6,21 @@
 
 A "step" is one complete two-list intersection (merge-path partition + merge kernel + totals
 read-back) over synthetic sorted lists that are already resident in HBM.  Workload at N=1 is
-BASELINE.json configs[1]: two 2x10^9-entry k=25 lists (~24 GB each), `glistcompare -i`.  With N>1
-every rank owns one key-range shard of the same shape (the set operations are key-local, SURVEY
-8e): no data-path collective, only the per-shard (n_words, total_count) header totals are
-all-gathered over RCCL; scaling is weak.
+BASELINE.json configs[1]: two 2x10^9-entry k=25 lists (~24 GB each), `glistcompare -i`.  With N>1 the
+default is the SAME job (`"scaling": "strong"`): every rank keeps its key range of the one pair
+(gt4hip_shard_first_key; the set operations are key-local), merges it, and the per-shard
+(n_words, total_count) header totals are all-gathered over RCCL inside every step.  `--scaling weak`
+gives every GPU an independent pair instead (no exchange; a reference line, not the metric's job).
+
+The default line also carries a `"union8"` record -- BASELINE configs[3], the 8-way union of eight
+5x10^8-entry lists as ONE job sharded by key range over the ranks: `value_with_gather` (RCCL gatherv of
+the payload to rank 0 inside the step) and `merge_only` (what the shards sustain when every rank writes
+its own extent, the C host's default); BASELINE's ">= 6x at 8 GPUs" refers to `merge_only`.  Every
+line checks its job totals against the closed forms of the generator (|A n B| = n / 2, 5 n distinct keys
+of the eight lists) and the totals committed for the default sizes, and exits 3 on a mismatch.
+
+`--dist` chooses the key distribution of the synthetic lists (genometester4_amd/synth.py): stride
+(default; one key per stride of the key space), iid, clustered, genomic.
 
 Prints ONE JSON line on rank 0.  `roofline` is computed from the merge kernel's own HIP-event time
 (recorded by the library on the stream it launches on); `cpu_baseline` times the REFERENCE binary
@@ -42,25 +53,34 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def build_lists(ctx, capi, n, k, seed_base):
-    """A = S u PA, B = S' u PB from three disjoint residue classes (mod 3): |A| = |B| = n,
-    |A n B| = |S| = n // 2 exactly; S' has S's keys with different counts."""
-    n_s = n // 2
-    n_p = n - n_s
-    s = ctx.alloc(n_s, k)
-    ctx.generate_ex(s, n_s, seed_base + 11, seed_base + 21, 8, 3, 0)
-    p = ctx.alloc(n_p, k)
-    ctx.generate_ex(p, n_p, seed_base + 12, seed_base + 23, 8, 3, 1)
-    _, out, _ = ctx.compare(s, p, capi.OP_UNION)
-    a = out[capi.OP_UNION]
-    ctx.generate_ex(s, n_s, seed_base + 11, seed_base + 22, 8, 3, 0)
-    ctx.generate_ex(p, n_p, seed_base + 13, seed_base + 24, 8, 3, 2)
-    _, out, _ = ctx.compare(s, p, capi.OP_UNION)
-    b = out[capi.OP_UNION]
-    s.free()
-    p.free()
-    assert a.n_words == n and b.n_words == n, (a.n_words, b.n_words, n)
-    return a, b
+def build_lists(ctx, capi, n, k, seed_base, dist="stride"):
+    """A and B of about n records, half of each shared (genometester4_amd/synth.py; `stride`: exactly n
+    and |A n B| = n // 2 from three disjoint residue classes)."""
+    from genometester4_amd import synth
+    return synth.make_pair(ctx, n, k, dist, seed_base)
+
+
+# job totals of the default sizes, committed with the round-3 profiles (profiles/round3/r3final_*_bench.json)
+EXPECTED_TOTALS = {
+    ("intersect", "stride", 2_000_000_000, 25): (1_000_000_000, 3_187_480_123),
+    ("union8", "stride", 500_000_000, 25): (2_500_000_000, 17_999_789_507),
+}
+
+
+def self_check(kind, dist, n, k, n_words, total_count):
+    """Closed forms of the stride generator + the committed totals of the default sizes -> None or a message."""
+    if dist != "stride":
+        return None
+    if os.environ.get("GT4_BENCH_BREAK_CHECK"):  # test hook: the failure path itself
+        n_words += 1
+    if kind == "intersect" and n_words != n // 2:
+        return "intersection holds %d records, generator says %d" % (n_words, n // 2)
+    if kind == "union8" and n_words != 5 * n:
+        return "union holds %d records, generator says %d" % (n_words, 5 * n)
+    exp = EXPECTED_TOTALS.get((kind, dist, n, k))
+    if exp and (n_words, total_count) != exp:
+        return "%s totals (%d, %d) differ from the committed N=1 totals %s" % (kind, n_words, total_count, exp)
+    return None
 
 
 def _ref_flags(ops, cutoff):
@@ -183,47 +203,48 @@ def union8_roofline(ctx, n_list, n_out_local, device_ms, kernel_ms, workload_n):
                     "tile partition, tile kernel); without committed PMC passes traffic = 12 x the records the library read and wrote"}
 
 
+def _xdev():
+    """device of the tensors that go through torch.distributed (the one-device test hook runs over gloo)"""
+    import torch.distributed as dist
+    return "cuda" if (not dist.is_initialized() or dist.get_backend() == "nccl") else "cpu"
+
+
 def bench_union8(args, ctx, capi, rank, local_rank, world):
-    """BASELINE configs[3]: 8-way union (MakeUnion.pl replacement) of eight lists -- ONE job, sharded
-    by key range over the ranks (strong scaling): every rank keeps its key range of every list
-    resident in HBM, unions its eight shards (pairwise tree in HBM), the header totals are
-    all-gathered and the payload is gathered on rank 0 over RCCL (gt4hip_comm_gatherv of the C ABI:
-    grouped ncclSend / ncclRecv -- the entry point the C command-line tool uses).  `--tree` takes the
-    pairwise tree of the pair kernel instead of the one-pass N-way tile kernel."""
+    """BASELINE configs[3]: 8-way union (MakeUnion.pl replacement, reference scripts/MakeUnion.pl:31-95) of eight
+    lists -- ONE job, sharded by key range over the ranks (strong scaling): every rank keeps its key range of every
+    list resident in HBM, unions its eight shards in one pass of the N-way tile kernel (or whatever the library
+    chooses for the lists), the header totals are all-gathered and the payload is gathered on rank 0 over RCCL
+    (gt4hip_comm_gatherv of the C ABI: grouped ncclSend / ncclRecv -- the entry point the C command-line tool
+    uses).  Rank 0 merges straight into the gathered list (its range is the first extent).  `--tree` takes the
+    pairwise tree of the pair kernel.  Returns the result line (rank 0) or None."""
     import torch
     import torch.distributed as dist
     from genometester4_amd import distributed as D
+    from genometester4_amd import synth
     n8 = args.n8
     if args.tree:
         ctx.set_option("kway", 0)
-    full = []
-    for j in range(8):
-        lst = ctx.alloc(n8, args.k)
-        # disjoint residue classes mod 16 for half of the lists' keys, shared class 0 for the rest:
-        # every key of class 0 is present in all lists that draw it (same key seed)
-        shared = j % 2 == 0
-        ctx.generate_ex(lst, n8, 7 if shared else 100 + j, 50 + j, 8, 16, 0 if shared else 1 + j)
-        full.append(lst)
+    full = synth.make_lists8(ctx, n8, args.k, args.dist)
+    n_in = sum(l.n_words for l in full)
     comm_id = None
-    if world > 1:
+    if world > 1 and _xdev() == "cuda":
         box = [capi.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         comm_id = box[0]
     sh = D.DeviceShards(ctx, rank, world, comm_id)
     shards = [sh.shard_of(l, args.k) for l in full]
     n_local_in = sum(s.n_words for s in shards)
-    out = ctx.alloc(max(1, n_local_in), args.k)
+    # rank 0 of a sharded job unions into the list the payload is gathered in: its extent is the first
+    has_comm = sh.comm is not None
+    root_direct = world > 1 and rank == 0 and has_comm
+    out = ctx.alloc(max(1, n_in if root_direct else n_local_in), args.k)
     op = D.gpu_union_multi_op(ctx)
 
     def totals_exchange(n, total):
-        return D.exchange_totals(n, total, device="cuda")
-
-    state = {"gathered": None}
+        return D.exchange_totals(n, total, device=_xdev())
 
     def step(gather=True):
-        n, total, res, totals = sh.run(shards, op, totals_exchange, root=0, out=out, gathered=state["gathered"], gather=gather)
-        if gather and world > 1 and rank == 0:
-            state["gathered"] = res  # allocated by the first step, reused afterwards
+        n, total, res, totals = sh.run(shards, op, totals_exchange, root=0, out=out, gathered=out if root_direct else None, gather=gather)
         return n, total, totals, dict(sh.last_ms)
 
     def fence():
@@ -252,22 +273,23 @@ def bench_union8(args, ctx, capi, rank, local_rank, world):
         ker_ms.append(ctx.get_counter("nway_kernel_us") / 1000.0 if ctx.get_counter("kway_calls") else 0.0)
     fence()
     merge_only = time.perf_counter() - t1
+    one_pass = bool(ctx.get_counter("nway_one_pass"))
     per_rank = [{"rank": rank, "shard_input_records": n_local_in, "merge_ms": statistics.mean(x["merge"] for x in ms),
                  "exchange_and_gather_ms": statistics.mean(x["exchange_and_gather"] for x in ms)}]
     if world > 1:
-        t = torch.tensor([elapsed, merge_only], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed, merge_only], dtype=torch.float64, device=_xdev())
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, merge_only = float(t[0].item()), float(t[1].item())
         box = [None] * world
         dist.all_gather_object(box, per_rank[0])
         per_rank = box
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.union8_no_cpu:
         # the oracle's union_multi (reference src/glistcompare.c:545-591, one thread) on a key window of all
         # eight lists; the GPU's totals for the same window must agree
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as O
-        m = min(n8, args.cpu_sample // 32)
+        m = min(full[0].n_words, args.cpu_sample // 32)
         last_key, _ = full[0].get_word(m - 1)
         cuts = [l.lower_bound(last_key + 1) for l in full]
         host = [l.download_range(0, c) for l, c in zip(full, cuts)]
@@ -282,27 +304,30 @@ def bench_union8(args, ctx, capi, rank, local_rank, world):
         o_g.free()
         for d in dev:
             d.free()
+    res = None
     if rank == 0:
-        n_in = 8 * n8
-        print(json.dumps({
+        res = {
             "metric": "k-mers merged/sec, 8-way k=%d union (MakeUnion.pl replacement), lists resident in HBM, result gathered on rank 0" % args.k,
             "value": n_in * args.steps / elapsed, "unit": "k-mers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u64 keys + u32 counts", "data": "synthetic",
-            "config": {"workload": "8-way union, eight %d-entry k=%d lists, ONE job key-range sharded over %d GPU(s), RCCL gatherv to rank 0" % (n8, args.k, world),
-                       "entries_per_list": n8, "output_records": n_out, "output_total_count": total_out, "device": ctx.device_info(),
-                       "per_rank": per_rank,
+            "config": {"workload": "8-way union, eight %d-entry k=%d lists (%s keys), ONE job key-range sharded over %d GPU(s), RCCL gatherv to rank 0" % (n8, args.k, args.dist, world),
+                       "entries_per_list": n8, "input_records": n_in, "dist": args.dist, "output_records": n_out, "output_total_count": total_out, "device": ctx.device_info(),
+                       "per_rank": per_rank, "path": "one pass of the N-way tile kernel" if one_pass else "pairwise tree of the pair kernel",
                        "merge_only_k_mers_per_s": n_in * args.steps / merge_only,
                        "merge_only_ms_per_step": merge_only / args.steps * 1e3,
-                       "gathered_bytes_per_step": 12 * (n_out - totals[0][0]) if world > 1 else 0},
-            "roofline": union8_roofline(ctx, n_local_in // 8, totals[0][0], statistics.mean(dev_ms), statistics.mean(ker_ms), n8),
+                       "gathered_bytes_per_step": 12 * (n_out - totals[0][0]) if has_comm else 0,
+                       "note": "value includes the RCCL gatherv of the payload to rank 0; merge_only_* is the same job with every rank keeping (or writing) its own extent: BASELINE's >= 6x at 8 GPUs refers to merge_only"},
+            "roofline": union8_roofline(ctx, n_local_in // 8, totals[0][0], statistics.mean(dev_ms), statistics.mean(ker_ms) if one_pass else 0.0, n8 if args.dist == "stride" else -1),
             **({"cpu_baseline": cpu[0], "verified": cpu[1]} if cpu else {}),
-        }), flush=True)
+        }
+        bad = self_check("union8", args.dist, n8, args.k, n_out, total_out)
+        res["self_check"] = "ok" if bad is None else "FAILED: " + bad
     sh.close()
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
-    ctx.close()
+    out.free()
+    for l in shards + full:
+        l.free()
+    return res
 
 
 def bench_sort(args, ctx, capi):
@@ -367,8 +392,7 @@ def bench_sort(args, ctx, capi):
                                "sample": "numpy.unique(return_counts=True) of the first %d words (sort + run lengths, one thread): what wordtable_sort + wordtable_find_frequencies compute" % m}
         dev = ctx.words_to_list(host, k).download()
         res["verified"] = bool(len(dev) == len(u) and (dev["key"] == u).all() and (dev["count"] == c.astype(np.uint32)).all())
-    print(json.dumps(res), flush=True)
-    ctx.close()
+    return res
 
 
 def bench_table(args, ctx, capi):
@@ -419,104 +443,62 @@ def bench_table(args, ctx, capi):
         dt = time.perf_counter() - t0
         res["cpu_baseline"] = {"value": sum(len(h) for h in host) / dt, "unit": "k-mers/s", "cores": 1, "host_nproc": os.cpu_count(), "kind": "port",
                                "sample": "oracle/gt4_oracle.c union_multi walk (the loop gt4_union shares, set-operations.c:153-181) over the first %d records of every list, one thread" % m}
-    print(json.dumps(res), flush=True)
-    ctx.close()
+    return res
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", "--entries", dest="n", type=int, default=2_000_000_000,
-                    help="entries per list per GPU (--entries: the spelling to use under torch.distributed.run, whose own parser takes --n for an abbreviation)")
-    ap.add_argument("--k", type=int, default=25)
-    ap.add_argument("--cpu-sample", type=int, default=200_000_000, help="records per list timed on the CPU")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--two-pass", action="store_true", help="count+scan+write instead of the single-pass kernel")
-    ap.add_argument("--ns", type=int, default=1_000_000_000, help="sort: words")
-    ap.add_argument("--nt", type=int, default=100_000_000, help="table: entries per list")
-    ap.add_argument("--nt-lists", type=int, default=6, help="table: lists")
-    ap.add_argument("--workload", choices=["intersect", "c2", "union8", "sort", "table"], default="intersect",
-                    help="intersect: BASELINE configs[1] (default, the headline metric); c2: configs[2], union + first complement "
-                         "with cutoff 3 on the same pair; union8: configs[3], 8-way union sharded by key range over the ranks "
-                         "with an RCCL gatherv to rank 0 (strong scaling)")
-    ap.add_argument("--n8", "--entries8", dest="n8", type=int, default=500_000_000, help="union8: entries per list (whole job)")
-    ap.add_argument("--tree", action="store_true", help="union8: the pairwise tree instead of the one-pass N-way kernel")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="intersect / c2 with --gpus N: weak = one independent pair of --n entries per GPU (default); strong = ONE "
-                         "pair of --n entries, every rank merges its key range (gt4hip_shard_first_key) and the header totals are "
-                         "all-gathered inside every step")
-    args = ap.parse_args()
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    import torch
-    import torch.distributed as dist
-    if os.environ.get("GT4_BENCH_ONE_DEVICE"):
-        # test hook: run the N-rank control flow with every rank on device 0 (RCCL refuses two ranks
-        # on one device, so the barrier / reductions go over gloo); never set by the driver
-        local_rank = 0
-        torch.cuda.set_device(0)
-        if world > 1:
-            dist.init_process_group("gloo")
-    else:
-        torch.cuda.set_device(local_rank)
-        if world > 1:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
-    from genometester4_amd import capi
-    ctx = capi.Context(local_rank)
-    if args.two_pass:
-        ctx.set_option("two_pass", 1)
-    if args.workload == "union8":
-        return bench_union8(args, ctx, capi, rank, local_rank, world)
-    if args.workload == "sort":
-        return bench_sort(args, ctx, capi)
-    if args.workload == "table":
-        return bench_table(args, ctx, capi)
+def bench_pair(args, ctx, capi, rank, world, torch, dist):
+    """The two-list workloads (intersect: BASELINE configs[1]; c2: configs[2]).  Returns the result line on rank 0."""
     n = args.n
     strong = args.scaling == "strong"
     ops = capi.OP_INTRSEC if args.workload == "intersect" else (capi.OP_UNION | capi.OP_DIFF1)
     cutoff = 1 if args.workload == "intersect" else 3
     op_bits = [bit for bit in (1, 2, 4) if ops & bit]
+    sharded = strong and world > 1
     while True:
+        a = b = full_a = full_b = outs = None
+        ok = True
         try:
             # strong scaling: every rank builds the SAME pair and keeps its key range of it
-            a, b = build_lists(ctx, capi, n, args.k, 0 if strong else 1000 * rank)
-            if strong and world > 1:
+            a, b = build_lists(ctx, capi, n, args.k, 0 if strong else 1000 * rank, args.dist)
+            if sharded:
                 from genometester4_amd import distributed as D
                 sh = D.DeviceShards(ctx, rank, world, None)
                 full_a, full_b = a, b
                 a, b = sh.shard_of(full_a, args.k), sh.shard_of(full_b, args.k)
             outs = {bit: ctx.alloc(max(1, {1: a.n_words + b.n_words, 2: min(a.n_words, b.n_words), 4: a.n_words}[bit]), args.k) for bit in op_bits}
-            break
         except capi.Gt4HipError as e:
             if e.code != capi.ENOMEM or n < 1_000_000:
                 raise
-            log("rank %d: %d entries per list do not fit (%s); halving" % (rank, n, e))
-            n //= 2
-    if world > 1 and not strong:  # all ranks must run the same shape
-        t = torch.tensor([n], dtype=torch.int64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        if int(t.item()) != n:
-            n = int(t.item())
-            a, b = a.slice(0, n), b.slice(0, n)
+            log("rank %d: %d entries per list do not fit (%s)" % (rank, n, e))
+            ok = False
+        # every rank must run the same shape (strong: the same JOB): agree on the smallest n that fits anywhere
+        n_next = n if ok else n // 2
+        if world > 1:
+            t = torch.tensor([n_next], dtype=torch.int64, device=_xdev())
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            n_next = int(t.item())
+        if ok and n_next == n:
+            break
+        for l in (outs or {}).values():
+            l.free()
+        for l in (a, b, full_a, full_b):
+            if l is not None:
+                l.free()
+        n = n_next
     n_a, n_b = a.n_words, b.n_words
+    n_job = (full_a.n_words + full_b.n_words) if sharded else (n_a + n_b)
 
     exchange_ms = []
     job_stat = {}  # strong scaling: the job-wide header totals of the last step
 
     def step():
         st, _, timing = ctx.compare(a, b, ops, cutoff=cutoff, out=outs)
-        if strong and world > 1:
+        if sharded:
             # the one exchange a sharded pair operation needs (SURVEY 8e step 1): per-shard header totals,
             # all-gathered over RCCL inside the step
             from genometester4_amd import distributed as D
             t0 = time.perf_counter()
-            xdev = "cuda" if dist.get_backend() == "nccl" else None  # (the one-device test hook runs over gloo)
-            job = {bit: tuple(sum(x[i] for x in D.exchange_totals(st[bit][0], st[bit][1], device=xdev)) for i in (0, 1)) for bit in op_bits}
+            job = {bit: tuple(sum(x[i] for x in D.exchange_totals(st[bit][0], st[bit][1], device=_xdev())) for i in (0, 1)) for bit in op_bits}
             exchange_ms.append((time.perf_counter() - t0) * 1e3)
             job_stat.update(job)
         return st, timing
@@ -543,42 +525,44 @@ def main():
     totals = [sum(stat[bit][0] for bit in op_bits), sum(stat[bit][1] for bit in op_bits) & 0x7FFFFFFFFFFFFFFF]
     per_rank = None
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=_xdev())
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         box = [None] * world
         dist.all_gather_object(box, {"rank": rank, "shard_input_records": n_a + n_b, "merge_kernel_ms": statistics.mean(kernel_ms),
                                      "totals_exchange_ms": statistics.mean(exchange_ms) if exchange_ms else 0.0})
         per_rank = box
-    if world > 1 and strong:
+    if sharded:
         totals = [sum(job_stat[bit][0] for bit in op_bits), sum(job_stat[bit][1] for bit in op_bits) & 0x7FFFFFFFFFFFFFFF]  # exchanged inside the step
     elif world > 1:
         # independent shards: the header totals are summed once, for the report
-        g = [torch.zeros(2, dtype=torch.int64, device="cuda") for _ in range(world)]
-        dist.all_gather(g, torch.tensor(totals, dtype=torch.int64, device="cuda"))
+        g = [torch.zeros(2, dtype=torch.int64, device=_xdev()) for _ in range(world)]
+        dist.all_gather(g, torch.tensor(totals, dtype=torch.int64, device=_xdev()))
         totals = [int(sum(x[0].item() for x in g)), int(sum(x[1].item() for x in g))]
 
+    res = None
     if rank == 0:
         n_out = sum(stat[bit][0] for bit in op_bits)
         k_ms = statistics.mean(kernel_ms)
         alg_bytes = 12 * (n_a + n_b) + 12 * n_out
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-        traffic, traffic_source = load_traffic(args.workload, n)
+        traffic, traffic_source = load_traffic(args.workload, n if args.dist == "stride" else -1)
         names = {1: "union", 2: "intrsec", 4: "diff1"}
+        shape = "two %d-entry k=%d lists (%.1f GB each, %s keys)" % (n, args.k, 12 * n / 1e9, args.dist)
         if args.workload == "intersect":
             metric = "k-mers merged/sec, 2-list k=%d intersection (glistcompare -i), lists resident in HBM" % args.k
-            if strong and world > 1:
-                wl = "ONE intersection of two %d-entry k=%d lists (%.1f GB each), key-range sharded over %d GPUs (gt4hip_shard_first_key), header totals all-gathered in every step, |A n B| = n/2" % (n, args.k, 12 * n / 1e9, world)
+            if sharded:
+                wl = "ONE intersection of %s, key-range sharded over %d GPUs (gt4hip_shard_first_key), header totals all-gathered in every step, |A n B| ~ n/2" % (shape, world)
             else:
-                wl = ("single-GPU" if world == 1 else "%d independent key-range shards, one per GPU:" % world) + " intersection, two %d-entry k=%d lists (%.1f GB each) per GPU, |A n B| = n/2" % (n, args.k, 12 * n / 1e9)
+                wl = ("single-GPU" if world == 1 else "%d independent pairs, one per GPU:" % world) + " intersection, %s per GPU, |A n B| ~ n/2" % shape
             kernel = "k_pair_merge<1024, 6, MODE_LOOKBACK, intersection, folded MIN>"
         else:
             metric = "k-mers merged/sec, 2-list k=%d union + first complement, cutoff %d (glistcompare -u -d -c %d), lists resident in HBM" % (args.k, cutoff, cutoff)
-            wl = ("single-GPU" if world == 1 else ("ONE job key-range sharded over %d GPUs:" % world if strong else "%d independent key-range shards, one per GPU:" % world)) + " union + difference_first with --cutoff %d, two %d-entry k=%d lists (%.1f GB each) per GPU, |A n B| = n/2" % (cutoff, n, args.k, 12 * n / 1e9)
+            wl = ("single-GPU" if world == 1 else ("ONE job key-range sharded over %d GPUs:" % world if strong else "%d independent pairs, one per GPU:" % world)) + " union + difference_first with --cutoff %d, %s per GPU, |A n B| ~ n/2" % (cutoff, shape)
             kernel = "k_pair_merge<1024, 4, MODE_LOOKBACK, any combination of outputs, default rules>"
         res = {
             "metric": metric,
-            "value": (2 * n if strong else world * (n_a + n_b)) * args.steps / elapsed,
+            "value": (n_job if (strong or world == 1) else world * (n_a + n_b)) * args.steps / elapsed,
             "unit": "k-mers/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -591,13 +575,15 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": wl,
+                "dist": args.dist,
                 "per_rank": per_rank,
-                "entries_per_list_per_gpu": n if not (strong and world > 1) else None,
+                "entries_per_list_per_gpu": n if not sharded else None,
                 "entries_per_list": n if strong else None,
+                "input_records": n_job if (strong or world == 1) else world * (n_a + n_b),
                 "word_length": args.k,
                 "output_records": {names[bit]: stat[bit][0] for bit in op_bits} if world == 1 else totals[0],
                 "output_total_count": {names[bit]: stat[bit][1] for bit in op_bits} if world == 1 else totals[1],
-                "sharding": ("one job, key ranges of equal width, totals all-gather per step" if strong else "one key-range shard per GPU, no data-path collective") if world > 1 else "none",
+                "sharding": ("one job, key ranges of equal width, totals all-gather per step" if strong else "independent pairs, no data-path collective") if world > 1 else "none",
                 "path": "two_pass" if args.two_pass else "single_pass_lookback",
                 "device": ctx.device_info(),
             },
@@ -614,8 +600,12 @@ def main():
                 "device_ms_avg": statistics.mean(device_ms),
                 "traffic": traffic,
                 "traffic_source": traffic_source,
+                "note": "rank 0's launch" + (": its key range of the job" if sharded else ""),
             },
         }
+        if args.workload == "intersect" and (strong or world == 1):
+            bad = self_check("intersect", args.dist, n, args.k, totals[0], totals[1])
+            res["self_check"] = "ok" if bad is None else "FAILED: " + bad
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"], res["verified"], res["verified_totals"] = cpu_baseline(ctx, capi, a, b, args.k, args.cpu_sample, ops, cutoff)
@@ -624,11 +614,99 @@ def main():
                 res["verified"] = False
             if res["verified"] is False and res["cpu_baseline"].get("value") is not None:
                 log("VERIFICATION FAILED: %s" % res.get("verified_totals"))
+    for l in list(outs.values()) + [a, b, full_a, full_b]:
+        if l is not None:
+            l.free()
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", "--entries", dest="n", type=int, default=2_000_000_000,
+                    help="entries per list (--entries: the spelling to use under torch.distributed.run, whose own parser takes --n for an abbreviation)")
+    ap.add_argument("--k", type=int, default=25)
+    ap.add_argument("--cpu-sample", type=int, default=200_000_000, help="records per list timed on the CPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--two-pass", action="store_true", help="count+scan+write instead of the single-pass kernel")
+    ap.add_argument("--ns", type=int, default=1_000_000_000, help="sort: words")
+    ap.add_argument("--nt", type=int, default=100_000_000, help="table: entries per list")
+    ap.add_argument("--nt-lists", type=int, default=6, help="table: lists")
+    ap.add_argument("--workload", choices=["intersect", "c2", "union8", "sort", "table"], default="intersect",
+                    help="intersect: BASELINE configs[1] (default, the headline metric; the line also embeds a union8 record); c2: configs[2], "
+                         "union + first complement with cutoff 3 on the same pair; union8: configs[3] alone, 8-way union sharded by key range "
+                         "over the ranks with an RCCL gatherv to rank 0 (strong scaling)")
+    ap.add_argument("--n8", "--entries8", dest="n8", type=int, default=500_000_000, help="union8: entries per list (whole job)")
+    ap.add_argument("--tree", action="store_true", help="union8: the pairwise tree instead of what the library chooses")
+    ap.add_argument("--dist", choices=["stride", "iid", "clustered", "genomic"], default="stride", help="key distribution of the synthetic lists (genometester4_amd/synth.py)")
+    ap.add_argument("--no-union8", action="store_true", help="intersect: leave the union8 record out of the line")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="strong",
+                    help="intersect / c2 with --gpus N > 1: strong (default) = ONE pair of --n entries, every rank merges its key range "
+                         "(gt4hip_shard_first_key) and the header totals are all-gathered inside every step; weak = one independent pair of "
+                         "--n entries per GPU, no exchange")
+    args = ap.parse_args()
+    args.union8_no_cpu = False
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import torch.distributed as dist
+    if os.environ.get("GT4_BENCH_ONE_DEVICE"):
+        # test hook: run the N-rank control flow with every rank on device 0 (RCCL refuses two ranks
+        # on one device, so the barrier / reductions go over gloo); never set by the driver
+        local_rank = 0
+        torch.cuda.set_device(0)
+        if world > 1:
+            dist.init_process_group("gloo")
+    else:
+        torch.cuda.set_device(local_rank)
+        if world > 1:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from genometester4_amd import capi
+    ctx = capi.Context(local_rank)
+    if args.two_pass:
+        ctx.set_option("two_pass", 1)
+    res = None
+    if args.workload == "union8":
+        res = bench_union8(args, ctx, capi, rank, local_rank, world)
+    elif args.workload == "sort":
+        res = bench_sort(args, ctx, capi)
+    elif args.workload == "table":
+        res = bench_table(args, ctx, capi)
+    else:
+        res = bench_pair(args, ctx, capi, rank, world, torch, dist)
+        if args.workload == "intersect" and not args.no_union8:
+            # the other north-star number in the same line: the 8-way union as ONE job over the same ranks
+            args.union8_no_cpu = True  # (its CPU leg belongs to --workload union8)
+            u = bench_union8(args, ctx, capi, rank, local_rank, world)
+            if rank == 0:
+                res["union8"] = {
+                    "workload": u["config"]["workload"], "n_gpus": world, "scaling": "strong",
+                    "value_with_gather": u["value"], "ms_per_step_with_gather": u["ms_per_step"],
+                    "merge_only": u["config"]["merge_only_k_mers_per_s"], "merge_only_ms_per_step": u["config"]["merge_only_ms_per_step"],
+                    "unit": "k-mers/s", "per_rank": u["config"]["per_rank"], "gathered_bytes": u["config"]["gathered_bytes_per_step"],
+                    "output_records": u["config"]["output_records"], "output_total_count": u["config"]["output_total_count"],
+                    "path": u["config"]["path"], "roofline_frac": u["roofline"]["frac"], "whole_call_frac": u["roofline"]["whole_call_frac"],
+                    "self_check": u["self_check"],
+                    "note": "BASELINE's >= 6x at 8 GPUs vs 1 refers to merge_only (every rank keeps / writes its own extent); value_with_gather "
+                            "moves the whole result into rank 0 over xGMI inside the step"}
+    failed = False
+    if rank == 0 and res is not None:
         print(json.dumps(res), flush=True)
+        checks = [res.get("self_check"), (res.get("union8") or {}).get("self_check")]
+        failed = any(c and c != "ok" for c in checks)
+        if failed:
+            log("SELF-CHECK FAILED: %s" % checks)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+    if failed:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -258,6 +258,10 @@ class Context:
         self._chk(lib().gt4hip_words_to_list(self.h, w.ctypes.data if len(w) else None, len(w), word_length, C.byref(h)))
         return DeviceList(self, h)
 
+    def sort_words(self, device_ptr, n_words, word_length):
+        """Sorts n_words packed words at `device_ptr` (device memory) ascending, in place."""
+        self._chk(lib().gt4hip_sort_words(self.h, C.c_void_p(device_ptr), n_words, word_length))
+
     def device_words_to_list(self, device_ptr, n_words, word_length) -> "DeviceList":
         """The same for n_words packed words at `device_ptr` (device memory; sorted in place)."""
         h = C.c_void_p()

@@ -381,7 +381,22 @@ int main (int argc, const char *argv[])
   static const char *const SUFFIX[4] = { "union", "intrsec", "0_diff1", "0_diff2" };
   uint64_t hbm_limit = parse_bytes (getenv ("GT4HIP_HBM_LIMIT"));
   int use_shards = n_gpus >= 1 || hbm_limit != 0;
+  int auto_budget = 0;
   gt4hip_context *ctx = NULL;
+  if (!use_shards) {
+    uint64_t in_records = 0;
+    for (unsigned int f = 0; f < nfiles; f++) in_records += files[f].header.n_words;
+    const int pipeline_off = getenv ("GT4HIP_PIPELINE") && !atoi (getenv ("GT4HIP_PIPELINE"));
+    if (12 * in_records >= (4ull << 30) && !pipeline_off) {
+      /* big inputs: key-range chunks through the loader / merger / writer pipeline, so that reading the next
+       * chunk and writing the previous one overlap the merge (GT4HIP_PIPELINE=0 keeps everything in one
+       * piece).  No context is created here: the worker that runs the job (in this process) creates the
+       * only one, measures the device's free memory and chooses the chunk budget itself -- the HIP runtime
+       * starts once per process. */
+      use_shards = 1;
+      auto_budget = 1;
+    }
+  }
   if (!use_shards) {
     const char *dev = getenv ("GT4HIP_DEVICE");
     if (gt4hip_create (dev ? atoi (dev) : 0, &ctx)) {
@@ -400,17 +415,6 @@ int main (int argc, const char *argv[])
       gt4hip_destroy (ctx);
       ctx = NULL;
       use_shards = 1;
-    } else if (12 * in_records >= (4ull << 30) && !(getenv ("GT4HIP_PIPELINE") && !atoi (getenv ("GT4HIP_PIPELINE")))) {
-      /* big inputs that do fit: still stream them in about eight key-range chunks, so that reading the
-       * next chunk and writing the previous one overlap the merge (measured on 2 x 1e9 records in
-       * /dev/shm: -i 2.9 -> 1.7 s, -u -i -d 5.6 -> 3.7 s); GT4HIP_PIPELINE=0 keeps the one-shot path */
-      hbm_limit = need / 8;
-      if (hbm_limit < (1ull << 30)) hbm_limit = 1ull << 30;
-      if (free_b && hbm_limit > free_b / 10 * 7) hbm_limit = free_b / 10 * 7;
-      if (verbose) fprintf (stderr, "Inputs of %llu bytes: streaming in key-range chunks of about %llu device bytes\n", 12ull * in_records, (unsigned long long) hbm_limit);
-      gt4hip_destroy (ctx);
-      ctx = NULL;
-      use_shards = 1;
     }
   }
   if (use_shards) {
@@ -421,6 +425,7 @@ int main (int argc, const char *argv[])
     job.word_length = wlen;
     job.n_ranks = n_gpus >= 1 ? n_gpus : 1;
     job.hbm_limit = hbm_limit;
+    job.auto_budget = auto_budget;
     job.gather_rccl = getenv ("GT4HIP_GATHER") && !strcmp (getenv ("GT4HIP_GATHER"), "rccl");
     job.debug = verbose;
     job.prm.rule = rule;

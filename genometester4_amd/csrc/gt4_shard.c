@@ -428,6 +428,19 @@ static int worker_main (const GT4ShardJob *job, Shared *sh, int rank)
       const int n_dev = gt4hip_device_count ();
       const int sharing = n_dev > 0 ? (G + n_dev - 1) / n_dev : G;
       limit = free_b / 10 * 7 / (uint64_t) (sharing > 0 ? sharing : 1);
+      if (job->auto_budget) {
+        /* inputs that fit the device, cut into chunks only to overlap file reads, merges and file writes:
+         * about an eighth of (inputs + worst-case outputs) in flight -- counting runs get many small chunks
+         * (the reads pace them), record-writing runs few large ones (measured on 2 x 2e9 records in tmpfs,
+         * profiles/round3/r3_cli_e2e_2x2e9_with_reference.log and round4) -- never more than the 70 % above */
+        uint64_t in_records = 0;
+        for (unsigned int f = 0; f < job->n_files; f++) in_records += job->files[f].header.n_words;
+        const uint64_t need = 12 * in_records * (job->mode == GT4_SHARD_PAIR ? 1 + (uint64_t) n_streams (job) : 4);
+        uint64_t want = need / 8;
+        if (want < (1ull << 30)) want = 1ull << 30;
+        if (want < limit) limit = want;
+        if (job->debug) fprintf (errf, "Inputs of %llu bytes: streaming in key-range chunks of about %llu device bytes\n", 12ull * (unsigned long long) in_records, (unsigned long long) limit);
+      }
     }
     sh->limits[rank] = limit ? limit : (1ull << 30);
   }

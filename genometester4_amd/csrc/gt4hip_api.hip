@@ -181,8 +181,10 @@ extern "C" int gt4hip_get_counter (gt4hip_context *ctx, const char *name, uint64
   if (!strcmp (name, "single_pass_fallbacks")) *value = ctx->single_pass_fallbacks;
   else if (!strcmp (name, "kway_calls")) *value = ctx->kway_calls;
   else if (!strcmp (name, "kway_overflows")) *value = ctx->kway_overflows;
+  else if (!strcmp (name, "kway_declined")) *value = ctx->kway_declined;
   else if (!strcmp (name, "nway_kernel_us")) *value = (uint64_t) (ctx->nway_kernel_ms * 1000.0);
   else if (!strcmp (name, "nway_tiles")) *value = ctx->nway_tiles;
+  else if (!strcmp (name, "nway_one_pass")) *value = (uint64_t) ctx->last_multi_one_pass;
   else if (!strcmp (name, "sort_us")) *value = (uint64_t) (ctx->sort_ms * 1000.0);
   else if (!strcmp (name, "fold_us")) *value = (uint64_t) (ctx->fold_ms * 1000.0);
   else if (!strcmp (name, "table_us")) *value = (uint64_t) (ctx->table_ms * 1000.0);
@@ -916,10 +918,12 @@ extern "C" int gt4hip_union_multi (gt4hip_context *ctx, const gt4hip_list *const
   for (uint32_t j = 0; j < n_lists; j++)
     if (lists[j]->n_words) work.push_back (lists[j]); /* :525-532 empty lists are dropped */
   const uint32_t wl = lists[0]->word_length;
+  ctx->last_multi_one_pass = 0;
   if (work.empty ()) return empty_result (ctx, wl, count_only != 0, res);
   if (ctx->kway_enabled && work.size () >= (ctx->kway_enabled >= 2 ? 2u : 3u)) {
     int done = 0;
     const int krc = union_multi_kway (ctx, work, (uint32_t) rule, cutoff, ovr, count_only != 0, res, &done);
+    if (!krc && done) ctx->last_multi_one_pass = 1;
     if (krc || done) return krc;
     res->device_ms = 0;
     res->records_read = res->records_written = 0;

@@ -46,15 +46,17 @@ struct gt4hip_context {
   size_t kway_part_bytes;
   void *kway_cnt;            /* samples of every list per bracket of 64 tiles */
   size_t kway_cnt_bytes;
-  int kway_enabled;          /* option "kway": 0 = always the pairwise tree */
+  int kway_enabled;          /* option "kway": 0 = always the pairwise tree, 1 = the one-pass kernel unless the keys are clustered, 2 = always, also for two lists */
   int64_t kway_g;            /* option "kway_g": samples per tile (0 = automatic) */
   int64_t kway_vt;           /* option "kway_vt": positions per thread in a merge pass, at least (0 = default) */
   uint64_t kway_overflows;   /* calls that fell back to the tree because a tile would not fit LDS */
   uint64_t kway_calls;       /* N-way unions done by the one-pass kernel */
+  uint64_t kway_declined;    /* ... handed to the pairwise tree because the keys are clustered (option "kway" = 1) */
   double table_ms;           /* the last gt4hip_union_table, wall time of the call */
   double sort_ms, fold_ms;   /* the last gt4hip_device_words_to_list: radix sort and fold (HIP events) */
   double nway_kernel_ms;     /* the last one-pass launch's kernel time (HIP events on the library's stream) and tiles */
   uint64_t nway_tiles;
+  int last_multi_one_pass;   /* the last gt4hip_union_multi was done by the one-pass tile kernel (counter "nway_one_pass") */
   gt4hip_io *io;            /* file <-> HBM staging (gt4hip_io.hip), NULL until first used */
   char err[512];
   char info[256];

@@ -441,6 +441,42 @@ __global__ __launch_bounds__ (64) void k_nway_partition_rows (NwayParams p, cons
   }
 }
 
+/* ---- Will the interpolation work on these keys?  A probe of the longest list in front of everything else:
+ * every workgroup takes a window of NWAY_PROBE_KEYS consecutive records -- about the key range of one tile --
+ * and counts the keys that fall into the bucket of their predecessor under the tile kernel's own bucket
+ * function over the window's key range.  Evenly spread keys share hardly any of the window's buckets (a
+ * quarter to a third of them do); stretches of adjacent keys between wide gaps put nearly all of them into a
+ * few.  flagged[0] += 1 per window in which more than 60 % do: such tiles take the pivot-run buckets or the
+ * search path (two to three times the time of a tile), and beyond a fifth of the tiles the pairwise tree of
+ * the pair kernel is the faster union (profiles/round4: 27 ms against 52 ms on clustered lists of 2.5e8). */
+constexpr u32 NWAY_PROBE_KEYS = 3072;
+constexpr u32 NWAY_PROBE_WINDOWS = 1024;
+
+__global__ __launch_bounds__ (256) void k_nway_probe (const u32 *__restrict__ list, u64 n, u32 windows, u32 n_buckets, u32 *__restrict__ flagged)
+{
+  __shared__ u32 same_s;
+  if (threadIdx.x == 0) same_s = 0;
+  __syncthreads ();
+  const u64 first = (u64) (((unsigned __int128) (n - NWAY_PROBE_KEYS) * blockIdx.x) / (windows > 1 ? windows - 1 : 1));
+  const u64 lo = load_key (list, first), hi = load_key (list, first + NWAY_PROBE_KEYS - 1);
+  const u64 D = hi - lo;
+  const u32 bl = D ? 64u - (u32) __builtin_clzll (D) : 0u;
+  const u32 sh = bl > 32u ? bl - 32u : 0u;
+  const u32 vmax = (u32) (D >> sh);
+  const bool direct = vmax < n_buckets;
+  const u32 mul = direct ? 0u : (u32) (((u64) n_buckets << 32) / ((u64) vmax + 1ull));
+  u32 same = 0;
+  for (u32 i = 1 + threadIdx.x; i < NWAY_PROBE_KEYS; i += blockDim.x) {
+    const u32 v0 = (u32) ((load_key (list, first + i - 1) - lo) >> sh), v1 = (u32) ((load_key (list, first + i) - lo) >> sh);
+    const u32 b0 = direct ? v0 : __umulhi (v0, mul), b1 = direct ? v1 : __umulhi (v1, mul);
+    same += b0 == b1 ? 1u : 0u;
+  }
+  same = dpp_wave_sum_u32 (same);
+  if ((threadIdx.x & 63) == 0) atomicAdd (&same_s, same);
+  __syncthreads ();
+  if (threadIdx.x == 0 && 10u * same_s > 6u * NWAY_PROBE_KEYS) atomicAdd (flagged, 1u);
+}
+
 /* a tile fits when its records fit the position space with every run rounded up to whole wavefronts */
 __global__ void k_nway_check (const u64 *__restrict__ part, u32 num_tiles, u32 cap, u32 *flag)
 {
@@ -454,6 +490,7 @@ __global__ void k_nway_check (const u64 *__restrict__ part, u32 num_tiles, u32 c
     slots += (b - a + WAVE - 1) / WAVE;
   }
   if (slots * WAVE > cap || !mono) atomicOr (flag, 1u);
+  if ((part[t * NWAY_PSTRIDE + NWAY_MAX + 1] >> 9) & 1ull) atomicAdd (flag + 1, 1u); /* the partition found the tile's samples clustered */
 }
 
 /* rows before every tile = exclusive prefix of the tiles' distinct keys (one workgroup walks the array) */
@@ -1427,7 +1464,32 @@ static int nway_run (gt4hip_context *ctx, const gt4hip_list *const lists[], uint
       for (int i = 0; i < NWAY_MAX; i++)
         if (lv.owned[i]) gt4hip_list_free (lv.owned[i]);
   };
-  HIPCHK (ctx, hipEventRecord (ctx->ev[0], st));
+  {
+    const hipError_t e0 = hipEventRecord (ctx->ev[0], st);
+    if (e0 != hipSuccess) return gt4hip_fail (ctx, GT4HIP_EHIP, "hipEventRecord failed: %s", hipGetErrorString (e0)); /* (nothing is owned yet) */
+  }
+  /* option "kway" = 1 (the default) lets the call decline clustered keys: *used = 0, the caller takes the tree */
+  const bool may_decline = ctx->kway_enabled == 1 && !table && ctx->kway_vt == 0;
+  if (may_decline) {
+    uint32_t longest = 0;
+    for (uint32_t i = 1; i < k; i++)
+      if (lists[i]->n_words > lists[longest]->n_words) longest = i;
+    const u64 nl = lists[longest]->n_words;
+    if (nl >= 16ull * NWAY_PROBE_KEYS) {
+      const u32 windows = (u32) (nl / (4 * NWAY_PROBE_KEYS) < NWAY_PROBE_WINDOWS ? nl / (4 * NWAY_PROBE_KEYS) : NWAY_PROBE_WINDOWS);
+      hipError_t e = hipMemsetAsync (ctx->scratch, 0, 64, st);
+      if (e == hipSuccess) {
+        hipLaunchKernelGGL (k_nway_probe, dim3 (windows), dim3 (256), 0, st, (const u32 *) lists[longest]->dev, nl, windows, (u32) (NWAY_NBF * NWAY_CAP), (u32 *) ctx->scratch);
+        e = hipMemcpyAsync (ctx->scratch_host, ctx->scratch, 8, hipMemcpyDeviceToHost, st);
+      }
+      if (e == hipSuccess) e = hipStreamSynchronize (st);
+      if (e != hipSuccess) return gt4hip_fail (ctx, GT4HIP_EHIP, "N-way key probe failed: %s", hipGetErrorString (e));
+      if (5ull * (u32) ctx->scratch_host[0] > windows) {
+        ctx->kway_declined++;
+        return GT4HIP_OK; /* *used = 0 */
+      }
+    }
+  }
   /* sample levels until one fits a single tile */
   const u64 one_tile = (u64) NWAY_CAP - 64ull * k;
   while (levels.back ().total > one_tile) {
@@ -1495,7 +1557,16 @@ static int nway_run (gt4hip_context *ctx, const gt4hip_list *const lists[], uint
         rc = gt4hip_fail (ctx, GT4HIP_EHIP, "N-way partition failed: %s", hipGetErrorString (e));
         break;
       }
-      if (!(ctx->scratch_host[0] & 0xffffffffu)) break;
+      if (!(ctx->scratch_host[0] & 0xffffffffu)) {
+        if (l == 0 && may_decline && tiles >= 64 && 5ull * (ctx->scratch_host[0] >> 32) > tiles) {
+          /* the probe of the longest list did not see it, the tiles' own samples do: clustered keys */
+          ctx->kway_declined++;
+          if (merged) gt4hip_list_free (merged);
+          cleanup ();
+          return GT4HIP_OK; /* *used = 0 */
+        }
+        break;
+      }
       /* a tile would overflow LDS: fewer samples per tile, down to the number that cannot overflow */
       ctx->kway_overflows++;
       if (G <= g_sure) {
@@ -1557,7 +1628,11 @@ static int nway_run (gt4hip_context *ctx, const gt4hip_list *const lists[], uint
     }
     if (l == 0) hipEventRecord (ctx->ev[2], st);
     /* every level reads its control block back: a refused tile or a wait that gave up must not go unseen */
-    if (l == 0) HIPCHK (ctx, hipEventRecord (ctx->ev[3], st));
+    e = l == 0 ? hipEventRecord (ctx->ev[3], st) : hipSuccess;
+    if (e != hipSuccess) {
+      rc = gt4hip_fail (ctx, GT4HIP_EHIP, "hipEventRecord failed: %s", hipGetErrorString (e));
+      break;
+    }
     e = hipMemcpyAsync (ctx->ctl_host, ctx->ctl, sizeof (PairControl), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize (st);
     if (e != hipSuccess) {

@@ -141,7 +141,7 @@ __global__ __launch_bounds__ (RADIX_MAX_DIGITS) void k_radix_bases (u64 *__restr
  *   5. the tile leaves LDS in digit order: runs of one digit go to consecutive addresses. */
 template <int B>
 __global__ __launch_bounds__ (RADIX_NT, GT4_RADIX_WAVES) void k_radix_scatter (const u64 *__restrict__ in, u64 *__restrict__ out, u64 n, u32 pass, u32 shift, const u64 *__restrict__ gbase,
-                                                                              u64 *__restrict__ state, u32 *__restrict__ ticket)
+                                                                              u64 *__restrict__ state, u32 *__restrict__ ticket, u32 *__restrict__ err, u32 spin_limit)
 {
   constexpr int ND = 1 << B, NDW = ND / WAVE; /* digits; wavefronts that own one digit per lane */
   static_assert (ND <= RADIX_NT && ND <= RADIX_MAX_DIGITS && RADIX_TILE <= 65535, "a digit per thread; 16-bit places");
@@ -244,7 +244,18 @@ __global__ __launch_bounds__ (RADIX_NT, GT4_RADIX_WAVES) void k_radix_scatter (c
 #pragma unroll
         for (int i = 0; i < RADIX_LOOK; i++) {
           if (done) continue;
-          while (!ready (v[i])) v[i] = __hip_atomic_load (&state[(j - 1 - i) * ND + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          /* bounded: a predecessor that never publishes (a fault, a device shared with a stuck process) must
+           * not hang the sort.  The wait that gives up raises *err (the host returns GT4HIP_EHIP; the output
+           * is garbage) and goes on as if it had met a PREFIX, so its own PREFIX lets the successors drain;
+           * every other wait notices the flag at its next look. */
+          for (u32 spins = 0; !ready (v[i]);) {
+            if (++spins >= spin_limit || ((spins & 255u) == 0 && peek_u32 (err))) {
+              atomicOr (err, 1u);
+              v[i] = RADIX_PREFIX | radix_tag (pass);
+              break;
+            }
+            v[i] = __hip_atomic_load (&state[(j - 1 - i) * ND + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
           excl += v[i] & RADIX_VALUE;
           done = (v[i] & RADIX_PREFIX) != 0;
         }
@@ -303,7 +314,7 @@ __device__ __forceinline__ u32 fold_heads (const u64 *__restrict__ w, u64 n, u64
 /* Pass 1: runs that start in each tile -> the number of runs before the tile (chained scan over one
  * state word per tile: a whole wavefront looks back, 64 tiles per round trip); tiles by ticket. */
 __global__ __launch_bounds__ (FOLD_NT) void k_fold_count (const u64 *__restrict__ w, u64 n, u64 *__restrict__ state, u64 *__restrict__ tile_excl, u64 tiles, u32 *__restrict__ ticket,
-                                                        u64 *__restrict__ total)
+                                                        u64 *__restrict__ total, u32 *__restrict__ err, u32 spin_limit)
 {
   __shared__ u32 ws[FOLD_NW];
   __shared__ u32 tile_s;
@@ -327,8 +338,13 @@ __global__ __launch_bounds__ (FOLD_NT) void k_fold_count (const u64 *__restrict_
     const bool in = j >= (u64) (1 + lane);
     u64 v;
     u64 pm, need; /* lanes whose tile's state is a PREFIX; lanes up to the nearest of them */
+    u32 spins = 0; /* bounded as the scatter kernel's waits are: *err, then on as if a PREFIX had been met */
     do {
       v = in ? __hip_atomic_load (&state[j - 1 - lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : RADIX_PREFIX;
+      if (++spins >= spin_limit || ((spins & 255u) == 0 && peek_u32 (err))) { /* uniform */
+        if (lane == 0) atomicOr (err, 1u);
+        v = RADIX_PREFIX;
+      }
       pm = __builtin_amdgcn_ballot_w64 ((v & RADIX_PREFIX) != 0);
       need = pm ? (2ull << __builtin_ctzll (pm)) - 1ull : ~0ull;
     } while (__builtin_amdgcn_ballot_w64 ((v >> 62) == 0) & need);
@@ -456,6 +472,8 @@ static int radix_sort_device (gt4hip_context *ctx, u64 *words, u64 *tmp, uint64_
     return gt4hip_fail (ctx, GT4HIP_ENOMEM, "gt4hip_sort_words: workspace of %llu bytes", (unsigned long long) (head + state_bytes));
   u64 *ghist = (u64 *) ws;
   u32 *tickets = (u32 *) (ws + (size_t) RADIX_MAX_PASSES * RADIX_MAX_DIGITS * 8);
+  u32 *err = tickets + 15; /* (the 64 bytes behind the digit bases: a ticket per pass, then the error word) */
+  const u32 spin_limit = ctx->spin_limit ? ctx->spin_limit : SPIN_LIMIT;
   u64 *state = (u64 *) (ws + head);
   hipStream_t st = ctx->stream;
   hipError_t e = hipMemsetAsync (ws, 0, head + state_bytes, st);
@@ -465,16 +483,18 @@ static int radix_sort_device (gt4hip_context *ctx, u64 *words, u64 *tmp, uint64_
   hipLaunchKernelGGL (k_radix_bases, dim3 (passes), dim3 (RADIX_MAX_DIGITS), 0, st, ghist);
   u64 *src = words, *dst = tmp;
   for (uint32_t p = 0; p < passes; p++) {
-    if (plan.bits[p] == 9) hipLaunchKernelGGL (k_radix_scatter<9>, dim3 ((unsigned) tiles), dim3 (RADIX_NT), 0, st, src, dst, n, p, plan.shift[p], ghist, state, tickets + p);
-    else hipLaunchKernelGGL (k_radix_scatter<8>, dim3 ((unsigned) tiles), dim3 (RADIX_NT), 0, st, src, dst, n, p, plan.shift[p], ghist, state, tickets + p);
+    if (plan.bits[p] == 9) hipLaunchKernelGGL (k_radix_scatter<9>, dim3 ((unsigned) tiles), dim3 (RADIX_NT), 0, st, src, dst, n, p, plan.shift[p], ghist, state, tickets + p, err, spin_limit);
+    else hipLaunchKernelGGL (k_radix_scatter<8>, dim3 ((unsigned) tiles), dim3 (RADIX_NT), 0, st, src, dst, n, p, plan.shift[p], ghist, state, tickets + p, err, spin_limit);
     u64 *const t = src;
     src = dst;
     dst = t;
   }
   if (e == hipSuccess) e = hipGetLastError ();
+  if (e == hipSuccess) e = hipMemcpyAsync (ctx->scratch_host, err, 4, hipMemcpyDeviceToHost, st);
   if (e == hipSuccess) e = hipStreamSynchronize (st);
   gt4hip_block_free (ws_owner);
   if (e != hipSuccess) return gt4hip_fail (ctx, GT4HIP_EHIP, "gt4hip_sort_words: %s", hipGetErrorString (e));
+  if ((u32) ctx->scratch_host[0]) return gt4hip_fail (ctx, GT4HIP_EHIP, "gt4hip_sort_words: a chained-scan wait gave up (device shared with a stuck workgroup?)");
   *result = src;
   return GT4HIP_OK;
 }
@@ -514,10 +534,13 @@ static int fold_sorted_words (gt4hip_context *ctx, const u64 *words, uint64_t n_
   if (gt4hip_block_alloc (ctx, bytes, (void **) &ws, &ws_owner)) return gt4hip_fail (ctx, GT4HIP_ENOMEM, "gt4hip_words_to_list: workspace");
   u64 *state = (u64 *) (ws + 64), *tile_excl = state + tiles;
   e = hipMemsetAsync (ws, 0, 64 + (size_t) tiles * 8, st);
-  hipLaunchKernelGGL (k_fold_count, dim3 ((unsigned) tiles), dim3 (FOLD_NT), 0, st, words, n_words, state, tile_excl, tiles, (u32 *) ws, ctx->scratch);
+  hipLaunchKernelGGL (k_fold_count, dim3 ((unsigned) tiles), dim3 (FOLD_NT), 0, st, words, n_words, state, tile_excl, tiles, (u32 *) ws, ctx->scratch, (u32 *) ws + 15,
+                      ctx->spin_limit ? ctx->spin_limit : SPIN_LIMIT);
   if (e == hipSuccess) e = hipMemcpyAsync (ctx->scratch_host, ctx->scratch, 8, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipMemcpyAsync (ctx->scratch_host + 1, (u32 *) ws + 15, 4, hipMemcpyDeviceToHost, st);
   if (e == hipSuccess) e = hipStreamSynchronize (st);
   if (e != hipSuccess) rc = gt4hip_fail (ctx, GT4HIP_EHIP, "gt4hip_words_to_list: %s", hipGetErrorString (e));
+  else if ((u32) ctx->scratch_host[1]) rc = gt4hip_fail (ctx, GT4HIP_EHIP, "gt4hip_words_to_list: a chained-scan wait gave up (device shared with a stuck workgroup?)");
   if (!rc) {
     const uint64_t n_heads = ctx->scratch_host[0];
     rc = gt4hip_list_new (ctx, n_heads, word_length, &l);

@@ -264,7 +264,10 @@ int gt4hip_comm_gatherv (gt4hip_comm *comm, const gt4hip_list *local, const uint
 /* Sorts n_words packed 64-bit k-mer words (device memory) ascending, in place: the reference's
  * wordtable_sort (src/word-table.c:217-231; hybridInPlaceRadixSort256, src/utils.c:127-198) as an LSD
  * radix sort over the 2 * word_length significant bits (8- and 9-bit digits; one histogram kernel, then one
- * chained-scan scatter kernel per digit).  Needs n_words * 8 bytes of scratch + 2 KB per 8192 words. */
+ * chained-scan scatter kernel per digit).  Needs n_words * 8 bytes of scratch + 4 KB of scan state per
+ * 8192 words (0.5 GB per 10^9 words).  n_words < 2^56 and fewer than 2^32 tiles of 8192 words (n_words <
+ * 2^45); more is GT4HIP_EINVAL.  The scans' waits are bounded (option "spin_limit"): one that gives up
+ * -- a device shared with a stuck process -- makes the call return GT4HIP_EHIP. */
 int gt4hip_sort_words (gt4hip_context *ctx, void *device_words, uint64_t n_words, uint32_t word_length);
 /* Sort + wordtable_find_frequencies (src/word-table.c:233-260): host words (any order, repeats
  * allowed) -> a new list of (word, number of occurrences) records, ascending -- what glistmaker writes
@@ -301,8 +304,11 @@ int gt4hip_synchronize (gt4hip_context *ctx);
  *                      allocation that fails gives the pooled blocks back and retries
  *   "grid" = n         workgroups of the merge kernel (0: one per resident slot)
  *   "kway" = 0 / 1 / 2 N-way unions of three and more lists by the pairwise tree of the pair kernel / by
- *                      the one-pass tile kernel (gt4hip_nway.hip; the default) / two-list unions of the
- *                      N-way entry points by the tile kernel too; count tables follow the same switch.
+ *                      the one-pass tile kernel (gt4hip_nway.hip) unless a probe of the keys or the tiles' own
+ *                      samples show them clustered -- stretches of adjacent keys between wide gaps, which the
+ *                      tile kernel orders two to three times slower: the tree is faster then (the default;
+ *                      counter "kway_declined") / always by the tile kernel, two-list unions of the N-way
+ *                      entry points too; count tables follow the same switch (and are never declined).
  *                      "kway_g": samples per tile of its first partition attempt; "kway_vt" (tests):
  *                      97 tile boundaries by searches over whole brackets, 98 every tile bucketed by
  *                      its pivot run, 99 every tile on the search path
@@ -314,9 +320,11 @@ int gt4hip_synchronize (gt4hip_context *ctx);
 int gt4hip_set_option (gt4hip_context *ctx, const char *name, int64_t value);
 /* Diagnostic counters of a context.  "single_pass_fallbacks": calls whose single-pass merge gave up a
  * bounded wait (a worker not resident: shared device) and were rerun on the two-pass path;
+ * "kway_declined": N-way unions handed to the pairwise tree because their keys are clustered;
  * "kway_calls" / "kway_overflows": N-way unions (and count tables) done by the one-pass tile kernel /
  * partitions repeated with fewer samples per tile because a tile would not have fit LDS;
- * "nway_kernel_us", "nway_tiles": the last N-way call's tile kernel; "sort_us", "fold_us", "table_us":
+ * "nway_kernel_us", "nway_tiles": the last N-way call's tile kernel; "nway_one_pass": 1 when the last
+ * gt4hip_union_multi took the one-pass tile kernel, 0 when it took the pairwise tree; "sort_us", "fold_us", "table_us":
  * the last gt4hip_device_words_to_list / gt4hip_union_table call. */
 int gt4hip_get_counter (gt4hip_context *ctx, const char *name, uint64_t *value);
 

@@ -50,23 +50,58 @@ def _bench(n_ranks, args, env_extra=None):
     return json.loads(lines[0])
 
 
-SMALL_PAIR = ["--workload", "intersect", "--entries", "6000000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+SMALL_PAIR = ["--workload", "intersect", "--entries", "6000000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-union8"]
+SMALL_BOTH = ["--entries", "6000000", "--entries8", "1500000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
 SMALL_UNION = ["--workload", "union8", "--entries8", "1500000", "--steps", "2", "--warmup", "1"]
 
 
-def test_strong_scaling_line_equals_the_default_line_on_one_gpu():
+def test_weak_scaling_line_equals_the_default_line_on_one_gpu():
     one = _bench(1, SMALL_PAIR)
-    strong = _bench(1, SMALL_PAIR + ["--scaling", "strong"])
-    assert strong["config"]["output_records"] == one["config"]["output_records"]
-    assert strong["config"]["output_total_count"] == one["config"]["output_total_count"]
-    assert strong["metric"] == one["metric"] and strong["n_gpus"] == 1
+    assert one["scaling"] == "strong" and one["self_check"] == "ok"  # the default: the job of BASELINE's metric
+    weak = _bench(1, SMALL_PAIR + ["--scaling", "weak"])
+    assert weak["config"]["output_records"] == one["config"]["output_records"]
+    assert weak["config"]["output_total_count"] == one["config"]["output_total_count"]
+    assert weak["metric"] == one["metric"] and weak["n_gpus"] == 1
+
+
+def test_default_line_carries_the_union8_record_and_checks_itself():
+    """what the driver runs: no workload flags -> the intersection line with the 8-way union embedded, both
+    checked against the generator's closed forms (|A n B| = n / 2, 5 n distinct keys)"""
+    r = _bench(1, SMALL_BOTH)
+    assert r["self_check"] == "ok" and r["config"]["output_records"]["intrsec"] == 3000000
+    u = r["union8"]
+    assert u["self_check"] == "ok" and u["output_records"] == 5 * 1500000
+    assert u["value_with_gather"] > 0 and u["merge_only"] > 0 and u["gathered_bytes"] == 0
+    alone = _bench(1, SMALL_UNION)
+    assert (alone["config"]["output_records"], alone["config"]["output_total_count"]) == (u["output_records"], u["output_total_count"])
+
+
+def test_two_ranks_on_one_device_default_line():
+    """the driver's N > 1 command with both ranks on device 0 (gloo; no RCCL gather there): strong scaling by
+    default, union8 embedded, the totals those of one GPU"""
+    one = _bench(1, SMALL_BOTH)
+    two = _bench(2, SMALL_BOTH, {"GT4_BENCH_ONE_DEVICE": "1"})
+    assert two["scaling"] == "strong" and two["n_gpus"] == 2 and two["self_check"] == "ok"
+    assert two["config"]["output_records"] == one["config"]["output_records"]["intrsec"]
+    assert two["union8"]["self_check"] == "ok"
+    assert (two["union8"]["output_records"], two["union8"]["output_total_count"]) == (one["union8"]["output_records"], one["union8"]["output_total_count"])
+    assert sum(r["shard_input_records"] for r in two["union8"]["per_rank"]) == 8 * 1500000
+
+
+def test_self_check_failure_exits_non_zero():
+    """a line whose totals contradict the generator's closed form must not exit 0 (GT4_BENCH_BREAK_CHECK: test hook)"""
+    env = dict(os.environ, GT4_BENCH_BREAK_CHECK="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + SMALL_PAIR, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 3, (p.returncode, p.stderr[-1000:])
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][0]
+    assert json.loads(line)["self_check"].startswith("FAILED")
 
 
 def test_two_ranks_on_one_device_strong_scaling_control_flow():
     """both ranks on device 0, reductions over gloo: the sharding arithmetic, the per-step totals
     exchange and the report, without RCCL"""
     one = _bench(1, SMALL_PAIR)
-    two = _bench(2, SMALL_PAIR + ["--scaling", "strong"], {"GT4_BENCH_ONE_DEVICE": "1"})
+    two = _bench(2, SMALL_PAIR, {"GT4_BENCH_ONE_DEVICE": "1"})
     assert two["scaling"] == "strong" and two["n_gpus"] == 2
     assert two["config"]["output_records"] == one["config"]["output_records"]["intrsec"]
     assert two["config"]["output_total_count"] == one["config"]["output_total_count"]["intrsec"]
@@ -77,7 +112,8 @@ def test_two_ranks_on_one_device_strong_scaling_control_flow():
 @pytest.mark.skipif("_n_devices() < 2", reason="needs two GPUs")
 def test_two_gpus_strong_scaling_intersection_over_rccl():
     one = _bench(1, SMALL_PAIR)
-    two = _bench(2, SMALL_PAIR + ["--scaling", "strong"])
+    two = _bench(2, SMALL_PAIR)
+    assert two["scaling"] == "strong" and two["self_check"] == "ok"
     assert two["config"]["output_records"] == one["config"]["output_records"]["intrsec"]
     assert two["config"]["output_total_count"] == one["config"]["output_total_count"]["intrsec"]
     assert sum(r["shard_input_records"] for r in two["config"]["per_rank"]) == 2 * 6000000
@@ -89,5 +125,13 @@ def test_two_gpus_eight_way_union_with_rccl_gatherv():
     two = _bench(2, SMALL_UNION)
     assert two["config"]["output_records"] == one["config"]["output_records"]
     assert two["config"]["output_total_count"] == one["config"]["output_total_count"]
-    assert two["config"]["gathered_bytes_per_step"] > 0
+    assert two["config"]["gathered_bytes_per_step"] > 0 and two["self_check"] == "ok"
     assert sum(r["shard_input_records"] for r in two["config"]["per_rank"]) == 8 * 1500000
+
+
+@pytest.mark.skipif("_n_devices() < 2", reason="needs two GPUs")
+def test_two_gpus_default_line_over_rccl():
+    one = _bench(1, SMALL_BOTH)
+    two = _bench(2, SMALL_BOTH)
+    assert two["self_check"] == "ok" and two["union8"]["self_check"] == "ok" and two["union8"]["gathered_bytes"] > 0
+    assert (two["union8"]["output_records"], two["union8"]["output_total_count"]) == (one["union8"]["output_records"], one["union8"]["output_total_count"])
