@@ -75,8 +75,10 @@ def self_check(kind, dist, n, k, n_words, total_count):
         n_words += 1
     if kind == "intersect" and n_words != n // 2:
         return "intersection holds %d records, generator says %d" % (n_words, n // 2)
-    if kind == "union8" and n_words != 5 * n:
-        return "union holds %d records, generator says %d" % (n_words, 5 * n)
+    if kind in ("union8", "union32") and n_words != (MULTI[kind]["lists"] // 2 + 1) * n:
+        return "union holds %d records, generator says %d" % (n_words, (MULTI[kind]["lists"] // 2 + 1) * n)
+    if kind == "intersect8" and n_words != n // 2:
+        return "intersection holds %d records, generator says %d" % (n_words, n // 2)
     exp = EXPECTED_TOTALS.get((kind, dist, n, k))
     if exp and (n_words, total_count) != exp:
         return "%s totals (%d, %d) differ from the committed N=1 totals %s" % (kind, n_words, total_count, exp)
@@ -182,25 +184,38 @@ def load_traffic(workload, n):
     return None, None
 
 
-def union8_roofline(ctx, n_list, n_out_local, device_ms, kernel_ms, workload_n):
-    """Rank 0's shard: algorithmic bytes (every input record read once, every output record written
-    once) against the average launch duration of the one-pass N-way tile kernel (HIP events on the
-    library's stream), and the bytes the whole call moved (records counted by the library)."""
+MULTI = {
+    # kind: lists, default entries per list, operation
+    "union8": dict(lists=8, op="union", what="8-way k=%d union (MakeUnion.pl replacement)", ref="scripts/MakeUnion.pl:31-95, src/glistcompare.c:545-591"),
+    "union32": dict(lists=32, op="union", what="32-way k=%d union (glistmaker's collation width, gt4_write_union)", ref="src/glistmaker.c:787-835, src/set-operations.c:40-129"),
+    "intersect8": dict(lists=8, op="intersect", what="8-way k=%d intersection (MakeIntersection.pl replacement)", ref="scripts/MakeIntersection.pl, src/glistcompare.c:605-717"),
+}
+
+
+def multi_roofline(ctx, kind, n_in_local, n_out_local, device_ms, kernel_ms, one_pass, workload_n):
+    """Rank 0's shard: algorithmic bytes (every input record read once, every output record written once).
+    `frac` is over the average launch of the dominant kernel where ONE kernel does the work (the one-pass N-way
+    tile kernel, HIP events on the library's stream); `whole_call_frac` over the whole call on the device (key
+    samples, their merges, tile partition, every launch) -- the only figure where the work is a chain or a tree
+    of pair-kernel launches, and then `frac` equals it."""
     rd, wr = ctx.last_multi_records
-    alg = 12 * (8 * n_list + n_out_local)  # n_list: this shard's records per list (average)
-    one_pass = kernel_ms > 0
-    t_ms = kernel_ms if one_pass else device_ms
+    alg = 12 * (n_in_local + n_out_local)
+    t_ms = kernel_ms if one_pass and kernel_ms > 0 else device_ms
     achieved = alg / (t_ms * 1e-3) / 1e9
-    traffic, traffic_source = load_traffic("union8", workload_n)
-    return {"bound": "hbm",
-            "kernel": "k_nway_merge<1024, 4, 1, NWAY_UNION> (one pass over eight lists)" if one_pass
-                      else "k_pair_merge<1024, 4, 1, 1> (3-level pairwise union tree, 7 launches)",
+    traffic, traffic_source = load_traffic(kind, workload_n)
+    if one_pass:
+        kernel = "k_nway_merge<1024, 4, 1, NWAY_UNION> (one pass over up to eight lists per launch)"
+    elif MULTI[kind]["op"] == "intersect":
+        kernel = "k_pair_merge<1024, 6, MODE_LOOKBACK, intersection> (left-to-right chain, one launch per list after the first)"
+    else:
+        kernel = "k_pair_merge<1024, 4, 1, 1> (pairwise union tree)"
+    return {"bound": "hbm", "kernel": kernel,
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "frac_definition": "algorithmic bytes / average launch of the tile kernel" if one_pass and kernel_ms > 0 else "algorithmic bytes / device time of the whole call",
             "traffic": traffic if traffic is not None else 12 * (rd + wr), "traffic_source": traffic_source,
             "algorithmic_bytes_per_launch": alg, "kernel_ms_avg": t_ms, "device_ms_avg": device_ms,
             "whole_call_frac": alg / (device_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "note": "per shard (rank 0); device_ms_avg = the whole union call on the device (key samples, their merges, "
-                    "tile partition, tile kernel); without committed PMC passes traffic = 12 x the records the library read and wrote"}
+            "note": "per shard (rank 0); device_ms_avg = the whole call on the device; without committed PMC passes traffic = 12 x the records the library read and wrote (intermediate levels included)"}
 
 
 def _xdev():
@@ -209,22 +224,85 @@ def _xdev():
     return "cuda" if (not dist.is_initialized() or dist.get_backend() == "nccl") else "cpu"
 
 
-def bench_union8(args, ctx, capi, rank, local_rank, world):
-    """BASELINE configs[3]: 8-way union (MakeUnion.pl replacement, reference scripts/MakeUnion.pl:31-95) of eight
-    lists -- ONE job, sharded by key range over the ranks (strong scaling): every rank keeps its key range of every
-    list resident in HBM, unions its eight shards in one pass of the N-way tile kernel (or whatever the library
-    chooses for the lists), the header totals are all-gathered and the payload is gathered on rank 0 over RCCL
-    (gt4hip_comm_gatherv of the C ABI: grouped ncclSend / ncclRecv -- the entry point the C command-line tool
-    uses).  Rank 0 merges straight into the gathered list (its range is the first extent).  `--tree` takes the
-    pairwise tree of the pair kernel.  Returns the result line (rank 0) or None."""
+def multi_cpu_leg(args, ctx, capi, kind, full):
+    """The reference on a key window of all the lists (files in tmpfs): `glistcompare L1 .. LN -u / -i --count_only`
+    (union_multi / intersect_multi, src/glistcompare.c:500-717) -- for union32 `ref_setops write_union` (the reference's
+    set-operations.c:40-129 behind this repo's driver) -- or, where the binaries are absent, the oracle's loop.
+    The GPU's totals on the same window must agree."""
+    from genometester4_amd.listio import write_list
+    spec = MULTI[kind]
+    m = min(full[0].n_words, max(1000, args.cpu_sample // (4 * spec["lists"])))
+    last_key, _ = full[0].get_word(m - 1)
+    cuts = [l.lower_bound(last_key + 1) for l in full]
+    host = [l.download_range(0, c) for l, c in zip(full, cuts)]
+    n_rec = sum(len(h) for h in host)
+    dev = [ctx.upload(h, args.k) for h in host]
+    fn = ctx.union_multi if spec["op"] == "union" else ctx.intersect_multi
+    rc_g, n_g, t_g, _ = fn(dev, count_only=True)
+    for d in dev:
+        d.free()
+    sample = "first %d records of list 0 and the same key range of the other %d lists (%d records)" % (m, spec["lists"] - 1, n_rec)
+    ref_cmp = os.path.join(ROOT, "oracle", "_ref", "glistcompare")
+    ref_set = os.path.join(ROOT, "oracle", "_ref", "ref_setops")
+    exe = ref_set if kind == "union32" else ref_cmp
+    if os.path.exists(exe) and os.access(exe, os.X_OK):
+        shm = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 40 * n_rec else None
+        d = tempfile.mkdtemp(prefix="gt4bench_", dir=shm)
+        try:
+            names = []
+            for j, h in enumerate(host):
+                names.append("l%d.list" % j)
+                write_list(os.path.join(d, names[-1]), h, args.k)
+            if kind == "union32":
+                cmd = [exe, "write_union", "1", "out.list"] + names
+            else:
+                cmd = [exe] + names + ["-u" if spec["op"] == "union" else "-i", "--count_only"]
+            times = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                r = subprocess.run(cmd, cwd=d, capture_output=True)
+                times.append(time.perf_counter() - t0)
+                if r.returncode != 0:
+                    raise RuntimeError("reference run failed: %s" % r.stderr.decode()[-300:])
+            ref_tot = _parse_count_only(r.stdout.decode())
+            ok = bool(rc_g == 0 and ref_tot and ref_tot[0] == (n_g, t_g))
+            return ({"value": n_rec / statistics.median(times), "unit": "k-mers/s", "cores": 1 if kind == "union32" else 1 + spec["lists"], "host_nproc": os.cpu_count(), "kind": "reference",
+                     "sample": sample + "; " + " ".join(cmd[:2] if kind == "union32" else [os.path.basename(exe), "L1 .. L%d" % spec["lists"]] + cmd[-2:])
+                               + ", files in %s, warm page cache, median of 3 runs; %s" % ("tmpfs" if shm else "the temp dir", "one thread (no scouts)" if kind == "union32" else "one merge thread + one scout thread per list"),
+                     "stdout": r.stdout.decode().strip().replace("\n", " ").replace("\t", "=")}, ok)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    t0c = time.perf_counter()
+    rc_o, n_o, t_o, _ = (O.union_multi if spec["op"] == "union" else O.intersect_multi)(host, 1, 0, 1)
+    dtc = time.perf_counter() - t0c
+    return ({"value": n_rec / dtc, "unit": "k-mers/s", "cores": 1, "host_nproc": os.cpu_count(), "kind": "port",
+             "sample": sample + "; oracle/gt4_oracle.c %s_multi, one thread" % spec["op"]}, bool(rc_o == 0 and rc_g == 0 and (n_g, t_g) == (n_o, t_o)))
+
+
+def bench_multi(args, ctx, capi, rank, local_rank, world, kind="union8"):
+    """The multi-list workloads, each ONE job sharded by key range over the ranks (strong scaling): every rank keeps
+    its key range of every list resident in HBM and runs the operation on its shards, the header totals are
+    all-gathered and the payload is gathered on rank 0 over RCCL (gt4hip_comm_gatherv of the C ABI: grouped ncclSend
+    / ncclRecv -- the entry point the C command-line tool uses); rank 0 merges straight into the gathered list (its
+    range is the first extent).
+      union8      BASELINE configs[3]: eight lists (MakeUnion.pl replacement, reference scripts/MakeUnion.pl:31-95), one
+                  pass of the N-way tile kernel -- or the pairwise tree where the library finds the keys clustered (`--tree`
+                  forces it)
+      union32     glistmaker's collation width (src/glistmaker.c:787-835): four eight-way passes, then a four-way one
+      intersect8  MakeIntersection.pl's job (src/glistcompare.c:605-717): the left-to-right chain of pair intersections
+    Returns the result line (rank 0) or None."""
     import torch
     import torch.distributed as dist
     from genometester4_amd import distributed as D
     from genometester4_amd import synth
-    n8 = args.n8
+    spec = MULTI[kind]
+    n_lists = spec["lists"]
+    n8 = {"union8": args.n8, "union32": args.n32, "intersect8": args.n8}[kind]
     if args.tree:
         ctx.set_option("kway", 0)
-    full = synth.make_lists8(ctx, n8, args.k, args.dist)
+    full = synth.make_lists8(ctx, n8, args.k, args.dist, n_lists) if spec["op"] == "union" else synth.make_lists_shared(ctx, n8, args.k, args.dist, n_lists)
     n_in = sum(l.n_words for l in full)
     comm_id = None
     if world > 1 and _xdev() == "cuda":
@@ -234,11 +312,13 @@ def bench_union8(args, ctx, capi, rank, local_rank, world):
     sh = D.DeviceShards(ctx, rank, world, comm_id)
     shards = [sh.shard_of(l, args.k) for l in full]
     n_local_in = sum(s.n_words for s in shards)
-    # rank 0 of a sharded job unions into the list the payload is gathered in: its extent is the first
+    # rank 0 of a sharded job writes its result into the list the payload is gathered in: its extent is the first
     has_comm = sh.comm is not None
     root_direct = world > 1 and rank == 0 and has_comm
-    out = ctx.alloc(max(1, n_in if root_direct else n_local_in), args.k)
-    op = D.gpu_union_multi_op(ctx)
+    worst_local = n_local_in if spec["op"] == "union" else min(s.n_words for s in shards)
+    worst_job = n_in if spec["op"] == "union" else min(l.n_words for l in full)
+    out = ctx.alloc(max(1, worst_job if root_direct else worst_local), args.k)
+    op = D.gpu_union_multi_op(ctx) if spec["op"] == "union" else D.gpu_intersect_multi_op(ctx)
 
     def totals_exchange(n, total):
         return D.exchange_totals(n, total, device=_xdev())
@@ -270,10 +350,10 @@ def bench_union8(args, ctx, capi, rank, local_rank, world):
     for _ in range(args.steps):
         step(gather=False)
         dev_ms.append(ctx.last_multi_device_ms)
-        ker_ms.append(ctx.get_counter("nway_kernel_us") / 1000.0 if ctx.get_counter("kway_calls") else 0.0)
+        ker_ms.append(ctx.get_counter("nway_kernel_us") / 1000.0)
     fence()
     merge_only = time.perf_counter() - t1
-    one_pass = bool(ctx.get_counter("nway_one_pass"))
+    one_pass = spec["op"] == "union" and bool(ctx.get_counter("nway_one_pass"))
     per_rank = [{"rank": rank, "shard_input_records": n_local_in, "merge_ms": statistics.mean(x["merge"] for x in ms),
                  "exchange_and_gather_ms": statistics.mean(x["exchange_and_gather"] for x in ms)}]
     if world > 1:
@@ -285,43 +365,34 @@ def bench_union8(args, ctx, capi, rank, local_rank, world):
         per_rank = box
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.union8_no_cpu:
-        # the oracle's union_multi (reference src/glistcompare.c:545-591, one thread) on a key window of all
-        # eight lists; the GPU's totals for the same window must agree
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import oracle_lib as O
-        m = min(full[0].n_words, args.cpu_sample // 32)
-        last_key, _ = full[0].get_word(m - 1)
-        cuts = [l.lower_bound(last_key + 1) for l in full]
-        host = [l.download_range(0, c) for l, c in zip(full, cuts)]
-        t0c = time.perf_counter()
-        rc_o, n_o, t_o, _ = O.union_multi(host, 1, 0, 1)
-        dtc = time.perf_counter() - t0c
-        dev = [ctx.upload(h, args.k) for h in host]
-        rc_g, n_g, t_g, o_g = ctx.union_multi(dev)
-        cpu = ({"value": sum(len(h) for h in host) / dtc, "unit": "k-mers/s", "cores": 1, "host_nproc": os.cpu_count(), "kind": "port",
-                "sample": "oracle/gt4_oracle.c union_multi over the first %d records of list 0 and the same key range of the other seven (%d records), one thread" % (m, sum(len(h) for h in host))},
-               bool(rc_o == 0 and rc_g == 0 and (n_g, t_g) == (n_o, t_o)))
-        o_g.free()
-        for d in dev:
-            d.free()
+        try:
+            cpu = multi_cpu_leg(args, ctx, capi, kind, full)
+        except Exception as e:  # the GPU number stands on its own; say why the CPU leg is missing
+            cpu = ({"value": None, "unit": "k-mers/s", "cores": 0, "kind": "reference", "sample": "failed: %s" % e}, False)
     res = None
     if rank == 0:
+        if one_pass and n_lists <= 8:
+            path = "one pass of the N-way tile kernel"
+        elif one_pass:
+            path = "levels of eight-way passes of the N-way tile kernel"
+        else:
+            path = "left-to-right chain of pair intersections" if spec["op"] == "intersect" else "pairwise tree of the pair kernel"
         res = {
-            "metric": "k-mers merged/sec, 8-way k=%d union (MakeUnion.pl replacement), lists resident in HBM, result gathered on rank 0" % args.k,
+            "metric": "k-mers merged/sec, %s, lists resident in HBM, result gathered on rank 0" % (spec["what"] % args.k),
             "value": n_in * args.steps / elapsed, "unit": "k-mers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u64 keys + u32 counts", "data": "synthetic",
-            "config": {"workload": "8-way union, eight %d-entry k=%d lists (%s keys), ONE job key-range sharded over %d GPU(s), RCCL gatherv to rank 0" % (n8, args.k, args.dist, world),
-                       "entries_per_list": n8, "input_records": n_in, "dist": args.dist, "output_records": n_out, "output_total_count": total_out, "device": ctx.device_info(),
-                       "per_rank": per_rank, "path": "one pass of the N-way tile kernel" if one_pass else "pairwise tree of the pair kernel",
+            "config": {"workload": "%s, %d lists of %d entries (%s keys), ONE job key-range sharded over %d GPU(s), RCCL gatherv to rank 0" % (spec["what"] % args.k, n_lists, n8, args.dist, world),
+                       "reference": spec["ref"], "lists": n_lists, "entries_per_list": n8, "input_records": n_in, "dist": args.dist, "output_records": n_out, "output_total_count": total_out,
+                       "device": ctx.device_info(), "per_rank": per_rank, "path": path,
                        "merge_only_k_mers_per_s": n_in * args.steps / merge_only,
                        "merge_only_ms_per_step": merge_only / args.steps * 1e3,
                        "gathered_bytes_per_step": 12 * (n_out - totals[0][0]) if has_comm else 0,
                        "note": "value includes the RCCL gatherv of the payload to rank 0; merge_only_* is the same job with every rank keeping (or writing) its own extent: BASELINE's >= 6x at 8 GPUs refers to merge_only"},
-            "roofline": union8_roofline(ctx, n_local_in // 8, totals[0][0], statistics.mean(dev_ms), statistics.mean(ker_ms) if one_pass else 0.0, n8 if args.dist == "stride" else -1),
+            "roofline": multi_roofline(ctx, kind, n_local_in, totals[0][0], statistics.mean(dev_ms), statistics.mean(ker_ms), one_pass and n_lists <= 8, n8 if args.dist == "stride" else -1),
             **({"cpu_baseline": cpu[0], "verified": cpu[1]} if cpu else {}),
         }
-        bad = self_check("union8", args.dist, n8, args.k, n_out, total_out)
+        bad = self_check(kind, args.dist, n8, args.k, n_out, total_out)
         res["self_check"] = "ok" if bad is None else "FAILED: " + bad
     sh.close()
     out.free()
@@ -634,10 +705,12 @@ def main():
     ap.add_argument("--ns", type=int, default=1_000_000_000, help="sort: words")
     ap.add_argument("--nt", type=int, default=100_000_000, help="table: entries per list")
     ap.add_argument("--nt-lists", type=int, default=6, help="table: lists")
-    ap.add_argument("--workload", choices=["intersect", "c2", "union8", "sort", "table"], default="intersect",
+    ap.add_argument("--workload", choices=["intersect", "c2", "union8", "union32", "intersect8", "sort", "table"], default="intersect",
                     help="intersect: BASELINE configs[1] (default, the headline metric; the line also embeds a union8 record); c2: configs[2], "
                          "union + first complement with cutoff 3 on the same pair; union8: configs[3] alone, 8-way union sharded by key range "
-                         "over the ranks with an RCCL gatherv to rank 0 (strong scaling)")
+                         "over the ranks with an RCCL gatherv to rank 0 (strong scaling); union32: 32 lists (glistmaker's collation width); "
+                         "intersect8: eight lists, MakeIntersection.pl's job")
+    ap.add_argument("--n32", "--entries32", dest="n32", type=int, default=125_000_000, help="union32: entries per list (whole job)")
     ap.add_argument("--n8", "--entries8", dest="n8", type=int, default=500_000_000, help="union8: entries per list (whole job)")
     ap.add_argument("--tree", action="store_true", help="union8: the pairwise tree instead of what the library chooses")
     ap.add_argument("--dist", choices=["stride", "iid", "clustered", "genomic"], default="stride", help="key distribution of the synthetic lists (genometester4_amd/synth.py)")
@@ -671,8 +744,8 @@ def main():
     if args.two_pass:
         ctx.set_option("two_pass", 1)
     res = None
-    if args.workload == "union8":
-        res = bench_union8(args, ctx, capi, rank, local_rank, world)
+    if args.workload in MULTI:
+        res = bench_multi(args, ctx, capi, rank, local_rank, world, args.workload)
     elif args.workload == "sort":
         res = bench_sort(args, ctx, capi)
     elif args.workload == "table":
@@ -682,7 +755,7 @@ def main():
         if args.workload == "intersect" and not args.no_union8:
             # the other north-star number in the same line: the 8-way union as ONE job over the same ranks
             args.union8_no_cpu = True  # (its CPU leg belongs to --workload union8)
-            u = bench_union8(args, ctx, capi, rank, local_rank, world)
+            u = bench_multi(args, ctx, capi, rank, local_rank, world, "union8")
             if rank == 0:
                 res["union8"] = {
                     "workload": u["config"]["workload"], "n_gpus": world, "scaling": "strong",

@@ -839,7 +839,7 @@ static int union_multi_kway (gt4hip_context *ctx, const std::vector<const gt4hip
     drop ();
     return rc;
   }
-  if (cur.size () < (ctx->kway_enabled >= 2 ? 2u : 3u)) {
+  if (cur.size () < (ctx->kway_enabled == 2 ? 2u : 3u)) {
     /* (possible only behind a level of eight-way merges) the last one or two go through the pair kernel */
     gt4hip_list empty_b;
     memset (&empty_b, 0, sizeof empty_b);
@@ -920,7 +920,7 @@ extern "C" int gt4hip_union_multi (gt4hip_context *ctx, const gt4hip_list *const
   const uint32_t wl = lists[0]->word_length;
   ctx->last_multi_one_pass = 0;
   if (work.empty ()) return empty_result (ctx, wl, count_only != 0, res);
-  if (ctx->kway_enabled && work.size () >= (ctx->kway_enabled >= 2 ? 2u : 3u)) {
+  if (ctx->kway_enabled && work.size () >= (ctx->kway_enabled == 2 ? 2u : 3u)) {
     int done = 0;
     const int krc = union_multi_kway (ctx, work, (uint32_t) rule, cutoff, ovr, count_only != 0, res, &done);
     if (!krc && done) ctx->last_multi_one_pass = 1;

@@ -46,7 +46,7 @@ struct gt4hip_context {
   size_t kway_part_bytes;
   void *kway_cnt;            /* samples of every list per bracket of 64 tiles */
   size_t kway_cnt_bytes;
-  int kway_enabled;          /* option "kway": 0 = always the pairwise tree, 1 = the one-pass kernel unless the keys are clustered, 2 = always, also for two lists */
+  int kway_enabled;          /* option "kway": 0 = always the pairwise tree, 1 = the one-pass kernel unless the keys are clustered, 2 = always, also for two lists, 3 = always (three lists and more) */
   int64_t kway_g;            /* option "kway_g": samples per tile (0 = automatic) */
   int64_t kway_vt;           /* option "kway_vt": positions per thread in a merge pass, at least (0 = default) */
   uint64_t kway_overflows;   /* calls that fell back to the tree because a tile would not fit LDS */

@@ -480,7 +480,16 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
   __shared__ Shared sh;
   u32 *const lds32 = sh.raw;
 
-  const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+  /* The general any-combination kernels sit at their register bound (128 at sixteen wavefronts per CU, 85 for the
+   * count-only geometry's three workgroups): there the thread number is made opaque once per tile, so that
+   * addresses and masks derived from it are recomputed where they are used (a few VALU each) instead of living in
+   * registers across the whole loop, hoisted by the compiler -- which had two to six of them in scratch memory.
+   * tools/kernel_resources.py / tests/test_kernel_resources.py: no instantiation may spill a vector register. */
+#ifndef GT4_OPAQUE_ALL
+#define GT4_OPAQUE_ALL 0
+#endif
+  constexpr bool OPAQUE_TID = GT4_OPAQUE_ALL == 2 || (OPS == 0 && (GT4_OPAQUE_ALL == 1 || !(FAST == 1 && (OPSET == 3 || OPSET == 5) && MODE != MODE_COUNT)));
+  int tid = threadIdx.x, lane = tid & (WAVE - 1); /* (not const: OPAQUE_TID) */
   const int wid = __builtin_amdgcn_readfirstlane (tid / WAVE); /* wave-uniform: scalar branches on it */
   static_assert (OPSET == 0 || OPS == 0, "a compile-time stream set belongs to the any-combination kernel");
   const u32 ops = OPS ? (u32) OPS : (OPSET ? (u32) OPSET : p.ops);
@@ -653,6 +662,10 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
   if (MODE == MODE_COUNT && (wid == 0 || wid == 4)) __builtin_amdgcn_s_setprio (1);
 
   while (cur < ntl) {
+    if (OPAQUE_TID) {
+      asm volatile ("" : "+v"(tid));
+      lane = tid & (WAVE - 1);
+    }
     /* position space of the tile: A records at [0, na), B records from the next multiple of 64 on, so
      * that every 64-position chunk (one wavefront pass) holds records of one list only */
     const u32 na = tr.na, nb = tr.nb, nbs = (na + (u32) WAVE - 1u) & ~((u32) WAVE - 1u), npos = nbs + nb;

@@ -246,3 +246,29 @@ def make_lists8(ctx, n8, k, dist="stride", n_lists=8):
     n_odd = n_lists // 2
     member = [(0,) if j % 2 == 0 else ((j + 1) // 2,) for j in range(n_lists)]
     return _from_universe(ctx, dist, n8 * (n_odd + 1), k, n_odd + 1, member, 4242)
+
+
+def make_lists_shared(ctx, n, k, dist="stride", n_lists=8):
+    """The N-way intersection bench's lists: every list holds the shared key set (half of its records) and keys
+    of its own; the intersection of all of them is the shared set (n // 2 records for `stride`)."""
+    from . import capi
+    if dist == "stride":
+        n_s, n_p = n // 2, n - n // 2
+        s, p = ctx.alloc(n_s, k), ctx.alloc(n_p, k)
+        lists = []
+        for j in range(n_lists):
+            ctx.generate_ex(s, n_s, 7, 300 + j, 8, n_lists + 1, 0)
+            ctx.generate_ex(p, n_p, 100 + j, 400 + j, 8, n_lists + 1, 1 + j)
+            _, out, _ = ctx.compare(s, p, capi.OP_UNION)
+            lists.append(out[capi.OP_UNION])
+            assert lists[-1].n_words == n
+        s.free()
+        p.free()
+        return lists
+    if dist == "genomic":
+        anc = _ancestor(n + n // 50 + k, 78)
+        # (1 - r)^(k * n_lists) ~ 0.5 of the ancestor's k-mers survive in every copy
+        r_inv = max(2, int(k * n_lists / 0.69))
+        return [_genome_list(ctx, _mutate(anc, r_inv, 200 + j), k) for j in range(n_lists)]
+    member = [(0, j + 1) for j in range(n_lists)]
+    return _from_universe(ctx, dist, (n // 2) * (n_lists + 1), k, n_lists + 1, member, 4343)

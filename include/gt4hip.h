@@ -303,12 +303,13 @@ int gt4hip_synchronize (gt4hip_context *ctx);
  *   "pool_cap_mb" = n  most the pool may hold (default: half of the device memory); every device
  *                      allocation that fails gives the pooled blocks back and retries
  *   "grid" = n         workgroups of the merge kernel (0: one per resident slot)
- *   "kway" = 0 / 1 / 2 N-way unions of three and more lists by the pairwise tree of the pair kernel / by
+ *   "kway" = 0 / 1 / 2 / 3  N-way unions of three and more lists by the pairwise tree of the pair kernel / by
  *                      the one-pass tile kernel (gt4hip_nway.hip) unless a probe of the keys or the tiles' own
  *                      samples show them clustered -- stretches of adjacent keys between wide gaps, which the
  *                      tile kernel orders two to three times slower: the tree is faster then (the default;
  *                      counter "kway_declined") / always by the tile kernel, two-list unions of the N-way
- *                      entry points too; count tables follow the same switch (and are never declined).
+ *                      entry points too / always by the tile kernel (three lists and more); count tables
+ *                      follow the same switch (and are never declined).
  *                      "kway_g": samples per tile of its first partition attempt; "kway_vt" (tests):
  *                      97 tile boundaries by searches over whole brackets, 98 every tile bucketed by
  *                      its pivot run, 99 every tile on the search path

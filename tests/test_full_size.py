@@ -174,36 +174,51 @@ def _check_multi_windows(lists, out, n_words, total, cutoff, rule, ovr=1):
     assert out.n_words == n_words and out.sum_counts() == total and out.is_sorted()
 
 
-def test_config3_eight_way_union_full_size(ctx):
+@pytest.mark.parametrize("dist", ["stride", "iid", "clustered"])
+def test_config3_eight_way_union_full_size(ctx, dist):
     """BASELINE config 3 on one GPU: the union of eight 5e8-entry k=25 lists (the bench's construction:
-    even lists share one key set, odd lists own disjoint residue classes) -- by the one-pass N-way tile
-    kernel and by the pairwise tree (whose intermediate levels keep every key and add raw counts,
-    src/glistcompare.c:545-591), each against the oracle on key windows, and against each other."""
+    even lists share one key set, odd lists own disjoint ones; genometester4_amd/synth.py) -- by the library's
+    own choice (the one-pass N-way tile kernel; the pairwise tree for clustered keys), by the tile kernel
+    whatever the keys, and by the pairwise tree (whose intermediate levels keep every key and add raw counts,
+    src/glistcompare.c:545-591), each against the oracle on key windows, and against each other.  Key
+    distributions: one key per stride of the key space (the bench's default), independent uniform draws, and
+    stretches of adjacent keys between wide gaps (which the default setting hands to the tree)."""
+    from genometester4_amd import synth
     n = 500_000_000
-    lists = []
-    for j in range(8):
-        lst = ctx.alloc(n, 25)
-        shared = j % 2 == 0
-        ctx.generate_ex(lst, n, 7 if shared else 100 + j, 50 + j, 8, 16, 0 if shared else 1 + j)
-        lists.append(lst)
-    before = ctx.get_counter("kway_calls")
+    lists = synth.make_lists8(ctx, n, 25, dist)
+    n_in = sum(l.n_words for l in lists)
+    if dist == "stride":
+        assert n_in == 8 * n
+    calls, declined = ctx.get_counter("kway_calls"), ctx.get_counter("kway_declined")
     rc, nw, tot, out = ctx.union_multi(lists)
-    assert rc == 0 and nw == 5 * n
-    assert ctx.get_counter("kway_calls") == before + 1 and ctx.get_counter("single_pass_fallbacks") == 0
+    assert rc == 0 and ctx.get_counter("single_pass_fallbacks") == 0
+    if dist == "stride":
+        assert nw == 5 * n
+    if dist == "clustered":
+        assert ctx.get_counter("kway_declined") == declined + 1 and ctx.get_counter("nway_one_pass") == 0
+    else:
+        assert ctx.get_counter("kway_calls") == calls + 1 and ctx.get_counter("nway_one_pass") == 1
     _check_multi_windows(lists, out, nw, tot, 1, 0)
     probe = out.download_range(nw // 3, 200000).tobytes()
     out.free()
-    ctx.set_option("kway", 0)
+    for kway in (0, 3):  # the tree; the tile kernel whatever the keys
+        ctx.set_option("kway", kway)
+        try:
+            rc, nw_t, tot_t, out_t = ctx.union_multi(lists)
+        finally:
+            ctx.set_option("kway", 1)
+        assert (rc, nw_t, tot_t) == (0, nw, tot)
+        assert ctx.get_counter("nway_one_pass") == (1 if kway else 0)
+        if kway == 0 or dist == "clustered":
+            _check_multi_windows(lists, out_t, nw, tot, 1, 0)
+        assert out_t.download_range(nw // 3, 200000).tobytes() == probe
+        out_t.free()
+    # rule MAX with a cutoff on the result (union_multi :574): both paths again
+    ctx.set_option("kway", 3)
     try:
-        rc, nw_t, tot_t, out_t = ctx.union_multi(lists)
+        rc, nw2, tot2, out2 = ctx.union_multi(lists, 5, 4)
     finally:
         ctx.set_option("kway", 1)
-    assert (rc, nw_t, tot_t) == (0, nw, tot)
-    _check_multi_windows(lists, out_t, nw, tot, 1, 0)
-    assert out_t.download_range(nw // 3, 200000).tobytes() == probe
-    out_t.free()
-    # rule MAX with a cutoff on the result (union_multi :574): both paths again
-    rc, nw2, tot2, out2 = ctx.union_multi(lists, 5, 4)
     assert rc == 0
     _check_multi_windows(lists, out2, nw2, tot2, 5, 4)
     ctx.set_option("kway", 0)

@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 def ctx():
     from genometester4_amd import capi
     c = capi.Context(0)
-    c.set_option("kway", 1)
+    c.set_option("kway", 3)  # the tile kernel whatever the keys (1, the default, hands clustered keys to the tree)
     yield c
     c.close()
 
@@ -163,6 +163,31 @@ def test_clustered_keys(ctx):
     _check(ctx, lists, k=25)
 
 
+def test_default_setting_hands_clustered_keys_to_the_tree(ctx):
+    """Option kway = 1 (the default): a probe of the longest list's keys sees stretches of adjacent keys between
+    wide gaps and the call takes the pairwise tree -- same bytes, counter kway_declined; evenly spread keys of the
+    same size stay on the tile kernel."""
+    rng = np.random.default_rng(77)
+    n_cl = 400
+    centres = np.sort(rng.choice(1 << 20, size=n_cl, replace=False).astype(np.uint64)) << np.uint64(30)
+    clustered = np.unique((centres[:, None] + rng.integers(0, 5000, size=(n_cl, 900), dtype=np.uint64)).ravel())
+    uniform = np.unique(rng.integers(0, 1 << 50, size=len(clustered), dtype=np.uint64))
+    ctx.set_option("kway", 1)
+    try:
+        for keys, declined in ((clustered, True), (uniform, False)):
+            lists = []
+            for j in range(5):
+                m = rng.random(len(keys)) < 0.6
+                lists.append(U.make_records(keys[m], rng.integers(1, 7, size=int(m.sum()), dtype=np.uint32)))
+            d0, c0 = ctx.get_counter("kway_declined"), ctx.get_counter("kway_calls")
+            _check(ctx, lists, k=25, expect_kway=False)
+            assert (ctx.get_counter("kway_declined") > d0) == declined
+            assert (ctx.get_counter("kway_calls") > c0) == (not declined)
+            assert ctx.get_counter("nway_one_pass") == (0 if declined else 1)
+    finally:
+        ctx.set_option("kway", 3)
+
+
 @pytest.mark.parametrize("span_bits", [14, 22, 31])
 def test_dense_keys_take_the_narrow_path(ctx, span_bits):
     """Tiles whose keys span less than 2^32 group and walk 4-byte keys relative to the tile's smallest
@@ -210,7 +235,7 @@ def test_tile_overflow_is_retried_with_fewer_samples_per_tile(ctx):
     try:
         _check(ctx, lists, expect_kway=False)
     finally:
-        ctx.set_option("kway", 1)
+        ctx.set_option("kway", 3)
 
 
 def test_generated_eight_lists_against_the_oracle(ctx):
@@ -281,7 +306,7 @@ def _check_table(ctx, lists, k=20, expect_kway=True):
     try:
         mk, mc = ctx.union_table(dev)
     finally:
-        ctx.set_option("kway", 1)
+        ctx.set_option("kway", 3)
     assert mk.tobytes() == tk.tobytes() and mc.tobytes() == tc.tobytes()
     # the tables restricted to the keys of list 0 (gt4_is_union / search_lists_multi; reference
     # src/set-operations.c:185-228, src/glistquery.c:776-812): counts, and membership (a list may hold a key with count 0)
@@ -308,7 +333,7 @@ def _check_table(ctx, lists, k=20, expect_kway=True):
             qk, qc = ctx.union_table(dev, probe=True)
             _, qp = ctx.union_table(dev, probe=True, presence=True)
         finally:
-            ctx.set_option("kway", 1)
+            ctx.set_option("kway", 3)
         assert qk.tobytes() == pk.tobytes() and qc.tobytes() == pc.tobytes() and qp.tobytes() == pp.tobytes()
     for d in dev:
         d.free()

@@ -3,7 +3,7 @@
 
   exp.py union8 [--n N] [--lists L] [--dist D] [--kway 0,1] [--reps R] [--g G]
         N-way union of the bench's lists: pairwise tree (kway 0) against the library's choice (1) / the one-pass
-        tile kernel forced (2); totals and a hash of head and tail must agree between the runs
+        tile kernel forced (3); totals and a hash of head and tail must agree between the runs
   exp.py dists [--n N] [--n8 N8] [--dists a,b,..]
         the pair kernels (intersection, union, -u -d) and the 8-way union (tree and one pass) on every key
         distribution of genometester4_amd/synth.py
@@ -100,7 +100,7 @@ def cmd_dists(a):
         ctx.synchronize()
         print("# %s lists generated in %.1f s: %s" % (d, time.time() - t0, [l.n_words for l in lists]), flush=True)
         ref = None
-        for kway in (0, 2, 1):
+        for kway in (0, 3, 1):
             _, sig = time_nway(ctx, "%-9s 8-way union" % d, lists, kway)
             ref = ref or sig
             if sig != ref:
