@@ -523,10 +523,6 @@ __global__ __launch_bounds__ (1024) void k_nway_tile_bases (const u32 *__restric
 
 /* ------------------------------------------------------------------ K7: the tile kernel */
 
-#ifndef GT4_NWAY_SVPRIO
-#define GT4_NWAY_SVPRIO 3
-#endif
-
 #ifndef GT4_NWAY_NT
 #define GT4_NWAY_NT 1024
 #endif
@@ -536,6 +532,30 @@ __global__ __launch_bounds__ (1024) void k_nway_tile_bases (const u32 *__restric
 #ifndef GT4_NWAY_NBF
 #define GT4_NWAY_NBF 1
 #endif
+#ifndef GT4_NWAY_SVPRIO
+#define GT4_NWAY_SVPRIO 3
+#endif
+/* Round 4: the per-tile work that does not depend on the number of records is 58 % of a tile (time per tile against
+ * samples per tile: 14.1 ns + 0.42 ns x G on 256 CUs, profiles/round4/r4_nway_experiments.log), part of it
+ * instructions every one of the sixteen wavefronts executes.  Three cuts, each A/B-measured (31.4 -> 30.1 ms together;
+ * GT4_NWAY_FILL / _SCAN4 / _LEAN = 0 restore the old forms):
+ *   FILL   the grouped-key area is filled with all-ones once per tile (two 16-byte stores per thread, behind the
+ *          walks of the previous tile) instead of every thread working out which skewed slots its buckets leave free
+ *          (-1.0 ms);
+ *   SCAN4  the bucket counters are scanned by four wavefronts (one per SIMD, eight words = sixteen counters per lane,
+ *          16-byte LDS accesses) instead of sixteen (two words per lane): twelve wavefronts skip two DPP scans, two
+ *          DPP maxima and their LDS traffic (-0.3 ms with FILL; +1.5 ms without it: sixteen slot tests per lane);
+ *   LEAN   one DPP scan behind B6 instead of a scan and a sum. */
+#ifndef GT4_NWAY_FILL
+#define GT4_NWAY_FILL 1
+#endif
+#ifndef GT4_NWAY_SCAN4
+#define GT4_NWAY_SCAN4 1
+#endif
+#ifndef GT4_NWAY_LEAN
+#define GT4_NWAY_LEAN 1
+#endif
+
 typedef u32 u32x3 __attribute__ ((ext_vector_type (3)));
 
 __device__ __forceinline__ u32 dpp_wave_max_u32 (u32 v)
@@ -575,7 +595,7 @@ struct NwayShared {
   alignas (16) u32 cnt[NB / 2 + 4];        /* 16-bit bucket counters, then bucket starts, in pairs (+ the total) */
   alignas (16) u32 live[(CAPS + 3) / 4];   /* one byte per position: a key was stored there */
   alignas (16) u32 stage[nway_staged (MODE) ? 3 * CAP + 4 : 4]; /* the kept records, packed, written out during the NEXT tile */
-  u32 wtot[NW], wmax[NW], wkept[NW];
+  alignas (16) u32 wtot[NW], wmax[NW], wkept[NW];
   /* the tiles of this iteration, the next one (being fetched) and the one after (being described),
    * three deep: one 64-record wave slot per wave-instruction */
   u64 slot_addr[3][NCH];
@@ -655,7 +675,7 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
   constexpr int CAP = Shared::CAP, NW = Shared::NW, NCH = Shared::NCH, NB = Shared::NB;
   constexpr int NWORDS = NB / 2, WPT = NWORDS / NT;
   constexpr int CAPS = Shared::CAPS;
-  static_assert (NCH <= WAVE, "one lane per wave slot builds the slot table");
+  static_assert (NCH <= 2 * WAVE, "one lane per wave slot builds the slot table, in two rounds at most");
   static_assert (WPT * NT == NWORDS && WPT >= 1, "every thread scans the same number of counter words");
   static_assert (NW <= 16 && NW >= 2, "wave totals are reduced by one DPP row");
   static_assert (NWAY_LIMIT % 2 == 0 && NWAY_TRY0 <= NWAY_LIMIT, "bucket walks go two steps at a time");
@@ -734,18 +754,22 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
       sh.tab_pbase[tb][lane] = excl * WAVE;
       sh.tab_len[tb][lane] = len;
     }
-    u32 run = 0;
 #pragma unroll
-    for (int q = 0; q < NWAY_MAX - 1; q++) run += (u32) lane >= (u32) __builtin_amdgcn_readlane ((int) incl, q) ? 1u : 0u;
-    const u32 len_r = __shfl (len, run, WAVE), excl_r = __shfl (excl, run, WAVE);
-    const u64 s_r = (u64) __shfl (rlo, run, WAVE) | ((u64) __shfl (rhi, run, WAVE) << 32);
-    const u64 lb_r = (u64) __shfl ((u32) lbv, run, WAVE) | ((u64) __shfl ((u32) (lbv >> 32), run, WAVE) << 32);
-    const bool in = (u32) lane < total;
-    const u32 first = in ? ((u32) lane - excl_r) * WAVE : 0u;
-    if (lane < NCH) {
-      sh.slot_cnt[tb][lane] = in ? (len_r - first < (u32) WAVE ? len_r - first : (u32) WAVE) : 0u;
-      sh.slot_addr[tb][lane] = lb_r + 12ull * (s_r + first);
-      if (MODE == NWAY_TABLE || MODE == NWAY_PROBE || MODE == NWAY_DUPS) sh.slot_run[tb][lane] = run;
+    for (int sb = 0; sb < NCH; sb += WAVE) { /* one lane per wave slot (two rounds when a tile has more than 64) */
+      const u32 slot = (u32) (sb + lane);
+      u32 run = 0;
+#pragma unroll
+      for (int q = 0; q < NWAY_MAX - 1; q++) run += slot >= (u32) __builtin_amdgcn_readlane ((int) incl, q) ? 1u : 0u;
+      const u32 len_r = __shfl (len, run, WAVE), excl_r = __shfl (excl, run, WAVE);
+      const u64 s_r = (u64) __shfl (rlo, run, WAVE) | ((u64) __shfl (rhi, run, WAVE) << 32);
+      const u64 lb_r = (u64) __shfl ((u32) lbv, run, WAVE) | ((u64) __shfl ((u32) (lbv >> 32), run, WAVE) << 32);
+      const bool in = slot < total;
+      const u32 first = in ? (slot - excl_r) * WAVE : 0u;
+      if (slot < (u32) NCH) {
+        sh.slot_cnt[tb][slot] = in ? (len_r - first < (u32) WAVE ? len_r - first : (u32) WAVE) : 0u;
+        sh.slot_addr[tb][slot] = lb_r + 12ull * (s_r + first);
+        if (MODE == NWAY_TABLE || MODE == NWAY_PROBE || MODE == NWAY_DUPS) sh.slot_run[tb][slot] = run;
+      }
     }
     u64 base = 0;
     if (MODE == NWAY_DUPS) {
@@ -812,6 +836,11 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
   }
 #pragma unroll
   for (int i = 0; i < WPT; i++) sh.cnt[tid * WPT + i] = 0;
+  auto fill_g = [&] () { /* all-ones wherever no key is: what a bucket walk meets behind its bucket must not be smaller than any key */
+    static_assert (Shared::GSZ % 2 == 0, "the grouped keys are filled 16 bytes at a time");
+    for (int i = tid; i < Shared::GSZ / 2; i += NT) *reinterpret_cast<u32x4 *> (&sh.g[2 * i]) = u32x4 { ~0u, ~0u, ~0u, ~0u };
+  };
+  if (GT4_NWAY_FILL) fill_g ();
   __syncthreads ();
   if (uniform32 (sh.hdr[0][0]) < ntl && (u32) (wid * RPT) < uniform32 (sh.hdr[0][2])) fetch (0);
 
@@ -900,6 +929,71 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
       __syncthreads (); /* B1: every record is counted */
       PHASE_STAMP (1);
 
+      if constexpr (GT4_NWAY_SCAN4 && NWORDS % (4 * WAVE * 4) == 0 && NW >= 4) {
+        /* ---- scan of the bucket counters by the first four wavefronts (one per SIMD: a workgroup's wavefronts go to
+         * the SIMDs in turn): WPL words = 2 WPL counters per lane, read and written 16 bytes at a time */
+        constexpr int WPL = NWORDS / (4 * WAVE);
+        u32 ex[2 * WPL];
+        u32 tsum = 0, incl = 0;
+        const int sl = (wid & 3) * WAVE + lane; /* the lane's place among the 256 scanning lanes */
+        if (wid < 4) {
+          u32 tmax = 0;
+          u32 w[WPL];
+#pragma unroll
+          for (int i = 0; i < WPL / 4; i++) {
+            const u32x4 q = *reinterpret_cast<const u32x4 *> (&sh.cnt[sl * WPL + 4 * i]);
+            w[4 * i] = q.x;
+            w[4 * i + 1] = q.y;
+            w[4 * i + 2] = q.z;
+            w[4 * i + 3] = q.w;
+          }
+#pragma unroll
+          for (int i = 0; i < WPL; i++) {
+            const u32 a = w[i] & 0xffffu, b = w[i] >> 16;
+            ex[2 * i] = tsum;
+            tsum += a;
+            ex[2 * i + 1] = tsum;
+            tsum += b;
+            tmax = a > tmax ? a : tmax;
+            tmax = b > tmax ? b : tmax;
+          }
+          incl = dpp_inclusive_scan_u32 (tsum);
+          const u32 wmx = dpp_wave_max_u32 (tmax);
+          if (lane == WAVE - 1) {
+            sh.wtot[wid] = incl;
+            sh.wmax[wid] = wmx;
+          }
+        }
+        PHASE_STAMP (2);
+        __syncthreads (); /* B2: the four wavefronts' totals */
+        PHASE_STAMP (3);
+        if (wid < 4) {
+          const u32x4 t4 = *reinterpret_cast<const u32x4 *> (&sh.wtot[0]);
+          const u32 wbase = (wid > 0 ? t4.x : 0u) + (wid > 1 ? t4.y : 0u) + (wid > 2 ? t4.z : 0u); /* (wid is uniform: scalar selects) */
+          const u32 tbase = wbase + incl - tsum;
+#pragma unroll
+          for (int i = 0; i < WPL / 4; i++) {
+            u32x4 q;
+            q.x = (tbase + ex[8 * i]) | ((tbase + ex[8 * i + 1]) << 16);
+            q.y = (tbase + ex[8 * i + 2]) | ((tbase + ex[8 * i + 3]) << 16);
+            q.z = (tbase + ex[8 * i + 4]) | ((tbase + ex[8 * i + 5]) << 16);
+            q.w = (tbase + ex[8 * i + 6]) | ((tbase + ex[8 * i + 7]) << 16);
+            *reinterpret_cast<u32x4 *> (&sh.cnt[sl * WPL + 4 * i]) = q;
+          }
+          if (sl == 4 * WAVE - 1) sh.cnt[NWORDS] = tbase + tsum; /* start of the bucket behind the last = the tile's records */
+          if (!GT4_NWAY_FILL) {
+#pragma unroll
+            for (int j = 0; j < 2 * WPL; j++) {
+              const u32 s0 = tbase + ex[j], e0 = tbase + (j + 1 < 2 * WPL ? ex[j + 1 < 2 * WPL ? j + 1 : 0] : tsum);
+              if ((e0 >> 5) != (s0 >> 5)) {
+                sh.g[e0 + (s0 >> 5)] = ~0ull;
+                if ((e0 >> 5) - (s0 >> 5) > 1u) sh.g[e0 + (s0 >> 5) + 1u] = ~0ull;
+              }
+            }
+          }
+        }
+        if (!GT4_NWAY_FILL && tid < NWAY_LIMIT + 2) sh.g[nway_skew (n) + (u32) tid] = ~0ull;
+      } else {
       /* ---- scan of the bucket counters: WPT words (two 16-bit counters each) per thread */
       u32 ex[2 * WPT];
       u32 tsum = 0, tmax = 0;
@@ -940,19 +1034,27 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
          * buckets' keys are not, and the skewed slots a bucket that crosses multiples of 32 leaves free
          * behind its last key (two at most: walked buckets hold no more than 48 keys) get all-ones here,
          * as do the slots behind the tile's last key */
+        if (!GT4_NWAY_FILL) {
 #pragma unroll
-        for (int j = 0; j < 2 * WPT; j++) {
-          const u32 s0 = tbase + ex[j], e0 = tbase + (j + 1 < 2 * WPT ? ex[j + 1 < 2 * WPT ? j + 1 : 0] : tsum);
-          if ((e0 >> 5) != (s0 >> 5)) {
-            sh.g[e0 + (s0 >> 5)] = ~0ull;
-            if ((e0 >> 5) - (s0 >> 5) > 1u) sh.g[e0 + (s0 >> 5) + 1u] = ~0ull;
+          for (int j = 0; j < 2 * WPT; j++) {
+            const u32 s0 = tbase + ex[j], e0 = tbase + (j + 1 < 2 * WPT ? ex[j + 1 < 2 * WPT ? j + 1 : 0] : tsum);
+            if ((e0 >> 5) != (s0 >> 5)) {
+              sh.g[e0 + (s0 >> 5)] = ~0ull;
+              if ((e0 >> 5) - (s0 >> 5) > 1u) sh.g[e0 + (s0 >> 5) + 1u] = ~0ull;
+            }
           }
+          if (tid < NWAY_LIMIT + 2) sh.g[nway_skew (n) + (u32) tid] = ~0ull; /* (+2: the walks read two steps ahead) */
         }
-        if (tid < NWAY_LIMIT + 2) sh.g[nway_skew (n) + (u32) tid] = ~0ull; /* (+2: the walks read two steps ahead) */
+      }
       }
       PHASE_STAMP (4);
       __syncthreads (); /* B3: bucket starts */
       PHASE_STAMP (5);
+      if constexpr (GT4_NWAY_SCAN4 && NWORDS % (4 * WAVE * 4) == 0 && NW >= 4) {
+        const u32x4 m4 = *reinterpret_cast<const u32x4 *> (&sh.wmax[0]);
+        const u32 m01 = m4.x > m4.y ? m4.x : m4.y, m23 = m4.z > m4.w ? m4.z : m4.w;
+        mx = uniform32 (m01 > m23 ? m01 : m23);
+      }
 
       /* ---- the keys grouped by bucket */
 #pragma unroll
@@ -1215,6 +1317,7 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
     __syncthreads (); /* B5: the tile in key order */
     PHASE_STAMP (11);
     if (service && !wo_done) write_out (12 * resolve_offset (agg, carry, pend_tile, lane, xagg, xcarry, ctl, spin_limit));
+    if (GT4_NWAY_FILL) fill_g (); /* every walk of this tile is behind B5: the grouped keys of the next tile start from all-ones */
     PHASE_STAMP (12);
 
     /* ---- positions in order, one per lane (a wavefront walks its RPT chunks of 64): keep test, ballots */
@@ -1265,7 +1368,7 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
       const u32 x = lane < NW ? sh.wkept[lane] : 0u;
       const u32 incl2 = dpp_inclusive_scan_u32 (x);
       tile_total = (u32) __builtin_amdgcn_readlane ((int) incl2, WAVE - 1);
-      const u32 wbase = dpp_wave_sum_u32 (lane < wid ? x : 0u);
+      const u32 wbase = GT4_NWAY_LEAN ? (wid ? (u32) __builtin_amdgcn_readlane ((int) incl2, wid - 1) : 0u) : dpp_wave_sum_u32 (lane < wid ? x : 0u);
       blk_cnt += tile_total;
       if (MODE == NWAY_UNION && service) {
         if (lane == 0) publish_u32 (&agg[cur], AGG_READY | tile_total);
