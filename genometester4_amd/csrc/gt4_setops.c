@@ -13,12 +13,55 @@
 #include <unistd.h>
 
 struct _GT4HipWordList {
-  gt4hip_list *dev;
+  gt4hip_list *dev;  /* the list in HBM; NULL while a file-backed handle has not been uploaded */
   uint64_t num_words;
   uint64_t sum_counts;
   unsigned int word_length;
   uint64_t last_key; /* key of the last record (valid when num_words > 0) */
+  /* File-backed handles (round 4): a list whose file is larger than the resident share of the device memory
+   * stays mapped instead of being uploaded at once.  gt4_write_union streams such inputs through the device in
+   * key-range chunks (gt4_shard.c: loader / merger / writer threads, the plan of the command-line tool); every
+   * other entry point uploads the list on first use and fails with a message if it does not fit. */
+  GT4ListFile file;
+  int file_backed;
 };
+
+#include "gt4_shard.h"
+
+/* device bytes a handle may take at once and stay resident: $GT4HIP_HBM_LIMIT (tests force the streaming path
+ * with it), else a quarter of what the device has free now */
+static uint64_t resident_limit (gt4hip_context *ctx)
+{
+  const char *e = getenv ("GT4HIP_HBM_LIMIT");
+  if (e && *e) {
+    char *end = NULL;
+    double v = strtod (e, &end);
+    if (end && (*end == 'K' || *end == 'k')) v *= 1024.0;
+    else if (end && (*end == 'M' || *end == 'm')) v *= 1024.0 * 1024.0;
+    else if (end && (*end == 'G' || *end == 'g')) v *= 1024.0 * 1024.0 * 1024.0;
+    return v > 0 ? (uint64_t) v : 0;
+  }
+  uint64_t free_b = 0, total_b = 0;
+  if (gt4hip_device_memory (ctx, &free_b, &total_b)) return 0;
+  return free_b / 4;
+}
+
+/* uploads a file-backed list that is not in HBM yet; 0 = the handle has a device list */
+static int ensure_device (gt4hip_context *ctx, GT4HipWordList *l, const char *who)
+{
+  if (!l) return 1;
+  if (l->dev) return 0;
+  if (!l->file_backed) return 1;
+  const GT4ListFile *lf = &l->file;
+  const int rc = lf->index_kmers ? gt4hip_list_upload_index (ctx, lf->index_kmers, lf->header.n_words, lf->index_locations, lf->header.word_length, &l->dev)
+                                 : gt4hip_list_upload (ctx, lf->records, lf->header.n_words, lf->header.word_length, &l->dev);
+  if (rc) {
+    fprintf (stderr, "%s: upload of %s failed: %s\n", who, lf->filename, gt4hip_last_error (ctx));
+    l->dev = NULL;
+    return 1;
+  }
+  return 0;
+}
 
 static gt4hip_context *g_ctx = NULL;
 
@@ -70,6 +113,21 @@ GT4HipWordList *gt4_hip_word_list_new (const char *listfilename, unsigned int ma
   /* a GT4I index is a sorted k-mer list too (gt4_index_map_new's GT4WordSList interface) */
   const int is_index = !gt4_listfile_sniff (listfilename, &code) && code == GT4_INDEX_CODE_VALUE;
   if (is_index ? gt4_indexfile_open (listfilename, major_version, &lf) : gt4_listfile_open (listfilename, major_version, &lf)) return NULL;
+  if (12 * lf.header.n_words > resident_limit (ctx) && lf.header.n_words > 0) {
+    /* too big to sit in HBM beside the others: stays mapped (see struct _GT4HipWordList) */
+    GT4HipWordList *l = (GT4HipWordList *) calloc (1, sizeof *l);
+    if (!l) {
+      gt4_listfile_close (&lf);
+      return NULL;
+    }
+    l->file = lf;
+    l->file_backed = 1;
+    l->num_words = lf.header.n_words;
+    l->sum_counts = lf.header.total_count;
+    l->word_length = lf.header.word_length;
+    l->last_key = gt4_listfile_key_at (&lf, lf.header.n_words - 1);
+    return l;
+  }
   gt4hip_list *dev = NULL;
   int rc = is_index ? gt4hip_list_upload_index (ctx, lf.index_kmers, lf.header.n_words, lf.index_locations, lf.header.word_length, &dev)
                     : gt4hip_list_upload (ctx, lf.records, lf.header.n_words, lf.header.word_length, &dev);
@@ -98,14 +156,16 @@ GT4HipWordList *gt4_hip_word_list_new_from_records (const void *records, uint64_
 void gt4_hip_word_list_delete (GT4HipWordList *list)
 {
   if (!list) return;
-  gt4hip_list_free (list->dev);
+  if (list->dev) gt4hip_list_free (list->dev);
+  if (list->file_backed) gt4_listfile_close (&list->file);
   free (list);
 }
 
 uint64_t gt4_hip_word_list_num_words (const GT4HipWordList *list) { return list ? list->num_words : 0; }
 uint64_t gt4_hip_word_list_sum_counts (const GT4HipWordList *list) { return list ? list->sum_counts : 0; }
 unsigned int gt4_hip_word_list_word_length (const GT4HipWordList *list) { return list ? list->word_length : 0; }
-const gt4hip_list *gt4_hip_word_list_device (const GT4HipWordList *list) { return list ? list->dev : NULL; }
+const gt4hip_list *gt4_hip_word_list_device (const GT4HipWordList *list) { return list ? list->dev : NULL; } /* (NULL while a file-backed list is not uploaded) */
+int gt4_hip_word_list_is_file_backed (const GT4HipWordList *list) { return list && list->file_backed && !list->dev; }
 
 static int write_fully (int fd, const void *buf, size_t len)
 {
@@ -130,6 +190,57 @@ unsigned int gt4_write_union (GT4HipWordList *arrays[], unsigned int n_arrays, u
   if (n_arrays == 0 || n_arrays > GT4_MAX_SETS || !arrays || !header) return 1;
   gt4hip_context *ctx = gt4_hip_default_context ();
   if (!ctx) return 1;
+  /* Inputs that were too big to upload (file-backed handles): when ALL of them are, the union is streamed through
+   * the device in key-range chunks -- the command-line tool's pipeline (gt4_shard.c), reading the mapped files and
+   * writing `ofile` behind its header -- so neither the inputs nor the output have to fit HBM; glistmaker's
+   * collation of up to 32 temporary lists (reference src/glistmaker.c:787-835) is this call. */
+  unsigned int n_backed = 0;
+  for (unsigned int j = 0; j < n_arrays; j++) n_backed += arrays[j] && arrays[j]->file_backed && !arrays[j]->dev;
+  if (n_backed == n_arrays && n_arrays <= 1024) {
+    GT4ListFile *files = (GT4ListFile *) malloc (n_arrays * sizeof *files);
+    if (!files) return 1;
+    for (unsigned int j = 0; j < n_arrays; j++) files[j] = arrays[j]->file;
+    gt4_list_header_init (header, arrays[0]->word_length);
+    GT4ShardJob job;
+    GT4ShardResult sres;
+    memset (&job, 0, sizeof job);
+    job.n_files = n_arrays;
+    job.files = files;
+    job.word_length = arrays[0]->word_length;
+    job.mode = GT4_SHARD_UNION_MULTI;
+    job.prm.rule = GT4HIP_RULE_ADD;
+    job.prm.cutoff = cutoff;
+    job.prm.count_only = ofile ? 0 : 1;
+    job.n_ranks = 1;
+    job.hbm_limit = resident_limit (ctx);
+    job.debug = getenv ("GT4HIP_VERBOSE") && atoi (getenv ("GT4HIP_VERBOSE"));
+    unsigned int bad = 0;
+    off_t pos = 0;
+    if (ofile) {
+      /* placeholder header (:65), records behind it, the real header over it at the end (:123-126) */
+      pos = lseek (ofile, 0, SEEK_CUR);
+      if (pos < 0) {
+        fprintf (stderr, "gt4_write_union: inputs of this size need a seekable output file\n");
+        free (files);
+        return 1;
+      }
+      bad |= write_fully (ofile, header, sizeof *header);
+      job.out_fd[0] = ofile;
+      job.out_base[0] = (uint64_t) pos + sizeof *header;
+    }
+    if (!bad && gt4_shard_run (&job, &sres)) bad = 1;
+    free (files);
+    if (bad) return 1;
+    header->n_words = sres.n_words[0];
+    header->total_count = sres.total_count[0];
+    if (ofile) {
+      if (pwrite (ofile, header, sizeof *header, pos) != (ssize_t) sizeof *header) return 1;
+      if (lseek (ofile, pos + (off_t) sizeof *header + (off_t) (header->n_words * 12u), SEEK_SET) < 0) return 1;
+    }
+    return 0;
+  }
+  for (unsigned int j = 0; j < n_arrays; j++)
+    if (ensure_device (ctx, arrays[j], "gt4_write_union")) return 1;
   const gt4hip_list **devs = (const gt4hip_list **) malloc (n_arrays * sizeof *devs);
   if (!devs) return 1;
   for (unsigned int j = 0; j < n_arrays; j++) devs[j] = arrays[j]->dev;
@@ -226,6 +337,8 @@ static unsigned int table_walk (GT4HipWordList *objs[], unsigned int n_objs, int
   if (n_objs == 0 || n_objs > GT4_MAX_SETS || !objs || !callback) return 1; /* src/set-operations.c:140-141 */
   gt4hip_context *ctx = gt4_hip_default_context ();
   if (!ctx) return 1;
+  for (unsigned int j = 0; j < n_objs; j++)
+    if (ensure_device (ctx, objs[j], probe ? "gt4_is_union" : "gt4_union")) return 1;
   const gt4hip_list **devs = (const gt4hip_list **) malloc (n_objs * sizeof *devs);
   if (!devs) return 1;
   for (unsigned int j = 0; j < n_objs; j++) devs[j] = objs[j]->dev;
@@ -271,6 +384,9 @@ unsigned int gt4_search_lists_multi (GT4HipWordList *query, GT4HipWordList *list
   gt4hip_context *ctx = gt4_hip_default_context ();
   if (!ctx) return 1;
   const unsigned int n = n_lists + 1;
+  if (ensure_device (ctx, query, "gt4_search_lists_multi")) return 1;
+  for (unsigned int j = 0; j < n_lists; j++)
+    if (ensure_device (ctx, lists[j], "gt4_search_lists_multi")) return 1;
   const gt4hip_list **devs = (const gt4hip_list **) malloc (n * sizeof *devs);
   if (!devs) return 1;
   devs[0] = query->dev;
@@ -321,6 +437,7 @@ unsigned int gt4_search_list_zipper (GT4HipWordList *list, GT4HipWordList *query
    * reference's loop has no count test at all) -- except keys whose count in `query` is 0, which
    * the reference prints and the intersection's "count != 0" test drops: those come from the
    * presence table instead, so use the table form when the query holds zero counts */
+  if (ensure_device (ctx, query, "gt4_search_list_zipper") || ensure_device (ctx, list, "gt4_search_list_zipper")) return 1;
   const gt4hip_list *devs[2] = { query->dev, list->dev };
   gt4hip_count_table tp;
   if (gt4hip_probe_table_ex (ctx, devs, 2, 1, &tp)) {

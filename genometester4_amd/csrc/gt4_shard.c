@@ -299,7 +299,7 @@ static void *writer_main (void *arg)
           wfirst[nw] = 0;
           wcount[nw] = w->out_n[slot][s];
           wfd[nw] = w->out_fd[s];
-          woff[nw] = 48 + 12 * start[s];
+          woff[nw] = (job->out_name[s] ? 48 : job->out_base[s]) + 12 * start[s];
           nw++;
         }
         if (nw && !stopped (w) && gt4hip_lists_write_fd (ctx, nw, wl, wfirst, wcount, wfd, woff))
@@ -480,6 +480,9 @@ static int worker_main (const GT4ShardJob *job, Shared *sh, int rank)
       }
       w->out_fd[s] = lw.fd;
     }
+    /* (a descriptor of the caller's: single worker, nothing to create) */
+    for (int s = 0; s < 4 && G == 1; s++)
+      if (!job->out_name[s] && job->out_fd[s] > 0) w->out_fd[s] = job->out_fd[s];
   }
   if (G > 1) pthread_barrier_wait (&sh->bar);
   if (!stopped (w) && plan.n_chunks != sh->n_chunks) worker_fail (w, "Error: %s", "internal: chunk plans differ");

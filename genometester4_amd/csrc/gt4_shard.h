@@ -29,6 +29,11 @@ typedef struct {
    * produced; written as <name>.tmp then renamed */
   const char *out_name[4];
   unsigned int out_mode;         /* creation mode of the output files                            */
+  /* ... or, single worker only (n_ranks = 1), a file the CALLER has opened (gt4_write_union's `ofile`,
+   * include/gt4_set_operations.h): out_fd[s] > 0 with out_name[s] = NULL -- the records go to byte
+   * out_base[s] + 12 * (records before); no header, no temporary, no rename, the descriptor stays open */
+  int out_fd[4];
+  uint64_t out_base[4];
   /* plan */
   int n_ranks;                   /* worker processes = GPUs (1: no fork, runs in the caller)     */
   uint64_t hbm_limit;            /* device bytes a worker may hold in flight; 0: 70 % of what is free */

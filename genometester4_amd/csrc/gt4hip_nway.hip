@@ -1388,6 +1388,17 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
         }
       }
       if (MODE == NWAY_TABLE) {
+        /* The tile's rows of the count matrix start as zeros: written here, 16 bytes per lane, instead of by a
+         * memset of the whole matrix in front of the launch (9.6 GB for the bench's table, a fifth of the call's
+         * traffic: most of it was overwritten again a moment later).  The records' own stores follow behind a
+         * wait for these and the barrier below, so they land on the zeros -- in this XCD's L2, where the two meet
+         * before the lines go to HBM. */
+        {
+          const u64 words = (u64) tile_total * p.table_cols;
+          const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc ((void *) (p.table_counts + out_base * p.table_cols), 0, (int) (4 * words), 0x00020000);
+          for (u32 c = (u32) tid; 4ull * c < words; c += NT) __builtin_amdgcn_raw_buffer_store_b128 (u32x4 { 0, 0, 0, 0 }, zr, 16 * c, 0, 0);
+          asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         /* the key column, and every position's row (over the ordered tile's counts, which this mode
          * does not fold) for the records to find */
         if (wave_kept) {
@@ -1772,7 +1783,7 @@ static int nway_run (gt4hip_context *ctx, const gt4hip_list *const lists[], uint
         if (rows) {
           if ((rc = gt4hip_table_alloc (ctx, table, rows, table->n_lists))) break;
           table->n_keys = rows;
-          hipMemsetAsync (table->device_counts, 0, (size_t) rows * table->n_lists * 4, st);
+          /* (the table launch zeroes every tile's rows itself) */
           hipLaunchKernelGGL (k_nway_tile_bases, dim3 (1), dim3 (1024), 0, st, (const u32 *) ctx->desc, tiles, bases);
           lv.p.tile_totals = NULL;
           lv.p.tile_base = bases;

@@ -33,7 +33,13 @@ gt4hip_context *gt4_hip_set_default_context (gt4hip_context *ctx);
 
 /* gt4_word_map_new (src/word-map.c:165-241) for the GPU path: map, validate, upload.  A GT4I index
  * file is accepted as the sorted k-mer list it contains (gt4_index_map_new, src/index-map.c:317-373).
- * NULL on failure (diagnostic on stderr). */
+ * NULL on failure (diagnostic on stderr).
+ * A file larger than the resident share of the device memory ($GT4HIP_HBM_LIMIT bytes, K / M / G suffixes
+ * accepted; default: a quarter of what the device has free) is NOT uploaded: the handle stays FILE-BACKED (the file
+ * mapped, as the reference's GT4WordMap is).  gt4_write_union over file-backed handles streams the inputs through
+ * the device in key-range chunks and writes `ofile` as it goes -- inputs and output of any size, e.g. glistmaker's
+ * collation of up to 32 temporary lists (reference src/glistmaker.c:787-835); every other entry point uploads a
+ * file-backed list on first use (and fails with a message if it does not fit). */
 GT4HipWordList *gt4_hip_word_list_new (const char *listfilename, unsigned int major_version);
 /* Wraps packed records already in host memory (copied to HBM). */
 GT4HipWordList *gt4_hip_word_list_new_from_records (const void *records, uint64_t n_words, unsigned int word_length);
@@ -42,7 +48,8 @@ void gt4_hip_word_list_delete (GT4HipWordList *list);
 uint64_t gt4_hip_word_list_num_words (const GT4HipWordList *list);
 uint64_t gt4_hip_word_list_sum_counts (const GT4HipWordList *list);
 unsigned int gt4_hip_word_list_word_length (const GT4HipWordList *list);
-const gt4hip_list *gt4_hip_word_list_device (const GT4HipWordList *list);
+const gt4hip_list *gt4_hip_word_list_device (const GT4HipWordList *list); /* NULL while a file-backed list has not been uploaded */
+int gt4_hip_word_list_is_file_backed (const GT4HipWordList *list);
 
 /* Combines N lists into one union (counts added, u32 wrap), keeps keys whose sum >= cutoff,
  * writes header + records to `ofile` when it is non-zero, always fills *header.

@@ -101,6 +101,56 @@ def test_set_operations_entry_points_match_reference(case, workdir):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", SETOPS_CASES, ids=lambda c: c["id"])
+def test_set_operations_over_file_backed_handles_match_reference(case, workdir):
+    """The same goldens with GT4HIP_HBM_LIMIT = 1 KiB: every list file is larger than the resident share, so the
+    handles stay file-backed -- gt4_write_union streams them through the device in key-range chunks (the command-line
+    tool's pipeline, csrc/gt4_shard.c) into the caller's descriptor; gt4_union / gt4_is_union upload on first use."""
+    before = set(os.listdir(workdir))
+    p = subprocess.run([SETOPS] + case["argv"], cwd=workdir, capture_output=True, timeout=300, env=dict(os.environ, GT4HIP_HBM_LIMIT="1K"))
+    created = sorted(set(os.listdir(workdir)) - before)
+    files = {}
+    for f in created:
+        with open(os.path.join(workdir, f), "rb") as fh:
+            files[f] = fh.read()
+        os.remove(os.path.join(workdir, f))
+    assert p.returncode == case["exit"], (p.returncode, p.stderr.decode("latin-1"))
+    assert p.stdout.decode("latin-1") == case["stdout"]
+    assert sorted(files) == sorted(case["files"])
+    for name, data in files.items():
+        assert data == bytes(OUTPUTS["%s/%s" % (case["id"], name)]), "%s differs from the reference output" % name
+
+
+@pytest.mark.gpu
+def test_write_union_streams_32_lists_beyond_the_resident_share(tmp_path):
+    """glistmaker's collation width (reference src/glistmaker.c:787-835: up to 32 temporary lists into gt4_write_union):
+    32 lists of 2e5 records with a 1 MiB resident share -- about a hundred chunks -- against the oracle's loop
+    (reference src/set-operations.c:77-116), byte for byte, for two cutoffs; and the count-only form (ofile = 0)."""
+    import numpy as np
+    import oracle_lib as O
+    from genometester4_amd.listio import make_records, header_bytes
+    rng = np.random.default_rng(5)
+    universe = np.unique(rng.integers(0, 1 << 44, size=1_500_000, dtype=np.uint64))
+    lists, names = [], []
+    for j in range(32):
+        m = rng.random(len(universe)) < 0.15
+        rec = make_records(universe[m], rng.integers(1, 9, size=int(m.sum()), dtype=np.uint32))
+        lists.append(rec)
+        names.append("t%02d.list" % j)
+        write_list(os.path.join(tmp_path, names[-1]), rec, 22)
+    for cutoff in (1, 3):
+        rc_o, n_o, t_o, r_o = O.union_multi(lists, cutoff, 1, 1)  # rule ADD, cutoff on the sum
+        p = subprocess.run([SETOPS, "write_union", str(cutoff), "out.list"] + names, cwd=tmp_path, capture_output=True, timeout=600,
+                           env=dict(os.environ, GT4HIP_HBM_LIMIT="1M"))
+        assert p.returncode == 0, p.stderr.decode("latin-1")
+        assert p.stdout.decode() == "NUnique\t%d\nNTotal\t%d\nresult\t0\n" % (n_o, t_o)
+        with open(os.path.join(tmp_path, "out.list"), "rb") as fh:
+            got = fh.read()
+        assert got[:48] == header_bytes(22, n_o, t_o) and got[48:] == r_o.tobytes()
+        os.remove(os.path.join(tmp_path, "out.list"))
+
+
+@pytest.mark.gpu
 def test_cli_can_check_that_inputs_are_sorted(workdir):
     import numpy as np
     rec, k, _ = INPUTS["A8"]

@@ -1,11 +1,12 @@
 """End-to-end wall time of the drop-in CLI against the reference binary on files in /dev/shm
 (GPU box; not part of the product).
 
-    python tools/cli_e2e.py [records_per_list] [--no-ref]
+    python tools/cli_e2e.py [records_per_list] [--no-ref] [--modes=plain,chunks,gpus2,plain]
 
-Modes of the drop-in: plain (whole lists in HBM, one process), chunks (GT4HIP_HBM_LIMIT: key-range
-chunks through the loader / merger / writer pipeline), gpus2 (two worker processes on the visible
-device(s)), and the reference binary.  Prints one line per run and whether the outputs are identical."""
+Modes of the drop-in: plain (no environment variables: inputs of 4 GiB and more take the chunk pipeline with a
+budget the tool chooses, smaller ones stay in one piece), chunks (GT4HIP_HBM_LIMIT: key-range chunks through the
+loader / merger / writer pipeline with a quarter of the inputs in flight), gpus2 (two worker processes on the
+visible device(s)), and the reference binary.  Prints one line per run and whether the outputs are identical."""
 import os, subprocess, sys, time, shutil, tempfile, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -31,22 +32,26 @@ try:
     ours = os.path.join(ROOT, "genometester4_amd", "glistcompare")
     ref = os.path.join(ROOT, "oracle", "_ref", "glistcompare")
     limit = str(max(64 << 20, 12 * n // 2))  # about a quarter of the inputs in flight
-    modes = [("plain", ours, {}), ("chunks", ours, {"GT4HIP_HBM_LIMIT": limit}), ("gpus2", ours, {"GT4HIP_GPUS": "2", "GT4HIP_HBM_LIMIT": limit})]
-    if with_ref:
-        modes.append(("ref", ref, {}))
+    all_modes = {"plain": (ours, {}), "chunks": (ours, {"GT4HIP_HBM_LIMIT": limit}), "gpus2": (ours, {"GT4HIP_GPUS": "2", "GT4HIP_HBM_LIMIT": limit}),
+                 "oneshot": (ours, {"GT4HIP_PIPELINE": "0"}), "ref": (ref, {})}
+    all_modes["plain2"] = all_modes["plain"]  # the same again (first-run effects)
+    verbose = {"GT4HIP_VERBOSE": "1"} if "--verbose" in sys.argv else {}
+    order = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--modes=")]
+    order = order[0].split(",") if order else ["plain", "chunks", "gpus2"] + (["ref"] if with_ref else [])
+    modes = [(m, all_modes[m][0], all_modes[m][1]) for m in order]
     for tag, exe, env in modes:
         for args in (["-i", "--count_only"], ["-i", "-o", tag], ["-u", "-i", "-d", "-o", tag + "3"]):
             t0 = time.perf_counter()
-            r = subprocess.run([exe, "a.list", "b.list"] + args, cwd=d, capture_output=True, env=dict(os.environ, **env))
+            r = subprocess.run([exe, "a.list", "b.list"] + args, cwd=d, capture_output=True, env=dict(os.environ, **env, **verbose))
             dt = time.perf_counter() - t0
             print("%-7s %-24s rc %d  %.3f s  (%.1f M k-mers/s)" % (tag, " ".join(args[:-1] if "-o" in args else args), r.returncode, dt, 2 * n / dt / 1e6), flush=True)
             results.append(dict(mode=tag, args=args, rc=r.returncode, seconds=dt, k_mers_per_s=2 * n / dt))
-            if r.returncode:
-                print(r.stderr.decode()[-400:])
-        if tag != "plain":
-            same = all(subprocess.run(["cmp", "-s", os.path.join(d, x % tag), os.path.join(d, x % "plain")]).returncode == 0
+            if r.returncode or verbose:
+                print(r.stderr.decode()[-1500:])
+        if tag != order[0] and os.path.exists(os.path.join(d, "%s_25_intrsec.list" % order[0])):
+            same = all(subprocess.run(["cmp", "-s", os.path.join(d, x % tag), os.path.join(d, x % order[0])]).returncode == 0
                        for x in ("%s_25_intrsec.list", "%s3_25_union.list", "%s3_25_0_diff1.list", "%s3_25_intrsec.list"))
-            print("%-7s outputs identical to plain: %s" % (tag, same), flush=True)
+            print("%-7s outputs identical to %s: %s" % (tag, order[0], same), flush=True)
             results.append(dict(mode=tag, identical_to_plain=same))
             for x in ("%s_25_intrsec.list", "%s3_25_union.list", "%s3_25_0_diff1.list", "%s3_25_intrsec.list"):
                 os.remove(os.path.join(d, x % tag))
