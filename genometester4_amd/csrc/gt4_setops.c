@@ -167,6 +167,68 @@ unsigned int gt4_hip_word_list_word_length (const GT4HipWordList *list) { return
 const gt4hip_list *gt4_hip_word_list_device (const GT4HipWordList *list) { return list ? list->dev : NULL; } /* (NULL while a file-backed list is not uploaded) */
 int gt4_hip_word_list_is_file_backed (const GT4HipWordList *list) { return list && list->file_backed && !list->dev; }
 
+/* ------------------------------------------------------------------ the one-list iterator (src/word-list-sorted.c:59-78) */
+
+#define ITER_BLOCK (1u << 20)
+
+/* makes record it->idx the current one; 1 = ok */
+static unsigned int iter_load (GT4HipWordSListIter *it)
+{
+  GT4HipWordList *l = it->list;
+  const unsigned char *rec = NULL;
+  if (!l->dev && l->file_backed && l->file.records) {
+    rec = l->file.records + 12 * it->idx; /* the mapping itself (src/word-map.h:89-99) */
+  } else {
+    if (it->idx < it->block_first || it->idx >= it->block_first + it->block_count || !it->block) {
+      gt4hip_context *ctx = gt4_hip_default_context ();
+      if (!ctx || ensure_device (ctx, l, "gt4_hip_word_slist")) return 0;
+      if (!it->block) it->block = malloc ((size_t) ITER_BLOCK * 12u);
+      if (!it->block) return 0;
+      const uint64_t cnt = l->num_words - it->idx < ITER_BLOCK ? l->num_words - it->idx : ITER_BLOCK;
+      if (gt4hip_list_download_range (ctx, l->dev, it->idx, cnt, it->block)) {
+        fprintf (stderr, "gt4_hip_word_slist: %s\n", gt4hip_last_error (ctx));
+        return 0;
+      }
+      it->block_first = it->idx;
+      it->block_count = cnt;
+    }
+    rec = (const unsigned char *) it->block + 12 * (it->idx - it->block_first);
+  }
+  memcpy (&it->word, rec, 8);
+  memcpy (&it->count, rec + 8, 4);
+  return 1;
+}
+
+unsigned int gt4_hip_word_slist_get_first_word (GT4HipWordList *list, GT4HipWordSListIter *it)
+{
+  if (!list || !it) return 0;
+  memset (it, 0, sizeof *it);
+  it->list = list;
+  it->num_words = list->num_words;
+  it->sum_counts = list->sum_counts;
+  it->word_length = list->word_length;
+  it->idx = 0; /* :64 */
+  if (!it->num_words) return 0; /* :65 */
+  return iter_load (it);
+}
+
+unsigned int gt4_hip_word_slist_get_next_word (GT4HipWordSListIter *it)
+{
+  if (!it || !it->list) return 0;
+  if (it->idx >= it->num_words) return 0; /* :73 */
+  it->idx += 1;                           /* :74 */
+  if (it->idx >= it->num_words) return 0; /* :75: word and count stay those of the last record */
+  return iter_load (it);
+}
+
+void gt4_hip_word_slist_iter_release (GT4HipWordSListIter *it)
+{
+  if (!it) return;
+  free (it->block);
+  it->block = NULL;
+  it->block_count = 0;
+}
+
 static int write_fully (int fd, const void *buf, size_t len)
 {
   const char *p = (const char *) buf;
@@ -287,6 +349,8 @@ unsigned int gt4_write_union (GT4HipWordList *arrays[], unsigned int n_arrays, u
 }
 
 #define TABLE_CHUNK (1u << 20) /* table rows per download */
+static uint64_t WALK_BLOCK = 1ull << 24;  /* records of the pacing list per key-range block of a walk ...              */
+static uint64_t WALK_SINGLE = 1ull << 26; /* ... of lists with more records than this in all (tests: GT4HIP_WALK_BLOCK) */
 
 static unsigned int walk_table (gt4hip_context *ctx, gt4hip_count_table *t, GT4HipWordList *objs[], unsigned int n_objs, int quirk,
                                 unsigned int (*callback) (uint64_t, uint32_t *, void *), void *data)
@@ -339,18 +403,81 @@ static unsigned int table_walk (GT4HipWordList *objs[], unsigned int n_objs, int
   if (!ctx) return 1;
   for (unsigned int j = 0; j < n_objs; j++)
     if (ensure_device (ctx, objs[j], probe ? "gt4_is_union" : "gt4_union")) return 1;
+  {
+    const char *e = getenv ("GT4HIP_WALK_BLOCK"); /* tests: small blocks on small lists */
+    if (e && atoll (e) > 0) {
+      WALK_BLOCK = (uint64_t) atoll (e);
+      WALK_SINGLE = 0;
+    }
+  }
   const gt4hip_list **devs = (const gt4hip_list **) malloc (n_objs * sizeof *devs);
   if (!devs) return 1;
   for (unsigned int j = 0; j < n_objs; j++) devs[j] = objs[j]->dev;
-  gt4hip_count_table t;
-  int rc = probe ? gt4hip_probe_table (ctx, devs, n_objs, &t) : gt4hip_union_table (ctx, devs, n_objs, &t);
+  /* Long lists are walked in KEY-RANGE BLOCKS (the operations are key-local): the table of a block is built, handed
+   * to the callback row by row, freed, then the next block's -- the table never holds more than a block, and a
+   * callback that stops the walk (reference src/set-operations.c:176-178) stops the device work with it instead of
+   * paying for the whole union first.  Block boundaries: every WALK_BLOCK-th key of the list that paces the walk
+   * (gt4_is_union: list 0, whose keys are the rows; gt4_union: the longest), located in the other lists by lower
+   * bounds on the device. */
+  uint64_t total = 0;
+  unsigned int pace = 0;
+  for (unsigned int j = 0; j < n_objs; j++) {
+    total += objs[j]->num_words;
+    if (!probe && objs[j]->num_words > objs[pace]->num_words) pace = j;
+  }
+  const char *const who = probe ? "gt4_is_union" : "gt4_union";
+  const uint64_t n_pace = objs[pace]->num_words;
+  const uint64_t n_blocks = total > WALK_SINGLE && n_pace > WALK_BLOCK ? (n_pace + WALK_BLOCK - 1) / WALK_BLOCK : 1;
+  unsigned int result = 0;
+  int rc = 0;
+  if (n_blocks == 1) {
+    gt4hip_count_table t;
+    rc = probe ? gt4hip_probe_table (ctx, devs, n_objs, &t) : gt4hip_union_table (ctx, devs, n_objs, &t);
+    if (!rc) {
+      result = walk_table (ctx, &t, objs, n_objs, !probe, callback, data);
+      gt4hip_table_free (&t);
+    }
+  } else {
+    uint64_t *lo = (uint64_t *) calloc (n_objs, sizeof *lo), *hi = (uint64_t *) calloc (n_objs, sizeof *hi);
+    gt4hip_list **views = (gt4hip_list **) calloc (n_objs, sizeof *views);
+    if (!lo || !hi || !views) rc = 1;
+    for (uint64_t b = 0; b < n_blocks && !rc && !result; b++) {
+      /* [lo, hi) of every list: records with a key below the pacing list's key at (b + 1) * WALK_BLOCK */
+      if (b + 1 == n_blocks) {
+        for (unsigned int j = 0; j < n_objs; j++) hi[j] = objs[j]->num_words;
+      } else {
+        uint64_t cut_key = 0;
+        uint32_t c = 0;
+        rc = gt4hip_list_get_word (ctx, devs[pace], (b + 1) * WALK_BLOCK, &cut_key, &c);
+        for (unsigned int j = 0; j < n_objs && !rc; j++) {
+          if (j == pace) hi[j] = (b + 1) * WALK_BLOCK;
+          else rc = gt4hip_list_lower_bound (ctx, devs[j], cut_key, &hi[j]);
+        }
+      }
+      for (unsigned int j = 0; j < n_objs && !rc; j++) rc = gt4hip_list_slice (ctx, devs[j], lo[j], hi[j] - lo[j], &views[j]);
+      if (!rc) {
+        gt4hip_count_table t;
+        rc = probe ? gt4hip_probe_table (ctx, (const gt4hip_list *const *) views, n_objs, &t) : gt4hip_union_table (ctx, (const gt4hip_list *const *) views, n_objs, &t);
+        if (!rc) {
+          result = walk_table (ctx, &t, objs, n_objs, !probe, callback, data);
+          gt4hip_table_free (&t);
+        }
+      }
+      for (unsigned int j = 0; j < n_objs; j++) {
+        if (views && views[j]) gt4hip_list_free (views[j]);
+        if (views) views[j] = NULL;
+        lo[j] = hi[j];
+      }
+    }
+    free (lo);
+    free (hi);
+    free (views);
+  }
   free (devs);
   if (rc) {
-    fprintf (stderr, "%s: %s\n", probe ? "gt4_is_union" : "gt4_union", gt4hip_last_error (ctx));
+    fprintf (stderr, "%s: %s\n", who, gt4hip_last_error (ctx));
     return 1;
   }
-  unsigned int result = walk_table (ctx, &t, objs, n_objs, !probe, callback, data);
-  gt4hip_table_free (&t);
   return result;
 }
 

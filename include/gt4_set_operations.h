@@ -51,6 +51,26 @@ unsigned int gt4_hip_word_list_word_length (const GT4HipWordList *list);
 const gt4hip_list *gt4_hip_word_list_device (const GT4HipWordList *list); /* NULL while a file-backed list has not been uploaded */
 int gt4_hip_word_list_is_file_backed (const GT4HipWordList *list);
 
+/* The iterator of the reference's sorted word lists -- GT4WordSListInstance with get_first_word / get_next_word
+ * (src/word-list-sorted.h:42-57, src/word-list-sorted.c:59-78) -- over a GT4HipWordList, for callers that walk ONE
+ * list record by record (glistquery's statistics, src/glistquery.c:560-640): the records come to the host in
+ * blocks of 2^20 (from HBM, or straight from the mapping of a file-backed handle).  Same contract: both return 1
+ * while `word` / `count` hold a record and 0 at the end or on error; get_next_word on the last record returns 0
+ * WITHOUT touching word / count (callers test idx < num_words, as the reference's do). */
+typedef struct {
+  uint64_t num_words, sum_counts; /* of the list */
+  uint64_t idx;                   /* index of the current record */
+  uint64_t word;
+  uint32_t count;
+  unsigned int word_length;
+  GT4HipWordList *list;           /* private from here on */
+  void *block;
+  uint64_t block_first, block_count;
+} GT4HipWordSListIter;
+unsigned int gt4_hip_word_slist_get_first_word (GT4HipWordList *list, GT4HipWordSListIter *it);
+unsigned int gt4_hip_word_slist_get_next_word (GT4HipWordSListIter *it);
+void gt4_hip_word_slist_iter_release (GT4HipWordSListIter *it); /* frees the block (the list stays the caller's) */
+
 /* Combines N lists into one union (counts added, u32 wrap), keeps keys whose sum >= cutoff,
  * writes header + records to `ofile` when it is non-zero, always fills *header.
  * Returns 0 on success (reference src/set-operations.c:40-129). */

@@ -122,6 +122,18 @@ def test_set_operations_over_file_backed_handles_match_reference(case, workdir):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("block", ["1", "3", "50"])
+@pytest.mark.parametrize("case", [c for c in SETOPS_CASES if c["argv"][0] in ("union", "is_union", "union_stop")], ids=lambda c: c["id"])
+def test_walks_in_key_range_blocks_match_reference(case, block, workdir):
+    """gt4_union / gt4_is_union walk long lists in key-range blocks (a table per block, so that a callback that stops
+    the walk stops the device work too); GT4HIP_WALK_BLOCK forces blocks of 1, 3 and 50 records of the pacing list on
+    the goldens: same callbacks in the same order, the exhausted-list quirk and the early stop included."""
+    p = subprocess.run([SETOPS] + case["argv"], cwd=workdir, capture_output=True, timeout=300, env=dict(os.environ, GT4HIP_WALK_BLOCK=block))
+    assert p.returncode == case["exit"], (p.returncode, p.stderr.decode("latin-1"))
+    assert p.stdout.decode("latin-1") == case["stdout"]
+
+
+@pytest.mark.gpu
 def test_write_union_streams_32_lists_beyond_the_resident_share(tmp_path):
     """glistmaker's collation width (reference src/glistmaker.c:787-835: up to 32 temporary lists into gt4_write_union):
     32 lists of 2e5 records with a 1 MiB resident share -- about a hundred chunks -- against the oracle's loop
