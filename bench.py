@@ -192,7 +192,7 @@ MULTI = {
 }
 
 
-def multi_roofline(ctx, kind, n_in_local, n_out_local, device_ms, kernel_ms, one_pass, workload_n):
+def multi_roofline(ctx, kind, n_in_local, n_out_local, device_ms, kernel_ms, one_pass, workload_n, dist="stride"):
     """Rank 0's shard: algorithmic bytes (every input record read once, every output record written once).
     `frac` is over the average launch of the dominant kernel where ONE kernel does the work (the one-pass N-way
     tile kernel, HIP events on the library's stream); `whole_call_frac` over the whole call on the device (key
@@ -202,7 +202,7 @@ def multi_roofline(ctx, kind, n_in_local, n_out_local, device_ms, kernel_ms, one
     alg = 12 * (n_in_local + n_out_local)
     t_ms = kernel_ms if one_pass and kernel_ms > 0 else device_ms
     achieved = alg / (t_ms * 1e-3) / 1e9
-    traffic, traffic_source = load_traffic(kind, workload_n)
+    traffic, traffic_source = load_traffic(kind if dist == "stride" else "%s_%s" % (kind, dist), workload_n)
     if one_pass:
         kernel = "k_nway_merge<1024, 4, 1, NWAY_UNION> (one pass over up to eight lists per launch)"
     elif MULTI[kind]["op"] == "intersect":
@@ -389,7 +389,7 @@ def bench_multi(args, ctx, capi, rank, local_rank, world, kind="union8"):
                        "merge_only_ms_per_step": merge_only / args.steps * 1e3,
                        "gathered_bytes_per_step": 12 * (n_out - totals[0][0]) if has_comm else 0,
                        "note": "value includes the RCCL gatherv of the payload to rank 0; merge_only_* is the same job with every rank keeping (or writing) its own extent: BASELINE's >= 6x at 8 GPUs refers to merge_only"},
-            "roofline": multi_roofline(ctx, kind, n_local_in, totals[0][0], statistics.mean(dev_ms), statistics.mean(ker_ms), one_pass and n_lists <= 8, n8 if args.dist == "stride" else -1),
+            "roofline": multi_roofline(ctx, kind, n_local_in, totals[0][0], statistics.mean(dev_ms), statistics.mean(ker_ms), one_pass and n_lists <= 8, n8, args.dist),
             **({"cpu_baseline": cpu[0], "verified": cpu[1]} if cpu else {}),
         }
         bad = self_check(kind, args.dist, n8, args.k, n_out, total_out)
@@ -617,7 +617,7 @@ def bench_pair(args, ctx, capi, rank, world, torch, dist):
         k_ms = statistics.mean(kernel_ms)
         alg_bytes = 12 * (n_a + n_b) + 12 * n_out
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-        traffic, traffic_source = load_traffic(args.workload, n if args.dist == "stride" else -1)
+        traffic, traffic_source = load_traffic(args.workload if args.dist == "stride" else "%s_%s" % (args.workload, args.dist), n)
         names = {1: "union", 2: "intrsec", 4: "diff1"}
         shape = "two %d-entry k=%d lists (%.1f GB each, %s keys)" % (n, args.k, 12 * n / 1e9, args.dist)
         if args.workload == "intersect":

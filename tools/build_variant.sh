@@ -12,5 +12,5 @@ OBJS=""
 for f in gt4hip_kernels gt4hip_nway gt4hip_sort gt4hip_api gt4hip_io gt4hip_comm; do
   if [ "$f.hip" = "$SRC" ]; then OBJS="$OBJS /tmp/$f.$NAME.o"; else OBJS="$OBJS $f.hip.o"; fi
 done
-hipcc --offload-arch=gfx950 -shared -fPIC $OBJS gt4_listfile.o gt4_setops.o -o ../libgt4hip_$NAME.so -lpthread -ldl
+hipcc --offload-arch=gfx950 -shared -fPIC $OBJS gt4_listfile.o gt4_setops.o gt4_shard.o -o ../libgt4hip_$NAME.so -lpthread -ldl
 echo built libgt4hip_$NAME.so

@@ -11,7 +11,7 @@ import csv, glob, json, os, sys
 
 src, tag = sys.argv[1], sys.argv[2]
 workload = sys.argv[3] if len(sys.argv) > 3 else "intersect"
-ROUND = os.environ.get("GT4_ROUND", "round3")
+ROUND = os.environ.get("GT4_ROUND", "round4")
 dst = os.path.join(src, "summary")
 os.makedirs(dst, exist_ok=True)
 
@@ -68,6 +68,9 @@ if fetch and write:
     cand = [k for k in fetch if k.startswith("k_pair_merge") or k.startswith("k_nway") or k.startswith("k_radix")]
     if workload == "sort":
         cand = [k for k in cand if k.startswith("k_radix")]
+    if workload.startswith(("union", "table")) and any(k.startswith("k_nway_merge") for k in cand):
+        # the N-way workloads build their lists with the pair kernel (class unions): the tile kernel is what is measured
+        cand = [k for k in cand if k.startswith("k_nway")] or cand
     dom = max(cand, key=lambda k: sum(fetch[k].values()))
     fv = list(fetch[dom].values())
     wv = list(write.get(dom, {}).values())
@@ -93,7 +96,7 @@ if fetch and write:
                   "correction of MI355X_MICROARCH.md (HBM section); WRITE_SIZE as is",
         "source": ["profiles/%s/" % ROUND + os.path.basename(fpath), "profiles/%s/" % ROUND + os.path.basename(wpath)],
     }
-    if workload == "union8" and dom.startswith("k_nway_merge"):
+    if workload.startswith("union") and dom.startswith("k_nway_merge"):
         # one launch of the dominant instantiation per union; the call's other kernels (key samples, their
         # merges, the tile partition) are counted into the per-union figure
         unions = max(1, len(fv))
@@ -102,7 +105,7 @@ if fetch and write:
         tj["note"] = ("one launch of the one-pass N-way tile kernel per 8-way union (hbm_bytes_per_launch); the per-union figure adds "
                       "the sample, partition and sample-merge kernels of the call; the bench runs every step twice (with and without "
                       "the gather), so a PMC pass of --steps 2 --warmup 1 holds more unions than steps")
-    elif workload == "union8":
+    elif workload.startswith("union8"):
         # 7 pair merges per union: count the unions of the pass from the launches themselves
         launches = sum(len(fetch[k]) for k in cand)
         unions = max(1, launches // 7)
