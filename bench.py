@@ -192,13 +192,13 @@ MULTI = {
 }
 
 
-def multi_roofline(ctx, kind, n_in_local, n_out_local, device_ms, kernel_ms, one_pass, workload_n, dist="stride"):
+def multi_roofline(ctx, kind, n_in_local, n_out_local, device_ms, kernel_ms, one_pass, workload_n, dist="stride", moved=None):
     """Rank 0's shard: algorithmic bytes (every input record read once, every output record written once).
     `frac` is over the average launch of the dominant kernel where ONE kernel does the work (the one-pass N-way
     tile kernel, HIP events on the library's stream); `whole_call_frac` over the whole call on the device (key
     samples, their merges, tile partition, every launch) -- the only figure where the work is a chain or a tree
     of pair-kernel launches, and then `frac` equals it."""
-    rd, wr = ctx.last_multi_records
+    rd, wr = moved if moved else ctx.last_multi_records
     alg = 12 * (n_in_local + n_out_local)
     t_ms = kernel_ms if one_pass and kernel_ms > 0 else device_ms
     achieved = alg / (t_ms * 1e-3) / 1e9
@@ -354,6 +354,7 @@ def bench_multi(args, ctx, capi, rank, local_rank, world, kind="union8"):
     fence()
     merge_only = time.perf_counter() - t1
     one_pass = spec["op"] == "union" and bool(ctx.get_counter("nway_one_pass"))
+    moved = ctx.last_multi_records  # records the library read and wrote in the last timed call (before the CPU leg's small calls)
     per_rank = [{"rank": rank, "shard_input_records": n_local_in, "merge_ms": statistics.mean(x["merge"] for x in ms),
                  "exchange_and_gather_ms": statistics.mean(x["exchange_and_gather"] for x in ms)}]
     if world > 1:
@@ -389,7 +390,7 @@ def bench_multi(args, ctx, capi, rank, local_rank, world, kind="union8"):
                        "merge_only_ms_per_step": merge_only / args.steps * 1e3,
                        "gathered_bytes_per_step": 12 * (n_out - totals[0][0]) if has_comm else 0,
                        "note": "value includes the RCCL gatherv of the payload to rank 0; merge_only_* is the same job with every rank keeping (or writing) its own extent: BASELINE's >= 6x at 8 GPUs refers to merge_only"},
-            "roofline": multi_roofline(ctx, kind, n_local_in, totals[0][0], statistics.mean(dev_ms), statistics.mean(ker_ms), one_pass and n_lists <= 8, n8, args.dist),
+            "roofline": multi_roofline(ctx, kind, n_local_in, totals[0][0], statistics.mean(dev_ms), statistics.mean(ker_ms), one_pass and n_lists <= 8, n8, args.dist, moved),
             **({"cpu_baseline": cpu[0], "verified": cpu[1]} if cpu else {}),
         }
         bad = self_check(kind, args.dist, n8, args.k, n_out, total_out)

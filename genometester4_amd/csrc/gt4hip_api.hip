@@ -122,6 +122,8 @@ extern "C" void gt4hip_destroy (gt4hip_context *ctx)
   if (ctx->part) hipFree (ctx->part);
   if (ctx->kway_part) hipFree (ctx->kway_part);
   if (ctx->kway_cnt) hipFree (ctx->kway_cnt);
+  if (ctx->kway_part2) hipFree (ctx->kway_part2);
+  if (ctx->kway_need) hipFree (ctx->kway_need);
   if (ctx->desc) hipFree (ctx->desc);
   if (ctx->block_sums) hipFree (ctx->block_sums);
   if (ctx->ctl) hipFree (ctx->ctl);
@@ -182,6 +184,7 @@ extern "C" int gt4hip_get_counter (gt4hip_context *ctx, const char *name, uint64
   else if (!strcmp (name, "kway_calls")) *value = ctx->kway_calls;
   else if (!strcmp (name, "kway_overflows")) *value = ctx->kway_overflows;
   else if (!strcmp (name, "kway_declined")) *value = ctx->kway_declined;
+  else if (!strcmp (name, "kway_splits")) *value = ctx->kway_splits;
   else if (!strcmp (name, "nway_kernel_us")) *value = (uint64_t) (ctx->nway_kernel_ms * 1000.0);
   else if (!strcmp (name, "nway_tiles")) *value = ctx->nway_tiles;
   else if (!strcmp (name, "nway_one_pass")) *value = (uint64_t) ctx->last_multi_one_pass;

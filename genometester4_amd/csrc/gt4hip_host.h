@@ -46,6 +46,11 @@ struct gt4hip_context {
   size_t kway_part_bytes;
   void *kway_cnt;            /* samples of every list per bracket of 64 tiles */
   size_t kway_cnt_bytes;
+  uint64_t *kway_part2;      /* the boundaries with the tiles that would not fit LDS cut in two (the table the tile kernel reads) */
+  size_t kway_part2_bytes;
+  void *kway_need;           /* tiles each nominal tile becomes (u32), block sums (u32) */
+  size_t kway_need_bytes;
+  uint64_t kway_splits;      /* counter "kway_splits": tiles cut in two by the last N-way call */
   int kway_enabled;          /* option "kway": 0 = always the pairwise tree, 1 = the one-pass kernel unless the keys are clustered, 2 = always, also for two lists, 3 = always (three lists and more) */
   int64_t kway_g;            /* option "kway_g": samples per tile (0 = automatic) */
   int64_t kway_vt;           /* option "kway_vt": positions per thread in a merge pass, at least (0 = default) */

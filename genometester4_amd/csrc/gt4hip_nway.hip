@@ -42,8 +42,9 @@
  *                             go left), plus the tile's key range, interpolation constants and whether its samples
  *                             look clustered; k_nway_partition: the same by searches over brackets of 64 tiles (the
  *                             topmost level, which has no merged samples; option "kway_vt" = 97)
- *      k_nway_check           no tile may exceed the LDS capacity (else the host retries with fewer samples
- *                             per tile, down to the number for which it cannot happen)
+ *      k_nway_need, _need_scan, a tile that would exceed the LDS capacity is cut in two at the middle key of its longest run
+ *      k_nway_emit            (more than two pieces: the host retries with fewer samples per tile, down to the number for
+ *                             which it cannot happen)
  *   K7 k_nway_merge           the tile kernel; NWAY_DUPS keeps every record and remembers its list (it is how the
  *                             sample lists themselves are merged, one level up: the recursion ends when a level
  *                             fits one tile), NWAY_UNION / NWAY_COUNT fold equal keys and apply the rule,
@@ -67,6 +68,9 @@ constexpr int NWAY_MAX = 8;       /* lists per launch */
 #endif
 constexpr int NWAY_SAMPLE = GT4_NWAY_SAMPLE; /* S: one sample per S records */
 constexpr int NWAY_PSTRIDE = 10;  /* u64 per tile boundary in the partition table: eight cuts, the tile's smallest possible key, interpolation constants */
+#ifndef GT4_NWAY_MARGIN
+#define GT4_NWAY_MARGIN 5.0 /* standard deviations of a tile's size kept free at the first try.  2.5 (27 samples per tile instead of 24, 7 % of the tiles cut in two) measured 36.4 ms against 30.1: fuller tiles give the service wavefront records of its own */
+#endif
 #ifndef GT4_NWAY_LIMIT
 #define GT4_NWAY_LIMIT 48
 #endif
@@ -477,20 +481,173 @@ __global__ __launch_bounds__ (256) void k_nway_probe (const u32 *__restrict__ li
   if (threadIdx.x == 0 && 10u * same_s > 6u * NWAY_PROBE_KEYS) atomicAdd (flagged, 1u);
 }
 
-/* a tile fits when its records fit the position space with every run rounded up to whole wavefronts */
-__global__ void k_nway_check (const u64 *__restrict__ part, u32 num_tiles, u32 cap, u32 *flag)
+/* ---- Tiles that would not fit LDS are cut in two (round 4).  A tile holds G merged samples' worth of records
+ * plus what the lists' offsets against their sample grids add (sigma = S sqrt (k / 6) records); G sits five sigma
+ * below the capacity.  Round 3 repeated the whole partition with fewer samples per tile when any tile overflowed
+ * all the same (lists of very different density); now such a tile is cut at the middle key of its longest run and
+ * only a tile that needs more than two pieces sends the call back.  (Fuller tiles -- G two and a half sigma below,
+ * one tile in fourteen cut -- were the reason to build this and measured SLOWER: GT4_NWAY_MARGIN.)
+ *   k_nway_need    per nominal tile: 1, or 2 when its wave slots exceed the capacity (more than two: the old retry);
+ *                  sums per block of NWAY_SPLIT_BLOCK tiles
+ *   k_nway_need_scan  exclusive prefix over the blocks (one workgroup)
+ *   k_nway_emit    the final table: row base + prefix inside the block; the second half's cuts by eight
+ *                  upper bounds of the pivot key inside the tile's runs, key ranges and bucket constants per half */
+constexpr u32 NWAY_SPLIT_BLOCK = 1024;
+
+__device__ __forceinline__ u64 nway_bucket_consts (u64 lo, u64 hi, u32 n_buckets)
 {
-  const u64 t = (u64) blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= num_tiles) return;
+  const u64 D = hi >= lo ? hi - lo : 0ull;
+  const u32 bl = D ? 64u - (u32) __builtin_clzll (D) : 0u;
+  const u32 sh = bl > 32u ? bl - 32u : 0u;
+  const u32 vmax = (u32) (D >> sh);
+  const bool direct = vmax < n_buckets;
+  const u32 mul = direct ? 0u : (u32) (((u64) n_buckets << 32) / ((u64) vmax + 1ull));
+  return (u64) sh | (direct ? 1ull << 8 : (u64) mul << 32);
+}
+
+__device__ __forceinline__ u32 nway_tile_slots (const u64 *__restrict__ part, u64 t, bool *mono)
+{
   u64 slots = 0;
-  bool mono = true;
   for (int i = 0; i < NWAY_MAX; i++) {
     const u64 a = part[t * NWAY_PSTRIDE + i], b = part[(t + 1) * NWAY_PSTRIDE + i];
-    mono &= b >= a;
+    *mono &= b >= a;
     slots += (b - a + WAVE - 1) / WAVE;
   }
-  if (slots * WAVE > cap || !mono) atomicOr (flag, 1u);
-  if ((part[t * NWAY_PSTRIDE + NWAY_MAX + 1] >> 9) & 1ull) atomicAdd (flag + 1, 1u); /* the partition found the tile's samples clustered */
+  return slots > 0xffffffffull ? 0xffffffffu : (u32) slots;
+}
+
+/* flag[0]: a tile needs more than two pieces (or the table is not monotone); flag[1]: tiles whose samples look
+ * clustered; flag[2]: tiles cut in two */
+__global__ __launch_bounds__ (NWAY_SPLIT_BLOCK) void k_nway_need (const u64 *__restrict__ part, u32 num_tiles, u32 nch, u32 *__restrict__ need, u32 *__restrict__ block_sums, u32 *flag)
+{
+  __shared__ u32 ws[NWAY_SPLIT_BLOCK / WAVE];
+  const u64 t = (u64) blockIdx.x * NWAY_SPLIT_BLOCK + threadIdx.x;
+  u32 v = 0;
+  if (t < num_tiles) {
+    bool mono = true;
+    const u32 slots = nway_tile_slots (part, t, &mono);
+    v = slots <= nch ? 1u : 2u;
+    if (!mono || slots > 2 * nch - 2 * NWAY_MAX) atomicOr (flag, 1u); /* (each half rounds every run up once more) */
+    if ((part[t * NWAY_PSTRIDE + NWAY_MAX + 1] >> 9) & 1ull) atomicAdd (flag + 1, 1u);
+    if (v == 2u) atomicAdd (flag + 2, 1u);
+    need[t] = v;
+  }
+  v = dpp_wave_sum_u32 (v);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x / WAVE] = v;
+  __syncthreads ();
+  if (threadIdx.x == 0) {
+    u32 sum = 0;
+    for (u32 w = 0; w < NWAY_SPLIT_BLOCK / WAVE; w++) sum += ws[w];
+    block_sums[blockIdx.x] = sum;
+  }
+}
+
+__global__ __launch_bounds__ (1024) void k_nway_need_scan (u32 *__restrict__ block_sums, u32 n_blocks, u32 *__restrict__ total)
+{
+  __shared__ u32 wsum[16];
+  __shared__ u32 carry_s;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads ();
+  for (u32 b0 = 0; b0 < n_blocks; b0 += 1024) {
+    const u32 i = b0 + threadIdx.x;
+    const u32 v = i < n_blocks ? block_sums[i] : 0u;
+    const u32 incl = dpp_inclusive_scan_u32 (v);
+    if (lane == 63) wsum[wid] = incl;
+    __syncthreads ();
+    u32 before = 0, all = 0;
+    for (int w = 0; w < 16; w++) {
+      const u32 x = wsum[w];
+      before += w < wid ? x : 0u;
+      all += x;
+    }
+    const u32 c = carry_s;
+    if (i < n_blocks) block_sums[i] = c + before + incl - v;
+    __syncthreads ();
+    if (threadIdx.x == 0) carry_s = c + all;
+    __syncthreads ();
+  }
+  if (threadIdx.x == 0) *total = carry_s;
+}
+
+__global__ __launch_bounds__ (NWAY_SPLIT_BLOCK) void k_nway_emit (NwayParams p, const u64 *__restrict__ part, u32 num_tiles, const u32 *__restrict__ need, const u32 *__restrict__ block_base,
+                                                                 u32 n_buckets, u32 nch, u64 *__restrict__ out, u32 *flag)
+{
+  __shared__ u32 ws[NWAY_SPLIT_BLOCK / WAVE];
+  const u64 t = (u64) blockIdx.x * NWAY_SPLIT_BLOCK + threadIdx.x;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const u32 v = t < num_tiles ? need[t] : 0u;
+  const u32 incl = dpp_inclusive_scan_u32 (v);
+  if (lane == 63) ws[wid] = incl;
+  __syncthreads ();
+  u32 before = block_base[blockIdx.x];
+  for (int w = 0; w < wid; w++) before += ws[w];
+  const u64 at = (u64) before + incl - v; /* the tile's (first) row in the final table */
+  if (t == num_tiles) { /* the lists' ends */
+    for (int i = 0; i < NWAY_PSTRIDE; i++) out[at * NWAY_PSTRIDE + i] = part[t * NWAY_PSTRIDE + i];
+    return;
+  }
+  if (t > num_tiles) return;
+  u64 row[NWAY_PSTRIDE];
+  for (int i = 0; i < NWAY_PSTRIDE; i++) row[i] = part[t * NWAY_PSTRIDE + i];
+  if (v == 1u) {
+    for (int i = 0; i < NWAY_PSTRIDE; i++) out[at * NWAY_PSTRIDE + i] = row[i];
+    return;
+  }
+  /* two pieces: the pivot is the middle key of the tile's longest run; keys <= pivot go left (equal keys of different
+   * lists stay together) */
+  u64 end[NWAY_MAX];
+  u32 longest = 0;
+  u64 best = 0;
+  for (int i = 0; i < NWAY_MAX; i++) {
+    end[i] = part[(t + 1) * NWAY_PSTRIDE + i];
+    if ((u32) i < p.k && end[i] - row[i] > best) {
+      best = end[i] - row[i];
+      longest = (u32) i;
+    }
+  }
+  const u64 pivot = load_key (p.list[longest], row[longest] + (best - 1) / 2);
+  u64 mid[NWAY_MAX];
+  for (u32 i = 0; i < NWAY_MAX; i++) {
+    u64 lo = row[i], hi = end[i];
+    if (i >= p.k) {
+      mid[i] = row[i];
+      continue;
+    }
+    while (lo < hi) {
+      const u64 m = (lo + hi) >> 1;
+      if (load_key (p.list[i], m) <= pivot) lo = m + 1;
+      else hi = m;
+    }
+    mid[i] = lo;
+  }
+  /* the tile's largest possible key: the next tile's smallest minus one; the last tile ends at the lists' largest key */
+  u64 hi_key;
+  if (t + 1 < num_tiles) {
+    hi_key = part[(t + 1) * NWAY_PSTRIDE + NWAY_MAX] - 1ull;
+  } else {
+    hi_key = 0;
+    for (u32 j = 0; j < p.k; j++)
+      if (p.n[j]) {
+        const u64 l = load_key (p.list[j], p.n[j] - 1);
+        hi_key = l > hi_key ? l : hi_key;
+      }
+  }
+  const u64 clustered = row[NWAY_MAX + 1] & (1ull << 9);
+  for (int i = 0; i < NWAY_MAX; i++) out[at * NWAY_PSTRIDE + i] = row[i];
+  out[at * NWAY_PSTRIDE + NWAY_MAX] = row[NWAY_MAX];
+  out[at * NWAY_PSTRIDE + NWAY_MAX + 1] = nway_bucket_consts (row[NWAY_MAX], pivot, n_buckets) | clustered;
+  for (int i = 0; i < NWAY_MAX; i++) out[(at + 1) * NWAY_PSTRIDE + i] = mid[i];
+  out[(at + 1) * NWAY_PSTRIDE + NWAY_MAX] = pivot + 1ull; /* (pivot < hi_key: the right piece holds a larger key) */
+  out[(at + 1) * NWAY_PSTRIDE + NWAY_MAX + 1] = nway_bucket_consts (pivot + 1ull, hi_key, n_buckets) | clustered;
+  /* a piece that still does not fit (runs of very different length: the pivot halves the longest only) sends the
+   * call back to fewer samples per tile */
+  u64 s0 = 0, s1 = 0;
+  for (int i = 0; i < NWAY_MAX; i++) {
+    s0 += (mid[i] - row[i] + WAVE - 1) / WAVE;
+    s1 += (end[i] - mid[i] + WAVE - 1) / WAVE;
+  }
+  if (s0 > nch || s1 > nch) atomicOr (flag, 1u);
 }
 
 /* rows before every tile = exclusive prefix of the tiles' distinct keys (one workgroup walks the array) */
@@ -1540,11 +1697,12 @@ int nway_grow (gt4hip_context *ctx, void **p, size_t *have, size_t need)
 /* samples per tile: a tile between two boundary keys G samples apart holds at most G + k - 1 samples
  * (ties at the boundaries), each list at most (its samples + 1) * S - 1 records, every run rounded up
  * to whole wavefronts.  `sure`: the G for which no tile can overflow; the first try takes the expected
- * tile (G * S records) plus five standard deviations of the lists' offsets against their sample grids. */
+ * tile (G * S records) plus GT4_NWAY_MARGIN (five) standard deviations of the lists' offsets against their sample grids; tiles beyond the
+ * capacity are cut in two (k_nway_emit). */
 void nway_samples_per_tile (u32 k, u32 *first_try, u32 *sure)
 {
   const double cap = (double) NWAY_CAP - 32.0 * k; /* half a wavefront of padding per run, on average */
-  const double margin = 5.0 * NWAY_SAMPLE * sqrt ((double) k / 6.0);
+  const double margin = GT4_NWAY_MARGIN * NWAY_SAMPLE * sqrt ((double) k / 6.0);
   long g1 = (long) ((cap - margin) / NWAY_SAMPLE);
   long g0 = ((long) NWAY_CAP - 64L * k) / NWAY_SAMPLE - (2L * k - 1);
   if (g0 < 1) g0 = 1;
@@ -1640,6 +1798,7 @@ static int nway_run (gt4hip_context *ctx, const gt4hip_list *const lists[], uint
     const u64 m_total = merged ? merged->n_words : 0;
     u32 G = g_try;
     u64 tiles = 1;
+    const u64 *part_final = NULL; /* the table the tile kernel reads: the partition's, or the one with the split tiles */
     for (;;) {
       tiles = m_total ? m_total / G + 2 : 1;
       if (tiles >= 0xfffffff0ull) {
@@ -1662,17 +1821,47 @@ static int nway_run (gt4hip_context *ctx, const gt4hip_list *const lists[], uint
           hipLaunchKernelGGL (k_nway_partition, dim3 ((unsigned) ((threads + 255) / 256)), dim3 (256), 0, st, lv.p, merged ? (const u32 *) merged->dev : NULL,
                               m_total, G, (u32) (NWAY_NBF * NWAY_CAP), (u64 *) ctx->kway_part, pass);
       }
+      /* tiles that do not fit are cut in two (k_nway_need / _scan / _emit): flags = { more than two pieces,
+       * clustered tiles, tiles cut, tiles of the final table } */
+      const u64 n_blocks = (tiles + 1 + NWAY_SPLIT_BLOCK - 1) / NWAY_SPLIT_BLOCK;
+      if ((rc = nway_grow (ctx, (void **) &ctx->kway_need, &ctx->kway_need_bytes, (size_t) (tiles + 1 + n_blocks + 4) * 4))) break;
+      u32 *const need = (u32 *) ctx->kway_need, *const block_sums = need + tiles + 1;
       hipMemsetAsync (ctx->scratch, 0, 64, st);
-      hipLaunchKernelGGL (k_nway_check, dim3 ((unsigned) ((tiles + 255) / 256)), dim3 (256), 0, st, (const u64 *) ctx->kway_part, (u32) tiles, (u32) NWAY_CAP,
+      hipLaunchKernelGGL (k_nway_need, dim3 ((unsigned) n_blocks), dim3 (NWAY_SPLIT_BLOCK), 0, st, (const u64 *) ctx->kway_part, (u32) tiles, (u32) (NWAY_CAP / WAVE), need, block_sums,
                           (u32 *) ctx->scratch);
-      hipError_t e = hipMemcpyAsync (ctx->scratch_host, ctx->scratch, 8, hipMemcpyDeviceToHost, st);
+      hipLaunchKernelGGL (k_nway_need_scan, dim3 (1), dim3 (1024), 0, st, block_sums, (u32) n_blocks, (u32 *) ctx->scratch + 3);
+      hipError_t e = hipMemcpyAsync (ctx->scratch_host, ctx->scratch, 16, hipMemcpyDeviceToHost, st);
       if (e == hipSuccess) e = hipStreamSynchronize (st);
       if (e != hipSuccess) {
         rc = gt4hip_fail (ctx, GT4HIP_EHIP, "N-way partition failed: %s", hipGetErrorString (e));
         break;
       }
-      if (!(ctx->scratch_host[0] & 0xffffffffu)) {
-        if (l == 0 && may_decline && tiles >= 64 && 5ull * (ctx->scratch_host[0] >> 32) > tiles) {
+      const u32 *const fl = (const u32 *) ctx->scratch_host;
+      bool overflow = fl[0] != 0;
+      part_final = (const u64 *) ctx->kway_part;
+      if (!overflow && fl[2]) {
+        const u64 tiles2 = fl[3];
+        if ((rc = nway_grow (ctx, (void **) &ctx->kway_part2, &ctx->kway_part2_bytes, (size_t) (tiles2 + 1) * NWAY_PSTRIDE * 8))) break;
+        hipLaunchKernelGGL (k_nway_emit, dim3 ((unsigned) n_blocks), dim3 (NWAY_SPLIT_BLOCK), 0, st, lv.p, (const u64 *) ctx->kway_part, (u32) tiles, need, block_sums,
+                            (u32) (NWAY_NBF * NWAY_CAP), (u32) (NWAY_CAP / WAVE), (u64 *) ctx->kway_part2, (u32 *) ctx->scratch);
+        e = hipMemcpyAsync (ctx->scratch_host + 4, ctx->scratch, 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize (st);
+        if (e != hipSuccess) {
+          rc = gt4hip_fail (ctx, GT4HIP_EHIP, "N-way partition failed: %s", hipGetErrorString (e));
+          break;
+        }
+        overflow = (u32) ctx->scratch_host[4] != 0;
+        if (!overflow) {
+          if (l == 0) ctx->kway_splits = fl[2];
+          part_final = (const u64 *) ctx->kway_part2;
+          tiles = tiles2;
+          lv.p.num_tiles = (u32) tiles;
+        }
+      } else if (!overflow && l == 0) {
+        ctx->kway_splits = 0;
+      }
+      if (!overflow) {
+        if (l == 0 && may_decline && tiles >= 64 && 5ull * fl[1] > tiles) {
           /* the probe of the longest list did not see it, the tiles' own samples do: clustered keys */
           ctx->kway_declined++;
           if (merged) gt4hip_list_free (merged);
@@ -1735,7 +1924,7 @@ static int nway_run (gt4hip_context *ctx, const gt4hip_list *const lists[], uint
     }
     hipMemsetAsync (ctx->ctl, 0, sizeof (PairControl), st);
     if (l == 0) hipEventRecord (ctx->ev[1], st);
-    hipError_t e = launch_nway_mode (st, mode, grid, lv.p, (const u64 *) ctx->kway_part, dst, (u64 *) ctx->desc, ctx->ctl);
+    hipError_t e = launch_nway_mode (st, mode, grid, lv.p, part_final, dst, (u64 *) ctx->desc, ctx->ctl);
     if (e != hipSuccess) {
       rc = gt4hip_fail (ctx, GT4HIP_EHIP, "N-way merge launch failed: %s", hipGetErrorString (e));
       break;
@@ -1795,7 +1984,7 @@ static int nway_run (gt4hip_context *ctx, const gt4hip_list *const lists[], uint
           int g2 = ctx->n_cus * nway_blocks_per_cu (NWAY_TABLE);
           if ((u64) g2 > tiles) g2 = (int) tiles;
           hipMemsetAsync (ctx->ctl, 0, sizeof (PairControl), st);
-          e = launch_nway_mode (st, NWAY_TABLE, g2, lv.p, (const u64 *) ctx->kway_part, NULL, (u64 *) ctx->desc, ctx->ctl);
+          e = launch_nway_mode (st, NWAY_TABLE, g2, lv.p, part_final, NULL, (u64 *) ctx->desc, ctx->ctl);
           if (e == hipSuccess) e = hipMemcpyAsync (ctx->ctl_host, ctx->ctl, sizeof (PairControl), hipMemcpyDeviceToHost, st);
           if (e == hipSuccess) e = hipStreamSynchronize (st);
           if (e != hipSuccess || ctx->ctl_host->error) {

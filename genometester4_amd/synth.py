@@ -180,10 +180,15 @@ def _ancestor(length, seed, repeat_frac=0.05, repeat_len=1000):
     # planted repeats: segments copied to other places (k-mers with more than one occurrence)
     n_rep = int(length * repeat_frac / repeat_len)
     if n_rep and length > 4 * repeat_len:
-        src = torch.randint(0, length - repeat_len, (n_rep,), generator=g, device="cuda").tolist()
-        dst = torch.randint(0, length - repeat_len, (n_rep,), generator=g, device="cuda").tolist()
-        for a, b in zip(src, dst):
-            seq[b: b + repeat_len] = seq[a: a + repeat_len].clone()
+        # (a handful of gathers, not one copy per repeat: tens of thousands of tiny launches are slow, and rocprofv3's
+        # counter passes do not survive them)
+        off = torch.arange(repeat_len, dtype=torch.int64, device="cuda")
+        step = max(1, (1 << 24) // repeat_len)
+        for i in range(0, n_rep, step):
+            m = min(step, n_rep - i)
+            src = torch.randint(0, length - repeat_len, (m,), generator=g, device="cuda")
+            dst = torch.randint(0, length - repeat_len, (m,), generator=g, device="cuda")
+            seq[(dst[:, None] + off).reshape(-1)] = seq[(src[:, None] + off).reshape(-1)]
     return seq
 
 

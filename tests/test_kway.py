@@ -163,6 +163,25 @@ def test_clustered_keys(ctx):
     _check(ctx, lists, k=25)
 
 
+@pytest.mark.parametrize("g", [28, 30, 34])
+def test_tiles_that_do_not_fit_are_cut_in_two(ctx, g):
+    """More samples per tile than the capacity takes on average (option kway_g): about half of the tiles exceed the 64 wave
+    slots and are cut at the middle key of their longest run (k_nway_need / _emit; counter kway_splits) -- same bytes
+    as the oracle's, no retry with fewer samples."""
+    rng = np.random.default_rng(g)
+    lists = _random_lists(rng, 8, 400000, zero_counts=False)
+    ctx.set_option("kway_g", g)
+    try:
+        before = ctx.get_counter("kway_overflows")
+        _check(ctx, lists, k=20)
+        assert ctx.get_counter("kway_splits") > 0
+        if g <= 30:
+            assert ctx.get_counter("kway_overflows") == before
+        _check(ctx, lists, k=20, rule=4, cutoff=2)
+    finally:
+        ctx.set_option("kway_g", 0)
+
+
 def test_default_setting_hands_clustered_keys_to_the_tree(ctx):
     """Option kway = 1 (the default): a probe of the longest list's keys sees stretches of adjacent keys between
     wide gaps and the call takes the pairwise tree -- same bytes, counter kway_declined; evenly spread keys of the
