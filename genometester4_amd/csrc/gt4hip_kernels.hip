@@ -444,7 +444,8 @@ struct TileRange {
  * coefficient form -- 1: the reference predicate with the operation's default rule (union: ADD,
  * intersection: MIN, first complement: SUBTRACT without -du; any-combination kernel: every
  * requested stream on its default rule), any cutoff; 2 / 3: ADD keeping every key / every sum
- * >= cutoff (intermediate and final N-way union levels). */
+ * >= cutoff (intermediate and final N-way union levels), and for the intersection the running minimum
+ * of intersect_multi's chain keeping every shared key / every count >= cutoff. */
 /* OPSET != 0 (any-combination kernel only): the set of output streams fixed at compile time -- the
  * other streams' code, registers and scalar branches disappear (glistcompare -u -d, BASELINE config 2) */
 template <int NT, int IPT, int MODE, int OPS, int FAST = 0, int OPSET = 0>
@@ -860,9 +861,16 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
              * lane), and the kept records are decided by the match alone */
             u32 f;
             bool keep;
-            if (OPS == 2) {
+            if (OPS == 2 && FAST == 1) {
               f = own[u] < ocnt ? own[u] : ocnt;                  /* MIN */
               keep = matched && f >= (p.cutoff ? p.cutoff : 1u); /* both counts >= cutoff <=> min >= cutoff; and min != 0 */
+            } else if (OPS == 2) {
+              /* FAST = 2 / 3: a step of intersect_multi's left-to-right chain (reference src/glistcompare.c:655-678): the
+               * running minimum restarts at 0 (`if (!freq || c < freq) freq = c`, :669 = RULE_MINZ); intermediate steps
+               * keep every shared key (FAST = 2), the last one those whose count reaches the cutoff (FAST = 3, :683) */
+              const u32 mn = own[u] < ocnt ? own[u] : ocnt;
+              f = own[u] == 0u ? ocnt : mn;
+              keep = matched && (FAST == 2 || f >= p.cutoff);
             } else {
               const u32 xb = matched ? ocnt : 0u;
               f = own[u] - xb;                                   /* SUBTRACT: kept only when f1 >= cutoff > f2 */
@@ -1293,6 +1301,8 @@ static int fast_variant (int ops_cls, const PairParams &p)
     if (ops_cls == 4 && p.rule[2] == 2u && !p.subtract) fast = 1;
   } else if (ops_cls == 1 && p.rule[0] == 1u) {
     fast = p.filter == FILTER_RAW ? 2 : 3; /* N-way union levels: keep every key / keep sums >= cutoff (union_multi, :574) */
+  } else if (ops_cls == 2 && p.rule[1] == RULE_MINZ) {
+    fast = p.filter == FILTER_RAW ? 2 : 3; /* the steps of intersect_multi's chain under its default rule (:655-683) */
   }
   /* any combination of outputs with every requested stream on its default rule, any cutoff, no -du */
   if (ops_cls == 0 && p.filter == FILTER_REFERENCE && !p.subtract && (!(p.ops & 1u) || p.rule[0] == 1u) && (!(p.ops & 2u) || p.rule[1] == 3u) &&
@@ -1308,7 +1318,7 @@ static hipError_t launch_pair_merge_ops (hipStream_t s, int mode, int grid, cons
 {
   /* the commonest single-output calls take the variant with the rule folded in (see FAST) */
   const int fast = fast_variant (OPS, p);
-  constexpr int F1 = 1, F2 = OPS == 1 ? 2 : 0, F3 = OPS == 1 ? 3 : 0;
+  constexpr int F1 = 1, F2 = (OPS == 1 || OPS == 2) ? 2 : 0, F3 = (OPS == 1 || OPS == 2) ? 3 : 0;
 #define GT4_LAUNCH_MERGE(M, F) hipLaunchKernelGGL ((k_pair_merge<NT, merge_ipt (NT, OPS), M, OPS, F>), dim3 (grid), dim3 (NT), 0, s, A, nA, B, nB, (u64 *) part, num_tiles, p, o, desc, ctl)
   if (OPS == 0 && fast == 1 && (p.ops == 3u || p.ops == 5u || p.ops == 15u) && (mode == MODE_COUNT ? NT == 512 : NT == 1024)) {
     /* the commonest output sets with the default rules (-u -i, -u -d, all four): the stream set is a
