@@ -1021,6 +1021,7 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
      * whole loop (hoisted by the compiler), which had the rank walk's registers spill */
     asm volatile ("" : "+v"(tid));
     lane = tid & (WAVE - 1);
+    PHASE_STAMP (23); /* (diagnostics: the back edge) */
     u32 cur, n, slots, bk0, bk_mul;
     u64 key_lo, out_base;
     {
@@ -1059,6 +1060,11 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
         cnt[k] = pre[k].z;
       }
     }
+    PHASE_STAMP (19); /* (diagnostics: the tile's header) */
+#ifdef GT4_PROFILE_PHASES
+    asm volatile ("s_waitcnt vmcnt(0)" ::: "memory"); /* (the diagnostics build takes the wait for the prefetched records here) */
+#endif
+    PHASE_STAMP (20); /* (diagnostics: the wait for the prefetched records) */
     u32 xagg = 0;
     u64 xcarry = 0;
     u32 st[RPT];
@@ -1297,6 +1303,7 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
       }
       count_pass (bk); /* (the atomics first: their round trip overlaps what follows) */
     }
+    PHASE_STAMP (21); /* (bucket numbers, counting atomics returned) */
     /* the next tile's records: asked for as soon as this tile's have left the registers, a whole
      * iteration before they are looked at (its table was written during the previous iteration).  One
      * tile per workgroup is all that is in flight. */
@@ -1304,6 +1311,7 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
       const u32 nxt = uniform32 (sh.hdr[tb1][0]);
       if (nxt < ntl && (u32) (wid * RPT) < uniform32 (sh.hdr[tb1][2])) fetch (tb1);
     }
+    PHASE_STAMP (22); /* (the next tile's fetch issued) */
     /* the ordered tile: counts 0, nothing live */
     for (int i = 4 * tid; i < CAPS; i += 4 * NT) *reinterpret_cast<u32x4 *> (&sh.s.scnt[i]) = u32x4 { 0, 0, 0, 0 };
     for (int i = tid; i < (CAPS + 3) / 4; i += NT) sh.live[i] = 0;
@@ -1954,11 +1962,11 @@ static int nway_run (gt4hip_context *ctx, const gt4hip_list *const lists[], uint
     if (l == 0) {
 #ifdef GT4_PROFILE_PHASES
       {
-        static const char *names[24] = { "p0 wait+bucket+atomic+zero", "B1", "scan1", "B2", "scan2+fetch issue", "B3", "group", "B4", "clear+rank", "fold", "service", "B5", "writeout", "order", "B6", "stage+publish", "sv:-", "sv:table", "sv:ticket+row", "sv:try writeout", "-", "-", "-", "-" };
+        static const char *names[24] = { "p0: zeroing", "B1", "scan1", "B2", "scan2", "B3", "group", "B4", "rank", "fold", "service", "B5", "writeout+fill", "order", "B6", "stage+publish", "sv:-", "sv:table", "sv:ticket+row", "sv:try writeout | header", "p0: wait for records", "p0: buckets+atomics", "p0: fetch issue", "back edge" };
         unsigned long long tot = 0;
         for (int i = 0; i < 24; i++) tot += ctx->ctl_host->phase_cycles[i];
         fprintf (stderr, "[nway phases] tiles %llu:", (unsigned long long) tiles);
-        for (int i = 0; i < 20; i++) fprintf (stderr, " %s %.1f%%", names[i], tot ? 100.0 * ctx->ctl_host->phase_cycles[i] / tot : 0.0);
+        for (int i = 0; i < 24; i++) fprintf (stderr, " %s %.1f%%", names[i], tot ? 100.0 * ctx->ctl_host->phase_cycles[i] / tot : 0.0);
         fprintf (stderr, " | avg cycles/tile %.0f\n", tiles ? (double) tot / tiles : 0.0);
       }
 #endif
