@@ -27,7 +27,7 @@ def table(source="gt4hip_kernels.hip", extra=()):
         def g(k):
             m = re.search(k + r": (\d+)", b)
             return int(m.group(1)) if m else -1
-        n = re.sub(r"\(.*", "", n.replace("void gt4::(anonymous namespace)::", ""))
+        n = re.sub(r"\(.*", "", n.replace("void ", "").replace("gt4::(anonymous namespace)::", "").replace("gt4::", ""))
         rows.append(dict(name=n, vgpr=g(" VGPRs"), sgpr=g("TotalSGPRs"), vspill=g("VGPRs Spill"), sspill=g("SGPRs Spill"),
                          scratch=g(r"ScratchSize \[bytes/lane\]"), lds=g(r"LDS Size \[bytes/block\]"), occ=g(r"Occupancy \[waves/SIMD\]")))
     return rows
