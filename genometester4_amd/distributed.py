@@ -58,7 +58,8 @@ def exchange_totals(n_words: int, total_count: int, device=None, group=None) -> 
     mine = torch.tensor([n_words, total_count & 0xFFFFFFFF, total_count >> 32], dtype=torch.int64, device=device)
     out = [torch.zeros_like(mine) for _ in range(world)]
     dist.all_gather(out, mine, group=group)
-    return [(int(t[0]), int(t[1]) | (int(t[2]) << 32)) for t in out]
+    rows = torch.stack(out).cpu().tolist()  # ONE device-to-host copy (element-wise int() would synchronise 3 x world times)
+    return [(int(r[0]), int(r[1]) | (int(r[2]) << 32)) for r in rows]
 
 
 def gatherv_records(local, counts: Sequence[int], root: int = 0, group=None):
