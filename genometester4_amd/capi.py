@@ -38,7 +38,7 @@ class MultiResult(C.Structure):
 
 class CountTable(C.Structure):
     _fields_ = [("n_keys", C.c_uint64), ("n_lists", C.c_uint32), ("device_keys", C.c_void_p),
-                ("device_counts", C.c_void_p), ("owner", C.c_void_p * 2)]
+                ("device_counts", C.c_void_p), ("owner", C.c_void_p * 2), ("ragged", C.c_void_p)]
 
 
 # every symbol include/gt4hip.h declares (checked by tests/test_capi_symbols.py)
@@ -48,7 +48,7 @@ SYMBOLS = [
     "gt4hip_list_download", "gt4hip_list_download_range", "gt4hip_list_free", "gt4hip_list_n_words",
     "gt4hip_list_word_length", "gt4hip_list_device_ptr", "gt4hip_list_set_n_words", "gt4hip_list_sum_counts",
     "gt4hip_list_is_sorted", "gt4hip_list_lower_bound", "gt4hip_list_get_word", "gt4hip_compare",
-    "gt4hip_union_multi", "gt4hip_intersect_multi", "gt4hip_union_table", "gt4hip_probe_table", "gt4hip_probe_table_ex", "gt4hip_table_download",
+    "gt4hip_union_multi", "gt4hip_intersect_multi", "gt4hip_union_table", "gt4hip_probe_table", "gt4hip_probe_table_ex", "gt4hip_table_compact", "gt4hip_table_download",
     "gt4hip_table_free", "gt4hip_generate", "gt4hip_generate_ex", "gt4hip_synchronize", "gt4hip_set_option",
     "gt4hip_get_counter", "gt4hip_device_memory", "gt4hip_list_upload_fd", "gt4hip_list_load_fd", "gt4hip_list_load",
     "gt4hip_list_write_fd", "gt4hip_lists_write_fd", "gt4hip_shard_first_key", "gt4hip_comm_unique_id", "gt4hip_comm_create", "gt4hip_comm_destroy",
@@ -102,6 +102,7 @@ def lib():
             "gt4hip_union_table": (C.c_int, [vp, C.POINTER(vp), u32, C.POINTER(CountTable)]),
             "gt4hip_probe_table": (C.c_int, [vp, C.POINTER(vp), u32, C.POINTER(CountTable)]),
             "gt4hip_probe_table_ex": (C.c_int, [vp, C.POINTER(vp), u32, C.c_int, C.POINTER(CountTable)]),
+            "gt4hip_table_compact": (C.c_int, [vp, C.POINTER(CountTable)]),
             "gt4hip_table_download": (C.c_int, [vp, C.POINTER(CountTable), u64, u64, vp, vp]),
             "gt4hip_table_free": (None, [C.POINTER(CountTable)]),
             "gt4hip_generate": (C.c_int, [vp, vp, u64, u64, u32]),
@@ -378,13 +379,19 @@ class Context:
     def intersect_multi(self, lists, cutoff=1, rule=0, count_override=1, count_only=False, out=None):
         return self._multi(lib().gt4hip_intersect_multi, lists, cutoff, rule, count_override, count_only, out)
 
-    def union_table(self, lists, probe=False, presence=False):
+    def union_table(self, lists, probe=False, presence=False, compact=False):
+        """(keys, counts) of the count table; compact: through gt4hip_table_compact first (a ragged table made
+        contiguous on the device); self.last_table_was_ragged says what the library built."""
         arr = (C.c_void_p * len(lists))(*[l.h for l in lists])
         t = CountTable()
         if probe:
             self._chk(lib().gt4hip_probe_table_ex(self.h, arr, len(lists), 1 if presence else 0, C.byref(t)))
         else:
             self._chk(lib().gt4hip_union_table(self.h, arr, len(lists), C.byref(t)))
+        self.last_table_was_ragged = bool(t.ragged)
+        if compact:
+            self._chk(lib().gt4hip_table_compact(self.h, C.byref(t)))
+            assert not t.ragged
         keys = np.empty(t.n_keys, dtype=np.uint64)
         counts = np.empty((t.n_keys, len(lists)), dtype=np.uint32)
         if t.n_keys:

@@ -1074,6 +1074,91 @@ int gt4hip_table_alloc (gt4hip_context *ctx, gt4hip_count_table *table, uint64_t
 
 static int table_alloc (gt4hip_context *ctx, gt4hip_count_table *table, uint64_t n, uint32_t n_lists) { return gt4hip_table_alloc (ctx, table, n, n_lists); }
 
+/* ---- ragged tables (see gt4hip_count_table in include/gt4hip.h) */
+namespace {
+struct TableRagged {
+  uint64_t tiles;
+  unsigned long long *compact, *padded; /* device, tiles + 1 entries each, one block */
+  void *owner;
+};
+
+/* rows [first, first + count) of a ragged table, gathered: one thread per row finds its tile (the last one whose
+ * compact base is not beyond the row) and copies the row from where the tile's rows lie */
+__global__ void k_table_gather (const unsigned long long *__restrict__ keys, const uint32_t *__restrict__ counts, uint32_t n_lists,
+                                const unsigned long long *__restrict__ compact, const unsigned long long *__restrict__ padded, uint64_t tiles,
+                                uint64_t first, uint64_t count, unsigned long long *__restrict__ out_keys, uint32_t *__restrict__ out_counts)
+{
+  const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const uint64_t r = first + i;
+  uint64_t lo = 0, hi = tiles; /* compact[lo] <= r < compact[hi] (compact[tiles] = n_keys) */
+  while (hi - lo > 1) {
+    const uint64_t mid = (lo + hi) >> 1;
+    if (compact[mid] <= r) lo = mid;
+    else hi = mid;
+  }
+  const uint64_t src = padded[lo] + (r - compact[lo]);
+  if (out_keys) out_keys[i] = keys[src];
+  if (out_counts)
+    for (uint32_t j = 0; j < n_lists; j++) out_counts[i * n_lists + j] = counts[src * n_lists + j];
+}
+}  // namespace
+
+int gt4hip_table_set_ragged (gt4hip_context *ctx, gt4hip_count_table *table, uint64_t tiles)
+{
+  TableRagged *r = new (std::nothrow) TableRagged ();
+  if (!r) return gt4hip_fail (ctx, GT4HIP_ENOMEM, "host allocation failed");
+  void *dev = NULL;
+  if (gt4hip_block_alloc (ctx, (size_t) (tiles + 1) * 16, &dev, &r->owner)) {
+    delete r;
+    return gt4hip_fail (ctx, GT4HIP_ENOMEM, "count table index of %llu tiles", (unsigned long long) tiles);
+  }
+  r->tiles = tiles;
+  r->compact = (unsigned long long *) dev;
+  r->padded = r->compact + tiles + 1;
+  table->ragged = r;
+  return GT4HIP_OK;
+}
+
+void *gt4hip_table_compact_bases (gt4hip_count_table *table) { return table && table->ragged ? ((TableRagged *) table->ragged)->compact : NULL; }
+void *gt4hip_table_padded_bases (gt4hip_count_table *table) { return table && table->ragged ? ((TableRagged *) table->ragged)->padded : NULL; }
+
+static hipError_t table_gather (gt4hip_context *ctx, const gt4hip_count_table *t, uint64_t first, uint64_t count, void *out_keys, void *out_counts)
+{
+  const TableRagged *r = (const TableRagged *) t->ragged;
+  hipLaunchKernelGGL (k_table_gather, dim3 ((unsigned) ((count + 255) / 256)), dim3 (256), 0, ctx->stream, (const unsigned long long *) t->device_keys,
+                      (const uint32_t *) t->device_counts, t->n_lists, r->compact, r->padded, r->tiles, first, count, (unsigned long long *) out_keys, (uint32_t *) out_counts);
+  return hipGetLastError ();
+}
+
+extern "C" int gt4hip_table_compact (gt4hip_context *ctx, gt4hip_count_table *t)
+{
+  if (!ctx || !t) return GT4HIP_EINVAL;
+  if (!t->ragged) return GT4HIP_OK;
+  HIPCHK (ctx, hipSetDevice (ctx->device));
+  gt4hip_count_table c;
+  memset (&c, 0, sizeof c);
+  c.n_keys = t->n_keys;
+  c.n_lists = t->n_lists;
+  if (t->n_keys) {
+    const int rc = gt4hip_table_alloc (ctx, &c, t->n_keys, t->n_lists);
+    if (rc) return rc;
+    /* (at most 2^31 blocks of 256 rows per launch) */
+    for (uint64_t first = 0; first < t->n_keys; first += 1ull << 32) {
+      const uint64_t cnt = t->n_keys - first < (1ull << 32) ? t->n_keys - first : (1ull << 32);
+      const hipError_t e = table_gather (ctx, t, first, cnt, (char *) c.device_keys + first * 8, (char *) c.device_counts + first * t->n_lists * 4);
+      if (e != hipSuccess) {
+        gt4hip_table_free (&c);
+        return gt4hip_fail (ctx, GT4HIP_EHIP, "gt4hip_table_compact: %s", hipGetErrorString (e));
+      }
+    }
+    HIPCHK (ctx, hipStreamSynchronize (ctx->stream));
+  }
+  gt4hip_table_free (t);
+  *t = c;
+  return GT4HIP_OK;
+}
+
 extern "C" int gt4hip_union_table (gt4hip_context *ctx, const gt4hip_list *const lists[], uint32_t n_lists, gt4hip_count_table *table)
 {
   if (!ctx || !lists || !n_lists || !table) return GT4HIP_EINVAL;
@@ -1217,6 +1302,20 @@ extern "C" int gt4hip_table_download (gt4hip_context *ctx, const gt4hip_count_ta
   if (!ctx || !t || first > t->n_keys || count > t->n_keys - first) return GT4HIP_EINVAL;
   if (!count) return GT4HIP_OK;
   HIPCHK (ctx, hipSetDevice (ctx->device));
+  if (t->ragged) {
+    /* gathered into a staging block on the device, then copied */
+    char *tmp = NULL;
+    void *owner = NULL;
+    const size_t kb = (size_t) count * 8, cb = (size_t) count * t->n_lists * 4;
+    if (gt4hip_block_alloc (ctx, kb + cb, (void **) &tmp, &owner)) return gt4hip_fail (ctx, GT4HIP_ENOMEM, "gt4hip_table_download: %zu bytes of staging", kb + cb);
+    hipError_t e = table_gather (ctx, t, first, count, host_keys ? tmp : NULL, host_counts ? tmp + kb : NULL);
+    if (e == hipSuccess && host_keys) e = hipMemcpyAsync (host_keys, tmp, kb, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && host_counts) e = hipMemcpyAsync (host_counts, tmp + kb, cb, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize (ctx->stream);
+    gt4hip_block_free (owner);
+    if (e != hipSuccess) return gt4hip_fail (ctx, GT4HIP_EHIP, "gt4hip_table_download: %s", hipGetErrorString (e));
+    return GT4HIP_OK;
+  }
   if (host_keys) HIPCHK (ctx, hipMemcpyAsync (host_keys, (const char *) t->device_keys + first * 8, (size_t) count * 8, hipMemcpyDeviceToHost, ctx->stream));
   if (host_counts)
     HIPCHK (ctx, hipMemcpyAsync (host_counts, (const char *) t->device_counts + first * t->n_lists * 4, (size_t) count * t->n_lists * 4,
@@ -1232,6 +1331,12 @@ extern "C" void gt4hip_table_free (gt4hip_count_table *t)
   else if (t->device_keys) hipFree (t->device_keys);
   if (t->owner[1]) gt4hip_block_free (t->owner[1]);
   else if (t->device_counts) hipFree (t->device_counts);
+  if (t->ragged) {
+    TableRagged *r = (TableRagged *) t->ragged;
+    if (r->owner) gt4hip_block_free (r->owner);
+    delete r;
+  }
+  t->ragged = NULL;
   t->device_keys = t->device_counts = NULL;
   t->owner[0] = t->owner[1] = NULL;
   t->n_keys = 0;

@@ -89,6 +89,11 @@ int gt4hip_nway_union (gt4hip_context *ctx, const gt4hip_list *const lists[], ui
 int gt4hip_block_alloc (gt4hip_context *ctx, size_t bytes, void **dev, void **owner);
 void gt4hip_block_free (void *owner);
 int gt4hip_table_alloc (gt4hip_context *ctx, gt4hip_count_table *table, uint64_t n, uint32_t n_lists);
+/* ragged tables (gt4hip_count_table.ragged): the index of `tiles` tiles -- rows before every tile (compact) and where
+ * the tile's rows lie in the arrays (padded), tiles + 1 device u64 each */
+int gt4hip_table_set_ragged (gt4hip_context *ctx, gt4hip_count_table *table, uint64_t tiles);
+void *gt4hip_table_compact_bases (gt4hip_count_table *table);
+void *gt4hip_table_padded_bases (gt4hip_count_table *table);
 int gt4hip_nway_table (gt4hip_context *ctx, const gt4hip_list *const lists[], uint32_t k, const uint32_t cols[], gt4hip_count_table *table, int probe,
                        int presence, int *used);
 int gt4hip_io_download (gt4hip_context *ctx, const void *dev, void *host, size_t bytes);

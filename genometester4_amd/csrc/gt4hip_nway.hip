@@ -650,6 +650,16 @@ __global__ __launch_bounds__ (NWAY_SPLIT_BLOCK) void k_nway_emit (NwayParams p, 
   if (s0 > nch || s1 > nch) atomicOr (flag, 1u);
 }
 
+/* where every tile's rows start in the ragged table = the records in front of the tile (the sum of its cuts) */
+__global__ void k_nway_padded_bases (const u64 *__restrict__ part, u64 tiles, u32 k, u64 *__restrict__ padded)
+{
+  const u64 t = (u64) blockIdx.x * blockDim.x + threadIdx.x;
+  if (t > tiles) return;
+  u64 sum = 0;
+  for (u32 i = 0; i < k; i++) sum += part[t * NWAY_PSTRIDE + i];
+  padded[t] = sum;
+}
+
 /* rows before every tile = exclusive prefix of the tiles' distinct keys (one workgroup walks the array) */
 __global__ __launch_bounds__ (1024) void k_nway_tile_bases (const u32 *__restrict__ totals, u64 tiles, u64 *__restrict__ bases)
 {
@@ -676,6 +686,7 @@ __global__ __launch_bounds__ (1024) void k_nway_tile_bases (const u32 *__restric
     if (threadIdx.x == 0) carry_s = c + all;
     __syncthreads ();
   }
+  if (threadIdx.x == 0) bases[tiles] = carry_s; /* (the array has tiles + 1 entries) */
 }
 
 /* ------------------------------------------------------------------ K7: the tile kernel */
@@ -886,7 +897,6 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
     u64 v = 0;
     if (tile < ntl && lane < 2 * NWAY_PSTRIDE)
       v = __hip_atomic_load (&part[(u64) tile * NWAY_PSTRIDE + (u64) lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (MODE == NWAY_TABLE && tile < ntl && lane == 2 * NWAY_PSTRIDE) v = p.tile_base[tile];
     return v;
   };
   /* the slot table of `tile` (partition entries in `row`, one per lane) into table tb: branch-free
@@ -929,11 +939,13 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
       }
     }
     u64 base = 0;
-    if (MODE == NWAY_DUPS) {
+    if (MODE == NWAY_DUPS || MODE == NWAY_TABLE) {
+      /* the records in front of the tile: where a level of merged samples starts the tile's output -- and where
+       * the count table starts the tile's rows (a tile has at most as many distinct keys as records: the table is
+       * RAGGED, see gt4hip_count_table) */
 #pragma unroll
       for (int q = 0; q < NWAY_MAX; q++) base += (u32) q < p.k ? readlane_u64 (row, q) : 0ull;
     }
-    if (MODE == NWAY_TABLE) base = readlane_u64 (row, 2 * NWAY_PSTRIDE);
     if (MODE == NWAY_PROBE) base = readlane_u64 (row, 0); /* the tile's first record of list 0 = its first row */
     const u32 lo_lo = (u32) __builtin_amdgcn_readlane ((int) rlo, NWAY_MAX), lo_hi = (u32) __builtin_amdgcn_readlane ((int) rhi, NWAY_MAX);
     const u32 bk_lo = (u32) __builtin_amdgcn_readlane ((int) rlo, NWAY_MAX + 1), bk_hi = (u32) __builtin_amdgcn_readlane ((int) rhi, NWAY_MAX + 1);
@@ -1538,7 +1550,7 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
       if (MODE == NWAY_UNION && service) {
         if (lane == 0) publish_u32 (&agg[cur], AGG_READY | tile_total);
       }
-      if (MODE == NWAY_COUNT && tid == 0 && p.tile_totals) p.tile_totals[cur] = tile_total;
+      if ((MODE == NWAY_COUNT || MODE == NWAY_TABLE) && tid == 0 && p.tile_totals) p.tile_totals[cur] = tile_total;
       if (nway_staged (MODE) && wave_kept) {
 #pragma unroll
         for (int i = 0; i < RPT; i++) {
@@ -1623,6 +1635,7 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
     if (lane == 0 && v) atomicAdd (&ctl->total_count[0], v);
     if (tid == 0 && blk_cnt) atomicAdd (&ctl->n_words[0], blk_cnt);
   }
+  if (MODE == NWAY_TABLE && tid == 0 && blk_cnt) atomicAdd (&ctl->n_words[0], blk_cnt); /* the table's rows */
 }
 
 constexpr int NWAY_NT = GT4_NWAY_NT;
@@ -1898,7 +1911,7 @@ static int nway_run (gt4hip_context *ctx, const gt4hip_list *const lists[], uint
     lv.p.filter = filter;
     lv.p.spin_limit = ctx->spin_limit;
     lv.p.force_fallback = ctx->kway_vt == 99 ? 1u : (ctx->kway_vt == 98 ? 2u : 0u); /* option "kway_vt" = 99 / 98: every tile takes the search path / the pivot-run buckets (tests) */
-    const int mode = l > 0 ? NWAY_DUPS : (table && probe ? NWAY_PROBE : (count_only || table ? NWAY_COUNT : NWAY_UNION));
+    const int mode = l > 0 ? NWAY_DUPS : (table ? (probe ? NWAY_PROBE : NWAY_TABLE) : (count_only ? NWAY_COUNT : NWAY_UNION));
     lv.p.scan_group = ctx->scan_group > 0 ? 1u : (ctx->scan_group < 0 ? 0u : (tiles > (48000ull << 6) ? 1u : 0u));
     lv.p.dynamic = ctx->dynamic > 0 ? 1u : (ctx->dynamic < 0 ? 0u : (mode == NWAY_UNION ? 1u : 0u));
     u32 *dst = NULL;
@@ -1926,9 +1939,18 @@ static int nway_run (gt4hip_context *ctx, const gt4hip_list *const lists[], uint
       lv.p.table_counts = (u32 *) table->device_counts;
       lv.p.table_cols = table->n_lists;
       for (uint32_t i = 0; i < k; i++) lv.p.table_col[i] = cols[i];
-    } else if (l == 0 && table) { /* the tiles' distinct keys, then the rows before every tile, behind each other in the descriptor area */
-      if ((rc = nway_grow (ctx, (void **) &ctx->desc, &ctx->desc_bytes, (size_t) tiles * 4 + 16 + (size_t) tiles * 8))) break;
+    } else if (l == 0 && table) {
+      /* ONE launch (round 4): every tile writes its rows where its records start -- a tile has at most as many distinct
+       * keys as records, so the table is allocated for the records and stays RAGGED (unused rows behind every tile's;
+       * gt4hip_table_download and gt4hip_table_compact know, see gt4hip_count_table).  Round 3 counted every tile's
+       * distinct keys in a launch of their own first: the records were read twice. */
+      if ((rc = nway_grow (ctx, (void **) &ctx->desc, &ctx->desc_bytes, (size_t) tiles * 4 + 16))) break;
+      if ((rc = gt4hip_table_alloc (ctx, table, lv.total, table->n_lists))) break;
       lv.p.tile_totals = (u32 *) ctx->desc;
+      lv.p.table_keys = (u64 *) table->device_keys;
+      lv.p.table_counts = (u32 *) table->device_counts;
+      lv.p.table_cols = table->n_lists;
+      for (uint32_t i = 0; i < k; i++) lv.p.table_col[i] = cols[i];
     }
     hipMemsetAsync (ctx->ctl, 0, sizeof (PairControl), st);
     if (l == 0) hipEventRecord (ctx->ev[1], st);
@@ -1973,32 +1995,15 @@ static int nway_run (gt4hip_context *ctx, const gt4hip_list *const lists[], uint
       *n_words = ctx->ctl_host->n_words[0];
       *total_count = ctx->ctl_host->total_count[0];
       if (table && !probe) {
-        /* second launch over the same partition: key column and counts, every tile at its rows */
-        const u64 rows = *n_words;
-        u64 *bases = (u64 *) ((char *) ctx->desc + (((size_t) tiles * 4 + 15) & ~(size_t) 15));
-        table->n_keys = rows;
-        if (rows) {
-          if ((rc = gt4hip_table_alloc (ctx, table, rows, table->n_lists))) break;
-          table->n_keys = rows;
-          /* (the table launch zeroes every tile's rows itself) */
-          hipLaunchKernelGGL (k_nway_tile_bases, dim3 (1), dim3 (1024), 0, st, (const u32 *) ctx->desc, tiles, bases);
-          lv.p.tile_totals = NULL;
-          lv.p.tile_base = bases;
-          lv.p.table_keys = (u64 *) table->device_keys;
-          lv.p.table_counts = (u32 *) table->device_counts;
-          lv.p.table_cols = table->n_lists;
-          for (uint32_t i = 0; i < k; i++) lv.p.table_col[i] = cols[i];
-          lv.p.dynamic = 0;
-          int g2 = ctx->n_cus * nway_blocks_per_cu (NWAY_TABLE);
-          if ((u64) g2 > tiles) g2 = (int) tiles;
-          hipMemsetAsync (ctx->ctl, 0, sizeof (PairControl), st);
-          e = launch_nway_mode (st, NWAY_TABLE, g2, lv.p, part_final, NULL, (u64 *) ctx->desc, ctx->ctl);
-          if (e == hipSuccess) e = hipMemcpyAsync (ctx->ctl_host, ctx->ctl, sizeof (PairControl), hipMemcpyDeviceToHost, st);
-          if (e == hipSuccess) e = hipStreamSynchronize (st);
-          if (e != hipSuccess || ctx->ctl_host->error) {
-            rc = gt4hip_fail (ctx, e != hipSuccess ? GT4HIP_EHIP : GT4HIP_EINTERNAL, "count table kernel failed: %s (flags 0x%x)", hipGetErrorString (e), ctx->ctl_host->error);
-            break;
-          }
+        /* the ragged table's index: rows before every tile (compact) and where the tile's rows lie (padded) */
+        table->n_keys = *n_words;
+        if ((rc = gt4hip_table_set_ragged (ctx, table, tiles))) break;
+        hipLaunchKernelGGL (k_nway_tile_bases, dim3 (1), dim3 (1024), 0, st, (const u32 *) ctx->desc, tiles, (u64 *) gt4hip_table_compact_bases (table));
+        hipLaunchKernelGGL (k_nway_padded_bases, dim3 ((unsigned) ((tiles + 256) / 256)), dim3 (256), 0, st, part_final, tiles, k, (u64 *) gt4hip_table_padded_bases (table));
+        e = hipStreamSynchronize (st);
+        if (e != hipSuccess) {
+          rc = gt4hip_fail (ctx, GT4HIP_EHIP, "count table index failed: %s", hipGetErrorString (e));
+          break;
         }
       }
       float ms = 0;

@@ -202,9 +202,10 @@ int gt4hip_intersect_multi (gt4hip_context *ctx, const gt4hip_list *const lists[
                             gt4hip_multi_result *result);
 
 /* Per-key count table of an N-way union: for every distinct key ascending, counts[j] = count in
- * list j or 0 (what gt4_union hands to its callback, src/set-operations.c:161-179).  Built by
- * merges only: the N-way union gives the keys, and each column is one more streaming merge of the
- * key list with list j (rule SECOND keeps list j's count, absent keys get 0).
+ * list j or 0 (what gt4_union hands to its callback, src/set-operations.c:161-179).  Up to eight non-empty lists:
+ * one launch of the N-way tile kernel (a ragged table, see below); more: by merges -- the N-way union gives the
+ * keys, and each column is one more streaming merge of the key list with list j (rule SECOND keeps list j's count,
+ * absent keys get 0).
  * keys_out: n_keys u64; counts_out: n_keys * n_lists u32, row-major.  Both are device buffers
  * owned by the result; release with gt4hip_table_free. */
 typedef struct {
@@ -213,6 +214,12 @@ typedef struct {
   void *device_keys;
   void *device_counts;
   void *owner[2]; /* library-private: the pooled device blocks behind the two arrays */
+  /* Non-NULL: the table is RAGGED.  gt4hip_union_table of up to eight lists writes the table in ONE launch of the
+   * N-way tile kernel: a tile of the merged key sequence puts its rows where its RECORDS start (it has at most as many
+   * distinct keys as records), so the two arrays are allocated for the lists' records and hold unused rows behind
+   * every tile's.  gt4hip_table_download gathers the rows asked for; gt4hip_table_compact turns the table into the
+   * contiguous form (n_keys rows, ragged = NULL) for callers that read the device arrays themselves. */
+  void *ragged;
 } gt4hip_count_table;
 int gt4hip_union_table (gt4hip_context *ctx, const gt4hip_list *const lists[], uint32_t n_lists,
                         gt4hip_count_table *table);
@@ -225,6 +232,8 @@ int gt4hip_probe_table (gt4hip_context *ctx, const gt4hip_list *const lists[], u
  * (reference src/glistquery.c:776-812). */
 int gt4hip_probe_table_ex (gt4hip_context *ctx, const gt4hip_list *const lists[], uint32_t n_lists, int presence,
                            gt4hip_count_table *table);
+/* Makes a ragged table contiguous on the device (a gather into new arrays; a no-op for a contiguous one). */
+int gt4hip_table_compact (gt4hip_context *ctx, gt4hip_count_table *table);
 /* Copies rows [first, first+count) of the table to host memory. */
 int gt4hip_table_download (gt4hip_context *ctx, const gt4hip_count_table *table, uint64_t first,
                            uint64_t count, uint64_t *host_keys, uint32_t *host_counts);

@@ -12,7 +12,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
-SOURCES = ["gt4hip_kernels.hip", "gt4hip_nway.hip", "gt4hip_sort.hip"]  # every file of csrc that holds a __global__ function
+SOURCES = ["gt4hip_kernels.hip", "gt4hip_nway.hip", "gt4hip_sort.hip", "gt4hip_api.hip"]  # every file of csrc that holds a __global__ function
 
 
 @pytest.fixture(scope="module")

@@ -307,14 +307,18 @@ def test_device_shards_world_of_one_with_rccl_gather(ctx):
 
 def _check_table(ctx, lists, k=20, expect_kway=True):
     """gt4hip_union_table (glistquery's multi-list dump, reference src/set-operations.c:131-183) by the
-    tile kernel (two launches: distinct keys per tile, then keys and counts at every tile's rows) against
-    numpy -- keys = sorted union of all lists, column j = list j's count of the key, 0 where absent -- and
-    against the table built by merges (option kway = 0)."""
+    tile kernel (one launch: every tile writes keys and counts where its records start -- a ragged table, gathered by
+    gt4hip_table_download or made contiguous by gt4hip_table_compact) against numpy -- keys = sorted union of all
+    lists, column j = list j's count of the key, 0 where absent -- and against the table built by merges (option
+    kway = 0)."""
     dev = [ctx.upload(x, k) for x in lists]
     before = ctx.get_counter("kway_calls")
     tk, tc = ctx.union_table(dev)
     if expect_kway and 2 <= sum(len(x) > 0 for x in lists) <= 8:
         assert ctx.get_counter("kway_calls") == before + 1
+        assert ctx.last_table_was_ragged
+        ck, cc = ctx.union_table(dev, compact=True)
+        assert ck.tobytes() == tk.tobytes() and cc.tobytes() == tc.tobytes()
     uni = np.unique(np.concatenate([x["key"] for x in lists])) if lists else np.zeros(0, dtype=np.uint64)
     assert tk.tobytes() == uni.tobytes()
     for j, x in enumerate(lists):
