@@ -32,8 +32,9 @@
  * its lower bounds in all the runs (binary searches) -- and continues at step 4.
  *
  * The same tile kernel also builds glistquery's count tables (gt4_union / gt4_is_union /
- * search_lists_multi: src/set-operations.c:131-228, src/glistquery.c:776-812): NWAY_COUNT with per-tile
- * totals + NWAY_TABLE (all distinct keys, a column per list), NWAY_PROBE (the keys of list 0).
+ * search_lists_multi: src/set-operations.c:131-228, src/glistquery.c:776-812): NWAY_TABLE (all distinct keys,
+ * a column per list; one launch, every tile's rows where its records start: a ragged table), NWAY_PROBE (the keys
+ * of list 0).
  *
  *   K5 k_nway_sample          every S-th key of every list -> "sample lists" (1/S of the data)
  *   K6 k_nway_sample_counts,  tile boundaries: the merged samples' every G-th key; a merged sample carries its
@@ -49,7 +50,8 @@
  *                             sample lists themselves are merged, one level up: the recursion ends when a level
  *                             fits one tile), NWAY_UNION / NWAY_COUNT fold equal keys and apply the rule,
  *                             NWAY_TABLE / NWAY_PROBE write count tables
- *      k_nway_tile_bases      rows before every tile (count tables)
+ *      k_nway_tile_bases,     rows before every tile and where its rows lie (the ragged count table's index)
+ *      k_nway_padded_bases
  */
 #include "gt4hip_device.h"
 #include "gt4hip_host.h"
@@ -96,16 +98,15 @@ struct NwayParams {
   u32 dynamic;         /* tiles by ticket (ctl->ticket) instead of round-robin */
   u32 force_fallback;  /* tests: 1 every tile takes the search path, 2 every tile is bucketed by its pivot run */
   u32 scan_group;      /* the scanner workgroup as summers + chainer (launches with very many rows) */
-  /* NWAY_COUNT with tile_totals: every tile's number of distinct keys -> tile_totals[tile].
-   * NWAY_TABLE (the count table of glistquery's multi-list dump, src/set-operations.c:131-183): row r of the
-   * table is the r-th distinct key; tile_base[tile] = rows before the tile (from a counting launch over the
-   * same partition); list i's count of the key goes to table_counts[r * table_cols + table_col[i]].
+  /* NWAY_TABLE (the count table of glistquery's multi-list dump, src/set-operations.c:131-183): a tile's j-th
+   * distinct key is row (records in front of the tile) + j of the ragged table; list i's count of the key goes to
+   * table_counts[row * table_cols + table_col[i]]; every tile's number of distinct keys -> tile_totals[tile]
+   * (the index gt4hip_table_download gathers by).
    * NWAY_PROBE (the table restricted to the keys of list 0: gt4_is_union, search_lists_multi; src/set-operations.c:
    * 185-228, src/glistquery.c:776-812): row r is record r of list 0 -- no counting launch, no ordered pass: list 0's
    * records leave their index at their position, every record of the same key finds it there.  rule NUMBER:
    * count_override instead of the count (membership). */
   u32 *tile_totals;
-  const u64 *tile_base;
   u64 *table_keys;
   u32 *table_counts;
   u32 table_cols;
