@@ -50,7 +50,8 @@
  *                             sample lists themselves are merged, one level up: the recursion ends when a level
  *                             fits one tile), NWAY_UNION / NWAY_COUNT fold equal keys and apply the rule,
  *                             NWAY_TABLE / NWAY_PROBE write count tables
- *      k_nway_tile_bases,     rows before every tile and where its rows lie (the ragged count table's index)
+ *      k_nway_base_sums, _scan, rows before every tile and where its rows lie (the ragged count table's index)
+ *      k_nway_tile_bases,
  *      k_nway_padded_bases
  */
 #include "gt4hip_device.h"
@@ -661,17 +662,32 @@ __global__ void k_nway_padded_bases (const u64 *__restrict__ part, u64 tiles, u3
   padded[t] = sum;
 }
 
-/* rows before every tile = exclusive prefix of the tiles' distinct keys (one workgroup walks the array) */
-__global__ __launch_bounds__ (1024) void k_nway_tile_bases (const u32 *__restrict__ totals, u64 tiles, u64 *__restrict__ bases)
+/* rows before every tile = exclusive prefix of the tiles' distinct keys, in three small launches (one workgroup
+ * walking 2e5 tiles took 0.28 ms of a 7 ms table): sums per block of 1024 tiles, their prefix, the tiles' own */
+__global__ __launch_bounds__ (1024) void k_nway_base_sums (const u32 *__restrict__ totals, u64 tiles, u64 *__restrict__ block_sums)
+{
+  __shared__ u64 ws[16];
+  const u64 i = (u64) blockIdx.x * 1024 + threadIdx.x;
+  const u64 v = wave_sum (i < tiles ? (u64) totals[i] : 0ull);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = v;
+  __syncthreads ();
+  if (threadIdx.x == 0) {
+    u64 sum = 0;
+    for (int w = 0; w < 16; w++) sum += ws[w];
+    block_sums[blockIdx.x] = sum;
+  }
+}
+
+__global__ __launch_bounds__ (1024) void k_nway_base_scan (u64 *__restrict__ block_sums, u64 n_blocks)
 {
   __shared__ u64 wsum[16];
   __shared__ u64 carry_s;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   if (threadIdx.x == 0) carry_s = 0;
   __syncthreads ();
-  for (u64 b0 = 0; b0 < tiles; b0 += 1024) {
+  for (u64 b0 = 0; b0 < n_blocks; b0 += 1024) {
     const u64 i = b0 + threadIdx.x;
-    const u64 v = i < tiles ? totals[i] : 0;
+    const u64 v = i < n_blocks ? block_sums[i] : 0ull;
     const u64 incl = wave_inclusive_scan (v, lane);
     if (lane == 63) wsum[wid] = incl;
     __syncthreads ();
@@ -682,12 +698,26 @@ __global__ __launch_bounds__ (1024) void k_nway_tile_bases (const u32 *__restric
       all += x;
     }
     const u64 c = carry_s;
-    if (i < tiles) bases[i] = c + before + incl - v;
+    if (i < n_blocks) block_sums[i] = c + before + incl - v;
     __syncthreads ();
     if (threadIdx.x == 0) carry_s = c + all;
     __syncthreads ();
   }
-  if (threadIdx.x == 0) bases[tiles] = carry_s; /* (the array has tiles + 1 entries) */
+}
+
+/* bases[t] for t <= tiles (bases[tiles] = the total) */
+__global__ __launch_bounds__ (1024) void k_nway_tile_bases (const u32 *__restrict__ totals, u64 tiles, const u64 *__restrict__ block_base, u64 *__restrict__ bases)
+{
+  __shared__ u64 wsum[16];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const u64 i = (u64) blockIdx.x * 1024 + threadIdx.x;
+  const u64 v = i < tiles ? (u64) totals[i] : 0ull;
+  const u64 incl = wave_inclusive_scan (v, lane);
+  if (lane == 63) wsum[wid] = incl;
+  __syncthreads ();
+  u64 before = block_base[blockIdx.x];
+  for (int w = 0; w < wid; w++) before += wsum[w];
+  if (i <= tiles) bases[i] = before + incl - v;
 }
 
 /* ------------------------------------------------------------------ K7: the tile kernel */
@@ -1945,7 +1975,7 @@ static int nway_run (gt4hip_context *ctx, const gt4hip_list *const lists[], uint
        * keys as records, so the table is allocated for the records and stays RAGGED (unused rows behind every tile's;
        * gt4hip_table_download and gt4hip_table_compact know, see gt4hip_count_table).  Round 3 counted every tile's
        * distinct keys in a launch of their own first: the records were read twice. */
-      if ((rc = nway_grow (ctx, (void **) &ctx->desc, &ctx->desc_bytes, (size_t) tiles * 4 + 16))) break;
+      if ((rc = nway_grow (ctx, (void **) &ctx->desc, &ctx->desc_bytes, (size_t) tiles * 4 + 32 + (size_t) ((tiles + 1 + 1023) / 1024) * 8))) break; /* the tiles' totals, then their sums per block of 1024 */
       if ((rc = gt4hip_table_alloc (ctx, table, lv.total, table->n_lists))) break;
       lv.p.tile_totals = (u32 *) ctx->desc;
       lv.p.table_keys = (u64 *) table->device_keys;
@@ -1999,7 +2029,13 @@ static int nway_run (gt4hip_context *ctx, const gt4hip_list *const lists[], uint
         /* the ragged table's index: rows before every tile (compact) and where the tile's rows lie (padded) */
         table->n_keys = *n_words;
         if ((rc = gt4hip_table_set_ragged (ctx, table, tiles))) break;
-        hipLaunchKernelGGL (k_nway_tile_bases, dim3 (1), dim3 (1024), 0, st, (const u32 *) ctx->desc, tiles, (u64 *) gt4hip_table_compact_bases (table));
+        {
+          const u64 nb = (tiles + 1 + 1023) / 1024;
+          u64 *const bsum = (u64 *) ((char *) ctx->desc + (((size_t) tiles * 4 + 15) & ~(size_t) 15)); /* (behind the tiles' totals) */
+          hipLaunchKernelGGL (k_nway_base_sums, dim3 ((unsigned) nb), dim3 (1024), 0, st, (const u32 *) ctx->desc, tiles, bsum);
+          hipLaunchKernelGGL (k_nway_base_scan, dim3 (1), dim3 (1024), 0, st, bsum, nb);
+          hipLaunchKernelGGL (k_nway_tile_bases, dim3 ((unsigned) nb), dim3 (1024), 0, st, (const u32 *) ctx->desc, tiles, (const u64 *) bsum, (u64 *) gt4hip_table_compact_bases (table));
+        }
         hipLaunchKernelGGL (k_nway_padded_bases, dim3 ((unsigned) ((tiles + 256) / 256)), dim3 (256), 0, st, part_final, tiles, k, (u64 *) gt4hip_table_padded_bases (table));
         e = hipStreamSynchronize (st);
         if (e != hipSuccess) {
