@@ -24,6 +24,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <sys/stat.h>
+#include <time.h>
 #include <unistd.h>
 
 struct gt4hip_context {
@@ -297,8 +298,12 @@ const char *gt4hip_comm_last_error (void) { return g_err; }
 
 int gt4hip_comm_unique_id (void *id_out)
 {
+  /* unique across runs: a failed run leaves its exchange files behind, and process numbers come round again
+   * (a later run that drew the same name would read the stale file before its peer has renamed the new one) */
+  struct timespec ts;
+  clock_gettime (CLOCK_REALTIME, &ts);
   memset (id_out, 0, GT4HIP_COMM_ID_BYTES);
-  snprintf ((char *) id_out, 40, "gt4stub_%ld_%ld", (long) getpid (), (long) random ());
+  snprintf ((char *) id_out, 40, "gt4stub_%ld_%llx", (long) getpid (), (unsigned long long) ts.tv_sec * 1000000000ull + (unsigned long long) ts.tv_nsec);
   return GT4HIP_OK;
 }
 
