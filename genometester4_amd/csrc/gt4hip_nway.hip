@@ -85,6 +85,16 @@ constexpr int NWAY_TRY0 = GT4_NWAY_TRY0;     /* ... that the interpolation's buc
 
 enum : int { NWAY_COUNT = 0, NWAY_UNION = 1, NWAY_DUPS = 2, NWAY_TABLE = 3, NWAY_PROBE = 4 };
 __host__ __device__ constexpr bool nway_staged (int mode) { return mode == NWAY_UNION || mode == NWAY_DUPS; } /* kept records leave through the staging area */
+/* LEAD (NWAY_UNION, NWAY_COUNT): no ordered copy of the tile.  The first record to set its position's bit in a bitmap
+ * is the position's LEADER; the counts are folded by LDS atomics as before; behind the barrier the leader reads
+ * the folded count, applies the cutoff (a leader that is not kept clears its bit again) and, behind one more barrier,
+ * finds its output slot as the number of bits below its own -- a popcount prefix every wavefront works out for itself.
+ * No key array, no live bytes, no pass over the positions (a quarter of them empty): the keys' 34 KB go to the grouped
+ * keys (which the pivot keys of a clustered tile then share: refilled behind the searches). */
+#ifndef GT4_NWAY_LEAD
+#define GT4_NWAY_LEAD 1
+#endif
+__host__ __device__ constexpr bool nway_lead (int mode) { return GT4_NWAY_LEAD && (mode == NWAY_UNION || mode == NWAY_COUNT); }
 
 struct NwayParams {
   const u32 *list[NWAY_MAX];
@@ -769,11 +779,14 @@ __device__ __forceinline__ u32 dpp_wave_max_u32 (u32 v)
   return (u32) __builtin_amdgcn_readlane ((int) v, WAVE - 1);
 }
 
+/* buckets of a tile: about one per position, a multiple of 2048 (the counters are scanned 16 bytes at a time by 256 lanes) */
+__host__ __device__ constexpr int nway_buckets (int positions) { return (positions + 2047) / 2048 * 2048; }
+
 template <int NT, int RPT, int NBF, int MODE>
 struct NwayShared {
   static constexpr int CAP = NT * RPT;     /* positions = records a tile may hold (runs rounded up to 64) */
   static constexpr int NCH = CAP / WAVE;   /* wave slots */
-  static constexpr int NB = NBF * CAP;     /* buckets */
+  static constexpr int NB = nway_buckets (NBF * CAP); /* buckets */
   static constexpr int NW = NT / WAVE;
   /* the tile in key order: key and folded count per position -- or, in the fallback, the records
    * as sorted runs (packed 12 bytes at their positions) */
@@ -783,22 +796,32 @@ struct NwayShared {
    * stride over all banks (measured before: 60 % of all LDS cycles were bank conflicts). */
   static constexpr int CAPS = CAP + CAP / 32;                 /* skewed positions */
   static constexpr int GSZ = (CAPS + NWAY_LIMIT + 5) & ~1;    /* grouped keys: + the longest bucket walk behind the last key */
+  static constexpr bool LEAD = nway_lead (MODE);
+  static constexpr int LWL = (CAP / 32 + WAVE - 1) / WAVE;    /* LEAD: bitmap words per lane of a scanning wavefront */
+  static constexpr int LW = LWL * WAVE;                       /* ... bitmap words (one bit per position, padded) */
   union {
     struct {
-      u64 skey[CAPS];
+      alignas (16) u64 skey[LEAD ? GSZ + WAVE : CAPS];        /* LEAD: the grouped keys live here (+ a row nobody reads: see the trash rows) */
       u32 scnt[CAPS];
     } s;
     u32 raw[3 * CAP];
   };
-  alignas (16) u64 g[GSZ];                 /* keys grouped by bucket; all-ones wherever no key is */
-  alignas (16) u32 cnt[NB / 2 + 4];        /* 16-bit bucket counters, then bucket starts, in pairs (+ the total) */
-  alignas (16) u32 live[(CAPS + 3) / 4];   /* one byte per position: a key was stored there */
-  alignas (16) u32 stage[nway_staged (MODE) ? 3 * CAP + 4 : 4]; /* the kept records, packed, written out during the NEXT tile */
+  alignas (16) u64 g_own[LEAD ? 2 : GSZ + WAVE]; /* keys grouped by bucket; all-ones wherever no key is */
+  __device__ __forceinline__ u64 *g () { return LEAD ? s.skey : g_own; }
+  /* TRASH ROWS: the per-record steps are straight-line code -- every LDS read of a thread's RPT records is issued
+   * before the first one is waited for, no exec-mask bookkeeping, no branch between them -- so a lane whose record
+   * is not there (or is not kept) does its store or atomic too, into a row of WAVE words / keys / records behind the
+   * array, one per lane, that nobody reads */
+  alignas (16) u32 cnt[NB / 2 + 4 + WAVE]; /* 16-bit bucket counters, then bucket starts, in pairs (+ the total) (+ a trash row) */
+  alignas (16) u32 live[LEAD ? 4 : (CAPS + 3) / 4]; /* one byte per position: a key was stored there */
+  alignas (16) u32 lead[2][LEAD ? LW : 4]; /* LEAD: the positions that have a (kept) leader, tiles alternating */
+  alignas (16) unsigned short wpre[LEAD && nway_staged (MODE) ? NT / WAVE : 1][LEAD && nway_staged (MODE) ? LW : 4]; /* LEAD: kept leaders in front of every bitmap word, per wavefront */
+  alignas (16) u32 stage[nway_staged (MODE) ? 3 * CAP + 4 + 3 * WAVE + 8 : 4]; /* the kept records, packed, written out during the NEXT tile (+ a trash row) */
   alignas (16) u32 wtot[NW], wmax[NW], wkept[NW];
   /* the tiles of this iteration, the next one (being fetched) and the one after (being described),
    * three deep: one 64-record wave slot per wave-instruction */
   u64 slot_addr[3][NCH];
-  u32 slot_cnt[3][NCH];
+  alignas (16) u32 slot_cnt[3][NCH];
   u32 slot_run[3][NCH];                    /* (NWAY_TABLE, NWAY_PROBE, NWAY_DUPS) the list a slot's records come from */
   u32 tab_pbase[3][NWAY_MAX];              /* first position of each run */
   u32 tab_len[3][NWAY_MAX];
@@ -815,6 +838,10 @@ struct NwayShared {
 __host__ __device__ constexpr int nway_waves_per_simd (int nt) { return GT4_NWAY_WAVES; }
 
 __device__ __forceinline__ u32 nway_skew (u32 i) { return i + (i >> 5); }
+/* a where the mask is all ones, b where it is zero -- one bit-field insert; `c ? a : b` on a per-lane condition became
+ * exec-mask bookkeeping (four scalar instructions each on the CU's one scalar unit) */
+__device__ __forceinline__ u32 nway_pick (u32 mask, u32 a, u32 b) { return (a & mask) | (b & ~mask); }
+__device__ __forceinline__ u32 nway_valid_mask (u32 ba) { return (u32) ((int) ba >> 31); }
 
 /* LDS accesses by byte offset through address-space-3 pointers: the compiler keeps generic pointers for
  * loop-invariant per-thread addresses otherwise (flat loads, two registers per address) */
@@ -866,6 +893,44 @@ __device__ __forceinline__ u64 readlane_u64 (u64 v, int l)
   return (u64) (u32) __builtin_amdgcn_readlane ((int) (u32) v, l) | ((u64) (u32) __builtin_amdgcn_readlane ((int) (u32) (v >> 32), l) << 32);
 }
 
+/* (diagnostics, off by default: GT4_NWAY_INJ_{VALU,SALU,LDS} dummy instructions per wavefront and tile at point
+ * GT4_NWAY_INJ_AT -- what a saturated unit charges for them is how the tile's time is told apart) */
+#ifndef GT4_NWAY_INJ_VALU
+#define GT4_NWAY_INJ_VALU 0
+#endif
+#ifndef GT4_NWAY_INJ_SALU
+#define GT4_NWAY_INJ_SALU 0
+#endif
+#ifndef GT4_NWAY_INJ_LDS
+#define GT4_NWAY_INJ_LDS 0
+#endif
+#ifndef GT4_NWAY_INJ_AT
+#define GT4_NWAY_INJ_AT 0
+#endif
+template <int AT>
+__device__ __forceinline__ void nway_inject (u32 lds_addr)
+{
+  if constexpr (AT == GT4_NWAY_INJ_AT) {
+    if constexpr (GT4_NWAY_INJ_VALU > 0) {
+      u32 a = 0, b = 1, c = 2, d = 3;
+#pragma unroll
+      for (int i = 0; i < GT4_NWAY_INJ_VALU / 4; i++)
+        asm volatile ("v_add_u32 %0, %0, 1\n\tv_add_u32 %1, %1, 1\n\tv_add_u32 %2, %2, 1\n\tv_add_u32 %3, %3, 1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    }
+    if constexpr (GT4_NWAY_INJ_SALU > 0) {
+      u32 a = 0, b = 1;
+#pragma unroll
+      for (int i = 0; i < GT4_NWAY_INJ_SALU / 2; i++) asm volatile ("s_add_u32 %0, %0, 1\n\ts_add_u32 %1, %1, 1" : "+s"(a), "+s"(b) : : "scc");
+    }
+    if constexpr (GT4_NWAY_INJ_LDS > 0) {
+      u32 r;
+#pragma unroll
+      for (int i = 0; i < GT4_NWAY_INJ_LDS; i++) asm volatile ("ds_read_b32 %0, %1" : "=v"(r) : "v"(lds_addr) : "memory");
+      asm volatile ("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
+}
+
 template <int NT, int RPT, int NBF, int MODE>
 __global__ __launch_bounds__ (NT, nway_waves_per_simd (NT)) void
 k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out, u64 *desc, PairControl *ctl)
@@ -874,6 +939,7 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
   constexpr int CAP = Shared::CAP, NW = Shared::NW, NCH = Shared::NCH, NB = Shared::NB;
   constexpr int NWORDS = NB / 2, WPT = NWORDS / NT;
   constexpr int CAPS = Shared::CAPS;
+  constexpr bool LEAD = Shared::LEAD;
   static_assert (NCH <= 2 * WAVE, "one lane per wave slot builds the slot table, in two rounds at most");
   static_assert (WPT * NT == NWORDS && WPT >= 1, "every thread scans the same number of counter words");
   static_assert (NW <= 16 && NW >= 2, "wave totals are reduced by one DPP row");
@@ -1038,7 +1104,9 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
   for (int i = 0; i < WPT; i++) sh.cnt[tid * WPT + i] = 0;
   auto fill_g = [&] () { /* all-ones wherever no key is: what a bucket walk meets behind its bucket must not be smaller than any key */
     static_assert (Shared::GSZ % 2 == 0, "the grouped keys are filled 16 bytes at a time");
-    for (int i = tid; i < Shared::GSZ / 2; i += NT) *reinterpret_cast<u32x4 *> (&sh.g[2 * i]) = u32x4 { ~0u, ~0u, ~0u, ~0u };
+#pragma unroll
+    for (int r = 0; r < Shared::GSZ / 2 / NT; r++) *reinterpret_cast<u32x4 *> (&sh.g ()[2 * (r * NT + tid)]) = u32x4 { ~0u, ~0u, ~0u, ~0u };
+    if (tid < Shared::GSZ / 2 - Shared::GSZ / 2 / NT * NT) *reinterpret_cast<u32x4 *> (&sh.g ()[2 * (Shared::GSZ / 2 / NT * NT + tid)]) = u32x4 { ~0u, ~0u, ~0u, ~0u };
   };
   if (GT4_NWAY_FILL) fill_g ();
   __syncthreads ();
@@ -1092,18 +1160,15 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
     u64 key[RPT];
     u32 cnt[RPT], ba[RPT]; /* ba: bucket | arrival number << 16 | valid << 31 */
 #pragma unroll
-    for (int k = 0; k < RPT; k++) {
-      key[k] = 0;
-      cnt[k] = ba[k] = 0;
-    }
-    if (has_rec) {
+    for (int k = 0; k < RPT; k++) ba[k] = 0;
+    /* (a wavefront without records of this tile keeps whatever the registers hold: its lanes are not valid) */
 #pragma unroll
-      for (int k = 0; k < RPT; k++) {
-        key[k] = (u64) pre[k].x | ((u64) pre[k].y << 32);
-        cnt[k] = pre[k].z;
-      }
+    for (int k = 0; k < RPT; k++) {
+      key[k] = (u64) pre[k].x | ((u64) pre[k].y << 32);
+      cnt[k] = pre[k].z;
     }
     PHASE_STAMP (19); /* (diagnostics: the tile's header) */
+    nway_inject<0> (lds_offset (&sh.hdr[0][0]) + 4u * (u32) lane);
 #ifdef GT4_PROFILE_PHASES
     asm volatile ("s_waitcnt vmcnt(0)" ::: "memory"); /* (the diagnostics build takes the wait for the prefetched records here) */
 #endif
@@ -1116,17 +1181,24 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
     /* one bucketing pass over bucket numbers bk[]: count (arrival numbers), scan, group the keys */
     auto count_pass = [&] (const u32 (&bk)[RPT]) {
       if (has_rec) {
+        u32 c[RPT], old[RPT];
+        if constexpr (RPT == 4) { /* (the wavefront's four slots: one 16-byte read; compared per lane, no scalar copy) */
+          const u32x4 c4 = *reinterpret_cast<const u32x4 *> (&sh.slot_cnt[tb][wid * RPT]);
+          c[0] = c4.x, c[1] = c4.y, c[2] = c4.z, c[3] = c4.w;
+        } else {
+#pragma unroll
+          for (int k = 0; k < RPT; k++) c[k] = sh.slot_cnt[tb][wid * RPT + k];
+        }
+#pragma unroll
+        for (int k = 0; k < RPT; k++) { /* the atomics one behind the other: one wait for all of them */
+          const u32 b = bk[k] < (u32) NB ? bk[k] : (u32) NB - 1u;
+          const u32 vm = (u32) lane < c[k] ? ~0u : 0u;
+          old[k] = atomicAdd (&sh.cnt[nway_pick (vm, b >> 1, (u32) (NB / 2 + 4) + (u32) lane)], 1u << ((b & 1u) * 16u));
+        }
 #pragma unroll
         for (int k = 0; k < RPT; k++) {
-          const int chunk = wid * RPT + k;
-          const u32 c = uniform32 (sh.slot_cnt[tb][chunk]);
           const u32 b = bk[k] < (u32) NB ? bk[k] : (u32) NB - 1u;
-          ba[k] = 0;
-          if ((u32) lane < c) {
-            const u32 s16 = (b & 1u) * 16u;
-            const u32 old = atomicAdd (&sh.cnt[b >> 1], 1u << s16);
-            ba[k] = b | (((old >> s16) & 0x7fffu) << 16) | 0x80000000u;
-          }
+          ba[k] = (u32) lane < c[k] ? b | (((old[k] >> ((b & 1u) * 16u)) & 0x7fffu) << 16) | 0x80000000u : 0u;
         }
       }
     };
@@ -1192,13 +1264,13 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
             for (int j = 0; j < 2 * WPL; j++) {
               const u32 s0 = tbase + ex[j], e0 = tbase + (j + 1 < 2 * WPL ? ex[j + 1 < 2 * WPL ? j + 1 : 0] : tsum);
               if ((e0 >> 5) != (s0 >> 5)) {
-                sh.g[e0 + (s0 >> 5)] = ~0ull;
-                if ((e0 >> 5) - (s0 >> 5) > 1u) sh.g[e0 + (s0 >> 5) + 1u] = ~0ull;
+                sh.g ()[e0 + (s0 >> 5)] = ~0ull;
+                if ((e0 >> 5) - (s0 >> 5) > 1u) sh.g ()[e0 + (s0 >> 5) + 1u] = ~0ull;
               }
             }
           }
         }
-        if (!GT4_NWAY_FILL && tid < NWAY_LIMIT + 2) sh.g[nway_skew (n) + (u32) tid] = ~0ull;
+        if (!GT4_NWAY_FILL && tid < NWAY_LIMIT + 2) sh.g ()[nway_skew (n) + (u32) tid] = ~0ull;
       } else {
       /* ---- scan of the bucket counters: WPT words (two 16-bit counters each) per thread */
       u32 ex[2 * WPT];
@@ -1245,11 +1317,11 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
           for (int j = 0; j < 2 * WPT; j++) {
             const u32 s0 = tbase + ex[j], e0 = tbase + (j + 1 < 2 * WPT ? ex[j + 1 < 2 * WPT ? j + 1 : 0] : tsum);
             if ((e0 >> 5) != (s0 >> 5)) {
-              sh.g[e0 + (s0 >> 5)] = ~0ull;
-              if ((e0 >> 5) - (s0 >> 5) > 1u) sh.g[e0 + (s0 >> 5) + 1u] = ~0ull;
+              sh.g ()[e0 + (s0 >> 5)] = ~0ull;
+              if ((e0 >> 5) - (s0 >> 5) > 1u) sh.g ()[e0 + (s0 >> 5) + 1u] = ~0ull;
             }
           }
-          if (tid < NWAY_LIMIT + 2) sh.g[nway_skew (n) + (u32) tid] = ~0ull; /* (+2: the walks read two steps ahead) */
+          if (tid < NWAY_LIMIT + 2) sh.g ()[nway_skew (n) + (u32) tid] = ~0ull; /* (+2: the walks read two steps ahead) */
         }
       }
       }
@@ -1267,13 +1339,16 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
       for (int k = 0; k < RPT; k++) st[k] = 0;
       accepted = mx <= limit;
       if (has_rec && accepted) {
+        u32 w0[RPT];
+#pragma unroll
+        for (int k = 0; k < RPT; k++) w0[k] = sh.cnt[(ba[k] & 0xffffu) >> 1]; /* (word 0 where no record is) */
 #pragma unroll
         for (int k = 0; k < RPT; k++) {
           const u32 b = ba[k] & 0xffffu;
-          const u32 w0 = sh.cnt[b >> 1];
-          const u32 s = (b & 1u) ? w0 >> 16 : w0; /* start of the bucket */
-          st[k] = (ba[k] >> 31) ? (s & 0xffffu) : 0u;
-          if (ba[k] >> 31) sh.g[nway_skew (st[k]) + ((ba[k] >> 16) & 0x7fffu)] = key[k]; /* a bucket's keys stay together */
+          const u32 s = (b & 1u) ? w0[k] >> 16 : w0[k]; /* start of the bucket */
+          const u32 vm = nway_valid_mask (ba[k]);
+          st[k] = s & 0xffffu & vm;
+          sh.g ()[nway_pick (vm, nway_skew (st[k]) + ((ba[k] >> 16) & 0x7fffu), (u32) Shared::GSZ + (u32) lane)] = key[k]; /* a bucket's keys stay together */
         }
       }
       PHASE_STAMP (6);
@@ -1332,17 +1407,20 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
         }
         bk[k] = (b << sub_bits) + sub;
       }
+      if (LEAD) { /* the pivot keys lay where the grouped keys go */
+        __syncthreads ();
+        fill_g ();
+      }
     };
     {
       u32 bk[RPT];
       if (__builtin_expect (pivot_first, 0)) {
         pivot_buckets (bk);
       } else {
+        /* (a tile whose shifted key range is below the number of buckets: v itself, less one -- the same multiply, no branch) */
+        const u32 mul = bk_direct ? 0xffffffffu : bk_mul;
 #pragma unroll
-        for (int k = 0; k < RPT; k++) {
-          const u32 v = (u32) ((key[k] - key_lo) >> bk_sh);
-          bk[k] = bk_direct ? v : __umulhi (v, bk_mul);
-        }
+        for (int k = 0; k < RPT; k++) bk[k] = __umulhi ((u32) ((key[k] - key_lo) >> bk_sh), mul);
       }
       count_pass (bk); /* (the atomics first: their round trip overlaps what follows) */
     }
@@ -1356,8 +1434,14 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
     }
     PHASE_STAMP (22); /* (the next tile's fetch issued) */
     /* the ordered tile: counts 0, nothing live */
-    for (int i = 4 * tid; i < CAPS; i += 4 * NT) *reinterpret_cast<u32x4 *> (&sh.s.scnt[i]) = u32x4 { 0, 0, 0, 0 };
-    for (int i = tid; i < (CAPS + 3) / 4; i += NT) sh.live[i] = 0;
+    {
+      static_assert (CAPS % 4 == 0 && CAPS >= 4 * NT, "the ordered tile's counts are zeroed 16 bytes at a time: whole rounds and a part of one");
+#pragma unroll
+      for (int r = 0; r < CAPS / (4 * NT); r++) *reinterpret_cast<u32x4 *> (&sh.s.scnt[4 * (r * NT + tid)]) = u32x4 { 0, 0, 0, 0 };
+      if (tid < (CAPS - CAPS / (4 * NT) * (4 * NT)) / 4) *reinterpret_cast<u32x4 *> (&sh.s.scnt[CAPS / (4 * NT) * (4 * NT) + 4 * tid]) = u32x4 { 0, 0, 0, 0 };
+    }
+    if (!LEAD) for (int i = tid; i < (CAPS + 3) / 4; i += NT) sh.live[i] = 0;
+    if (LEAD && tid < Shared::LW) sh.lead[it & 1][tid] = 0; /* (last read two tiles ago) */
     /* service: the chain words of the tile staged one iteration ago are asked for; they are looked at
      * behind B4 at the earliest (the memory counter retires in order: a look waits for every older
      * operation of this wavefront, the previous write-out's stores included) */
@@ -1374,22 +1458,26 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
      * runs have between two neighbours of the pivot run, whatever the keys' values.  Only a tile that
      * defeats that too (more than NWAY_LIMIT keys in a bucket) takes the full search path below. */
     bucket_pass (p.force_fallback ? 0u : (pivot_first ? (u32) NWAY_LIMIT : (u32) NWAY_TRY0));
-    if (p.force_fallback && mx == 0) accepted = true; /* (an empty tile) */
-    if (__builtin_expect (!accepted && !pivot_first && p.force_fallback != 1, 0)) { /* (cold: laid out behind the loop) */
-      u32 bk[RPT];
-      pivot_buckets (bk);
-      count_pass (bk);
-      bucket_pass ((u32) NWAY_LIMIT);
+    if (__builtin_expect (!accepted, 0)) { /* (cold: laid out behind the loop; ONE test on the usual path) */
+      if (p.force_fallback && mx == 0) {
+        accepted = true; /* (an empty tile) */
+      } else if (!pivot_first && p.force_fallback != 1) {
+        u32 bk[RPT];
+        pivot_buckets (bk);
+        count_pass (bk);
+        bucket_pass ((u32) NWAY_LIMIT);
+      }
     }
 
     /* ---- position of every record = number of smaller keys in the tile */
     u32 pos[RPT];
 #pragma unroll
     for (int k = 0; k < RPT; k++) pos[k] = 0;
+    nway_inject<1> (lds_offset (&sh.hdr[0][0]) + 4u * (u32) lane);
     if (__builtin_expect (accepted, 1)) {
       if (has_rec) {
         u32 lt[RPT], ga[RPT];
-        const u32 g0 = lds_offset (&sh.g[0]);
+        const u32 g0 = lds_offset (&sh.g ()[0]);
 #pragma unroll
         for (int k = 0; k < RPT; k++) {
           lt[k] = 0;
@@ -1397,12 +1485,16 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
         }
         /* every lane runs the longest bucket's length (rounded up to even): behind its own bucket a lane
          * meets larger keys or all-ones */
-        if constexpr (RPT == 4) {
-          nway_rank_steps<0> (mx, ga[0], ga[1], ga[2], ga[3], key, lt);
-        } else {
-          for (u32 j = 0; j < mx; j++) {
 #pragma unroll
-            for (int k = 0; k < RPT; k++) lt[k] += lds_load<u64> (ga[k] + 8u * j) < key[k] ? 1u : 0u;
+        for (int q = 0; q + 4 <= RPT; q += 4)
+          nway_rank_steps<0> (mx, ga[q], ga[q + 1], ga[q + 2], ga[q + 3], *reinterpret_cast<const u64 (*)[4]> (&key[q]), *reinterpret_cast<u32 (*)[4]> (&lt[q]));
+        if constexpr (RPT % 4 != 0) { /* (a fifth position per thread: two steps at a time as well) */
+          for (u32 j = 0; j < mx; j += 2) {
+#pragma unroll
+            for (int k = RPT / 4 * 4; k < RPT; k++) {
+              const u64 r0 = lds_load<u64> (ga[k] + 8u * j), r1 = lds_load<u64> (ga[k] + 8u * j + 8u);
+              lt[k] += (r0 < key[k] ? 1u : 0u) + (r1 < key[k] ? 1u : 0u);
+            }
           }
         }
 #pragma unroll
@@ -1445,6 +1537,8 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
 #pragma unroll
         for (int k = 0; k < RPT; k++) pos[k] += lo[k];
       }
+#pragma unroll
+      for (int k = 0; k < RPT; k++) pos[k] = (ba[k] >> 31) ? pos[k] : 0u; /* (lanes without a record searched with whatever their registers held) */
       __syncthreads ();
       for (int i = 4 * tid; i < CAPS; i += 4 * NT) *reinterpret_cast<u32x4 *> (&sh.s.scnt[i]) = u32x4 { 0, 0, 0, 0 }; /* (the runs lay over the counts) */
       __syncthreads ();
@@ -1452,7 +1546,22 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
     PHASE_STAMP (8);
 
     /* ---- the key once per position, the counts folded by LDS atomics */
-    if (has_rec) {
+    u32 lead_bits = 0;     /* LEAD: record k is the first of its key to arrive at its position (and, behind B5, is kept) */
+    u32 lead_before[RPT];  /* ... its bitmap word as the record found it */
+    if (LEAD && has_rec) {
+      /* straight-line: the folds, then the claims (a lane without a record adds 0 to a word of its own and claims nothing) */
+      if (p.rule == 1u) {
+#pragma unroll
+        for (int k = 0; k < RPT; k++) atomicAdd (&sh.s.scnt[nway_pick (nway_valid_mask (ba[k]), nway_skew (pos[k]), (u32) lane)], cnt[k] & nway_valid_mask (ba[k]));
+      } else if (p.rule == 4u) {
+#pragma unroll
+        for (int k = 0; k < RPT; k++) atomicMax (&sh.s.scnt[nway_pick (nway_valid_mask (ba[k]), nway_skew (pos[k]), (u32) lane)], cnt[k] & nway_valid_mask (ba[k]));
+      }
+#pragma unroll
+      for (int k = 0; k < RPT; k++)
+        lead_before[k] = atomicOr (&sh.lead[it & 1][nway_pick (nway_valid_mask (ba[k]), pos[k] >> 5, (u32) lane)], (1u << (pos[k] & 31u)) & nway_valid_mask (ba[k]));
+    }
+    if (!LEAD && has_rec) {
 #pragma unroll
       for (int k = 0; k < RPT; k++) {
         if (!(ba[k] >> 31)) continue;
@@ -1528,6 +1637,80 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
     if (GT4_NWAY_FILL) fill_g (); /* every walk of this tile is behind B5: the grouped keys of the next tile start from all-ones */
     PHASE_STAMP (12);
 
+    u32 tile_total;
+    if constexpr (LEAD) {
+      /* ---- the leaders look at the folded counts: cutoff, sum of the kept counts; a leader that is not kept gives
+       * its bit back */
+      u32 lf[RPT];
+#pragma unroll
+      for (int k = 0; k < RPT; k++) lf[k] = 0;
+      if (has_rec) {
+        /* (every lane reads: position 0 where no record is) */
+        if (p.rule == 7u) {
+#pragma unroll
+          for (int k = 0; k < RPT; k++) lf[k] = p.count_override;
+        } else {
+#pragma unroll
+          for (int k = 0; k < RPT; k++) lf[k] = lds_load<u32> (lds_offset (&sh.s.scnt[0]) + 4u * nway_skew (pos[k]));
+        }
+        const u32 least = p.filter == FILTER_RAW ? 0u : p.cutoff; /* kept iff the folded count reaches it */
+        u32 drop = 0;
+#pragma unroll
+        for (int k = 0; k < RPT; k++) { /* (masks, not conditions: see nway_pick) */
+          const u32 leads = nway_valid_mask (ba[k]) & (((lead_before[k] >> (pos[k] & 31u)) & 1u) - 1u);
+          const u32 enough = lf[k] >= least ? ~0u : 0u;
+          acc_sum += lf[k] & leads & enough;
+          lead_bits |= leads & enough & (1u << k);
+          drop |= leads & ~enough & (1u << k);
+        }
+        if (drop) { /* (rare: a cutoff above the counts) */
+#pragma unroll
+          for (int k = 0; k < RPT; k++)
+            if ((drop >> k) & 1u) atomicAnd (&sh.lead[it & 1][pos[k] >> 5], ~(1u << (pos[k] & 31u)));
+        }
+      }
+      PHASE_STAMP (13);
+      __syncthreads (); /* B6: the bitmap holds the kept leaders; the staging area is free */
+      PHASE_STAMP (14);
+      nway_inject<2> (lds_offset (&sh.hdr[0][0]) + 4u * (u32) lane);
+      /* kept leaders in front of every bitmap word: every wavefront scans the bitmap itself (LWL words per lane) */
+      constexpr int LWL = Shared::LWL;
+      u32 w[LWL], c = 0;
+#pragma unroll
+      for (int j = 0; j < LWL; j++) {
+        w[j] = sh.lead[it & 1][lane * LWL + j];
+        c += (u32) __popc (w[j]);
+      }
+      const u32 incl = dpp_inclusive_scan_u32 (c);
+      tile_total = (u32) __builtin_amdgcn_readlane ((int) incl, WAVE - 1);
+      blk_cnt += tile_total;
+      if (MODE == NWAY_UNION && service) {
+        if (lane == 0) publish_u32 (&agg[cur], AGG_READY | tile_total);
+      }
+      if (MODE == NWAY_COUNT && tid == 0 && p.tile_totals) p.tile_totals[cur] = tile_total;
+      if (nway_staged (MODE) && has_rec) {
+        u32 before = incl - c;
+#pragma unroll
+        for (int j = 0; j < LWL; j++) { /* (every lane its words, whether it holds a leader or not) */
+          sh.wpre[wid][lane * LWL + j] = (unsigned short) before;
+          before += (u32) __popc (w[j]);
+        }
+        /* (the table is this wavefront's own: LDS operations of one wavefront complete in order) */
+        u32 pw[RPT], lw[RPT];
+#pragma unroll
+        for (int k = 0; k < RPT; k++) {
+          pw[k] = sh.wpre[wid][pos[k] >> 5];
+          lw[k] = sh.lead[it & 1][pos[k] >> 5];
+        }
+#pragma unroll
+        for (int k = 0; k < RPT; k++) { /* (what is not kept goes to the lane's trash record) */
+          const u32 slot = nway_pick (0u - ((lead_bits >> k) & 1u), pw[k] + (u32) __popc (lw[k] & ((1u << (pos[k] & 31u)) - 1u)), (u32) CAP + 2u + (u32) lane);
+          sh.stage[3 * slot] = (u32) key[k];
+          sh.stage[3 * slot + 1] = (u32) (key[k] >> 32);
+          sh.stage[3 * slot + 2] = lf[k];
+        }
+      }
+    } else {
     /* ---- positions in order, one per lane (a wavefront walks its RPT chunks of 64): keep test, ballots */
     u64 okey[RPT];
     u32 ocnt[RPT];
@@ -1571,7 +1754,6 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
     PHASE_STAMP (13);
     __syncthreads (); /* B6: kept per wavefront; the staging area is free */
     PHASE_STAMP (14);
-    u32 tile_total;
     {
       const u32 x = lane < NW ? sh.wkept[lane] : 0u;
       const u32 incl2 = dpp_inclusive_scan_u32 (x);
@@ -1634,6 +1816,7 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
         __syncthreads (); /* (the rows lie where the next tile's counts are zeroed) */
       }
     }
+    } /* (!LEAD) */
     pend = nway_staged (MODE);
     pend_tot = tile_total;
     pend_tile = cur;
@@ -1670,14 +1853,19 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
 }
 
 constexpr int NWAY_NT = GT4_NWAY_NT;
-constexpr int NWAY_RPT = GT4_NWAY_RPT;
 constexpr int NWAY_NBF = GT4_NWAY_NBF;
-constexpr int NWAY_CAP = NWAY_NT * NWAY_RPT;
+/* positions per thread: the modes that keep no ordered copy of the tile (GT4_NWAY_LEAD) have LDS for one more */
+#ifndef GT4_NWAY_RPT_LEAD
+#define GT4_NWAY_RPT_LEAD GT4_NWAY_RPT
+#endif
+constexpr int nway_rpt (int mode) { return nway_lead (mode) ? GT4_NWAY_RPT_LEAD : GT4_NWAY_RPT; }
+constexpr int nway_cap (int mode) { return NWAY_NT * nway_rpt (mode); }
+constexpr int NWAY_CAP_MIN = NWAY_NT * (GT4_NWAY_RPT_LEAD < GT4_NWAY_RPT ? GT4_NWAY_RPT_LEAD : GT4_NWAY_RPT);
 
 template <int MODE>
 hipError_t launch_nway (hipStream_t s, int grid, const NwayParams &p, const u64 *part, u32 *out, u64 *desc, PairControl *ctl)
 {
-  hipLaunchKernelGGL ((k_nway_merge<NWAY_NT, NWAY_RPT, NWAY_NBF, MODE>), dim3 (grid), dim3 (NWAY_NT), 0, s, p, part, out, desc, ctl);
+  hipLaunchKernelGGL ((k_nway_merge<NWAY_NT, nway_rpt (MODE), NWAY_NBF, MODE>), dim3 (grid), dim3 (NWAY_NT), 0, s, p, part, out, desc, ctl);
   return hipGetLastError ();
 }
 
@@ -1696,11 +1884,11 @@ int nway_blocks_per_cu (int mode)
   if (!cache[mode]) {
     int n = 0;
     hipError_t e;
-    if (mode == NWAY_DUPS) e = hipOccupancyMaxActiveBlocksPerMultiprocessor (&n, k_nway_merge<NWAY_NT, NWAY_RPT, NWAY_NBF, NWAY_DUPS>, NWAY_NT, 0);
-    else if (mode == NWAY_COUNT) e = hipOccupancyMaxActiveBlocksPerMultiprocessor (&n, k_nway_merge<NWAY_NT, NWAY_RPT, NWAY_NBF, NWAY_COUNT>, NWAY_NT, 0);
-    else if (mode == NWAY_TABLE) e = hipOccupancyMaxActiveBlocksPerMultiprocessor (&n, k_nway_merge<NWAY_NT, NWAY_RPT, NWAY_NBF, NWAY_TABLE>, NWAY_NT, 0);
-    else if (mode == NWAY_PROBE) e = hipOccupancyMaxActiveBlocksPerMultiprocessor (&n, k_nway_merge<NWAY_NT, NWAY_RPT, NWAY_NBF, NWAY_PROBE>, NWAY_NT, 0);
-    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor (&n, k_nway_merge<NWAY_NT, NWAY_RPT, NWAY_NBF, NWAY_UNION>, NWAY_NT, 0);
+    if (mode == NWAY_DUPS) e = hipOccupancyMaxActiveBlocksPerMultiprocessor (&n, k_nway_merge<NWAY_NT, nway_rpt (NWAY_DUPS), NWAY_NBF, NWAY_DUPS>, NWAY_NT, 0);
+    else if (mode == NWAY_COUNT) e = hipOccupancyMaxActiveBlocksPerMultiprocessor (&n, k_nway_merge<NWAY_NT, nway_rpt (NWAY_COUNT), NWAY_NBF, NWAY_COUNT>, NWAY_NT, 0);
+    else if (mode == NWAY_TABLE) e = hipOccupancyMaxActiveBlocksPerMultiprocessor (&n, k_nway_merge<NWAY_NT, nway_rpt (NWAY_TABLE), NWAY_NBF, NWAY_TABLE>, NWAY_NT, 0);
+    else if (mode == NWAY_PROBE) e = hipOccupancyMaxActiveBlocksPerMultiprocessor (&n, k_nway_merge<NWAY_NT, nway_rpt (NWAY_PROBE), NWAY_NBF, NWAY_PROBE>, NWAY_NT, 0);
+    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor (&n, k_nway_merge<NWAY_NT, nway_rpt (NWAY_UNION), NWAY_NBF, NWAY_UNION>, NWAY_NT, 0);
     if (e != hipSuccess || n < 1) n = 1;
     const int by_regs = nway_waves_per_simd (NWAY_NT) * 4 / (NWAY_NT / 64);
     if (by_regs >= 1 && n > by_regs) n = by_regs;
@@ -1751,12 +1939,12 @@ int nway_grow (gt4hip_context *ctx, void **p, size_t *have, size_t need)
  * to whole wavefronts.  `sure`: the G for which no tile can overflow; the first try takes the expected
  * tile (G * S records) plus GT4_NWAY_MARGIN (five) standard deviations of the lists' offsets against their sample grids; tiles beyond the
  * capacity are cut in two (k_nway_emit). */
-void nway_samples_per_tile (u32 k, u32 *first_try, u32 *sure)
+void nway_samples_per_tile (u32 k, int positions, u32 *first_try, u32 *sure)
 {
-  const double cap = (double) NWAY_CAP - 32.0 * k; /* half a wavefront of padding per run, on average */
+  const double cap = (double) positions - 32.0 * k; /* half a wavefront of padding per run, on average */
   const double margin = GT4_NWAY_MARGIN * NWAY_SAMPLE * sqrt ((double) k / 6.0);
   long g1 = (long) ((cap - margin) / NWAY_SAMPLE);
-  long g0 = ((long) NWAY_CAP - 64L * k) / NWAY_SAMPLE - (2L * k - 1);
+  long g0 = ((long) positions - 64L * k) / NWAY_SAMPLE - (2L * k - 1);
   if (g0 < 1) g0 = 1;
   if (g1 < g0) g1 = g0;
   *first_try = (u32) g1;
@@ -1803,7 +1991,7 @@ static int nway_run (gt4hip_context *ctx, const gt4hip_list *const lists[], uint
       const u32 windows = (u32) (nl / (4 * NWAY_PROBE_KEYS) < NWAY_PROBE_WINDOWS ? nl / (4 * NWAY_PROBE_KEYS) : NWAY_PROBE_WINDOWS);
       hipError_t e = hipMemsetAsync (ctx->scratch, 0, 64, st);
       if (e == hipSuccess) {
-        hipLaunchKernelGGL (k_nway_probe, dim3 (windows), dim3 (256), 0, st, (const u32 *) lists[longest]->dev, nl, windows, (u32) (NWAY_NBF * NWAY_CAP), (u32 *) ctx->scratch);
+        hipLaunchKernelGGL (k_nway_probe, dim3 (windows), dim3 (256), 0, st, (const u32 *) lists[longest]->dev, nl, windows, (u32) nway_buckets (NWAY_NBF * nway_cap (NWAY_UNION)), (u32 *) ctx->scratch);
         e = hipMemcpyAsync (ctx->scratch_host, ctx->scratch, 8, hipMemcpyDeviceToHost, st);
       }
       if (e == hipSuccess) e = hipStreamSynchronize (st);
@@ -1815,7 +2003,7 @@ static int nway_run (gt4hip_context *ctx, const gt4hip_list *const lists[], uint
     }
   }
   /* sample levels until one fits a single tile */
-  const u64 one_tile = (u64) NWAY_CAP - 64ull * k;
+  const u64 one_tile = (u64) NWAY_CAP_MIN - 64ull * k;
   while (levels.back ().total > one_tile) {
     const Level &lo = levels.back ();
     Level up;
@@ -1842,12 +2030,15 @@ static int nway_run (gt4hip_context *ctx, const gt4hip_list *const lists[], uint
   }
   /* top-down: the merged samples of level l+1 cut level l into tiles */
   gt4hip_list *merged = NULL; /* merged sample records of the level above */
-  u32 g_try, g_sure;
-  nway_samples_per_tile (k, &g_try, &g_sure);
-  if (ctx->kway_g > 0) g_try = (u32) ctx->kway_g;
   for (int l = (int) levels.size () - 1; l >= 0 && !rc; l--) {
     Level &lv = levels[l];
     const u64 m_total = merged ? merged->n_words : 0;
+    const int mode = l > 0 ? NWAY_DUPS : (table ? (probe ? NWAY_PROBE : NWAY_TABLE) : (count_only ? NWAY_COUNT : NWAY_UNION));
+    const int cap = nway_cap (mode); /* positions of a tile */
+    const u32 n_buckets = (u32) nway_buckets (NWAY_NBF * cap);
+    u32 g_try, g_sure;
+    nway_samples_per_tile (k, cap, &g_try, &g_sure);
+    if (ctx->kway_g > 0) g_try = (u32) ctx->kway_g;
     u32 G = g_try;
     u64 tiles = 1;
     const u64 *part_final = NULL; /* the table the tile kernel reads: the partition's, or the one with the split tiles */
@@ -1866,12 +2057,12 @@ static int nway_run (gt4hip_context *ctx, const gt4hip_list *const lists[], uint
         if ((rc = nway_grow (ctx, (void **) &ctx->kway_cnt, &ctx->kway_cnt_bytes, (size_t) n_br * NWAY_MAX * 4))) break;
         hipLaunchKernelGGL (k_nway_sample_counts, dim3 ((unsigned) ((n_br + 3) / 4)), dim3 (256), 0, st, (const u32 *) merged->dev, m_total, G, n_br, (u32 *) ctx->kway_cnt);
         hipLaunchKernelGGL (k_nway_bracket_bases, dim3 (1), dim3 (64 * NWAY_MAX), 0, st, (u32 *) ctx->kway_cnt, n_br);
-        hipLaunchKernelGGL (k_nway_partition_rows, dim3 ((unsigned) n_br), dim3 (64), 0, st, lv.p, (const u32 *) merged->dev, m_total, G, (u32) (NWAY_NBF * NWAY_CAP),
+        hipLaunchKernelGGL (k_nway_partition_rows, dim3 ((unsigned) n_br), dim3 (64), 0, st, lv.p, (const u32 *) merged->dev, m_total, G, n_buckets,
                             (const u32 *) ctx->kway_cnt, (u64 *) ctx->kway_part);
       } else {
         for (int pass = 0; pass < 2; pass++)
           hipLaunchKernelGGL (k_nway_partition, dim3 ((unsigned) ((threads + 255) / 256)), dim3 (256), 0, st, lv.p, merged ? (const u32 *) merged->dev : NULL,
-                              m_total, G, (u32) (NWAY_NBF * NWAY_CAP), (u64 *) ctx->kway_part, pass);
+                              m_total, G, n_buckets, (u64 *) ctx->kway_part, pass);
       }
       /* tiles that do not fit are cut in two (k_nway_need / _scan / _emit): flags = { more than two pieces,
        * clustered tiles, tiles cut, tiles of the final table } */
@@ -1879,7 +2070,7 @@ static int nway_run (gt4hip_context *ctx, const gt4hip_list *const lists[], uint
       if ((rc = nway_grow (ctx, (void **) &ctx->kway_need, &ctx->kway_need_bytes, (size_t) (tiles + 1 + n_blocks + 4) * 4))) break;
       u32 *const need = (u32 *) ctx->kway_need, *const block_sums = need + tiles + 1;
       hipMemsetAsync (ctx->scratch, 0, 64, st);
-      hipLaunchKernelGGL (k_nway_need, dim3 ((unsigned) n_blocks), dim3 (NWAY_SPLIT_BLOCK), 0, st, (const u64 *) ctx->kway_part, (u32) tiles, (u32) (NWAY_CAP / WAVE), need, block_sums,
+      hipLaunchKernelGGL (k_nway_need, dim3 ((unsigned) n_blocks), dim3 (NWAY_SPLIT_BLOCK), 0, st, (const u64 *) ctx->kway_part, (u32) tiles, (u32) (cap / WAVE), need, block_sums,
                           (u32 *) ctx->scratch);
       hipLaunchKernelGGL (k_nway_need_scan, dim3 (1), dim3 (1024), 0, st, block_sums, (u32) n_blocks, (u32 *) ctx->scratch + 3);
       hipError_t e = hipMemcpyAsync (ctx->scratch_host, ctx->scratch, 16, hipMemcpyDeviceToHost, st);
@@ -1895,7 +2086,7 @@ static int nway_run (gt4hip_context *ctx, const gt4hip_list *const lists[], uint
         const u64 tiles2 = fl[3];
         if ((rc = nway_grow (ctx, (void **) &ctx->kway_part2, &ctx->kway_part2_bytes, (size_t) (tiles2 + 1) * NWAY_PSTRIDE * 8))) break;
         hipLaunchKernelGGL (k_nway_emit, dim3 ((unsigned) n_blocks), dim3 (NWAY_SPLIT_BLOCK), 0, st, lv.p, (const u64 *) ctx->kway_part, (u32) tiles, need, block_sums,
-                            (u32) (NWAY_NBF * NWAY_CAP), (u32) (NWAY_CAP / WAVE), (u64 *) ctx->kway_part2, (u32 *) ctx->scratch);
+                            n_buckets, (u32) (cap / WAVE), (u64 *) ctx->kway_part2, (u32 *) ctx->scratch);
         e = hipMemcpyAsync (ctx->scratch_host + 4, ctx->scratch, 4, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize (st);
         if (e != hipSuccess) {
@@ -1942,7 +2133,6 @@ static int nway_run (gt4hip_context *ctx, const gt4hip_list *const lists[], uint
     lv.p.filter = filter;
     lv.p.spin_limit = ctx->spin_limit;
     lv.p.force_fallback = ctx->kway_vt == 99 ? 1u : (ctx->kway_vt == 98 ? 2u : 0u); /* option "kway_vt" = 99 / 98: every tile takes the search path / the pivot-run buckets (tests) */
-    const int mode = l > 0 ? NWAY_DUPS : (table ? (probe ? NWAY_PROBE : NWAY_TABLE) : (count_only ? NWAY_COUNT : NWAY_UNION));
     lv.p.scan_group = ctx->scan_group > 0 ? 1u : (ctx->scan_group < 0 ? 0u : (tiles > (48000ull << 6) ? 1u : 0u));
     lv.p.dynamic = ctx->dynamic > 0 ? 1u : (ctx->dynamic < 0 ? 0u : (mode == NWAY_UNION ? 1u : 0u));
     u32 *dst = NULL;

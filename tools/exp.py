@@ -4,7 +4,7 @@
 exp_skew.py, exp_sort.py, exp_table.py ...: their profiles' READMEs name them; the sub-commands below are the same
 drivers.)
 
-  exp.py union8 [--n N] [--lists L] [--dist D] [--kway 0,1] [--reps R] [--g G]
+  exp.py union8 [--n N] [--lists L] [--dist D] [--kway 0,1] [--reps R] [--g G] [--count-only]
         N-way union of the bench's lists: pairwise tree (kway 0) against the library's choice (1) / the one-pass
         tile kernel forced (3); totals and a hash of head and tail must agree between the runs
   exp.py dists [--n N] [--n8 N8] [--dists a,b,..]
@@ -54,9 +54,16 @@ def time_pair(ctx, tag, a, b, ops, cutoff=1, reps=3):
     return ms
 
 
-def time_nway(ctx, tag, lists, kway, reps=3):
+def time_nway(ctx, tag, lists, kway, reps=3, count_only=False):
     ctx.set_option("kway", kway)
     sig = None
+    if count_only:
+        for _ in range(reps):
+            r = ctx.union_multi(lists, count_only=True)
+        one = ctx.get_counter("nway_one_pass")
+        print("%-44s kway %d -> %-8s count only: call %7.2f ms (tile kernel %6.2f)  %s" % (tag, kway, "one pass" if one else "tree", ctx.last_multi_device_ms,
+              ctx.get_counter("nway_kernel_us") / 1000.0 if one else 0.0, r[:3]), flush=True)
+        return ctx.last_multi_device_ms, tuple(r[:3])
     for _ in range(reps):
         rc, nw, tot, o = ctx.union_multi(lists)
         m = min(nw, 100000)
@@ -81,7 +88,7 @@ def cmd_union8(a):
     print("generated", [l.n_words for l in lists], flush=True)
     ref = None
     for kway in [int(x) for x in a.kway.split(",")]:
-        _, sig = time_nway(ctx, "%s %d x %d" % (a.dist, a.lists, a.n), lists, kway, a.reps)
+        _, sig = time_nway(ctx, "%s %d x %d" % (a.dist, a.lists, a.n), lists, kway, a.reps, a.count_only)
         if ref is None:
             ref = sig
         print("   ", "same as the first run" if sig == ref else "DIFFERS from the first run: %s vs %s" % (sig, ref), flush=True)
@@ -246,6 +253,7 @@ def main():
     p.add_argument("--kway", default="0,1")
     p.add_argument("--reps", type=int, default=3)
     p.add_argument("--g", type=int, default=0)
+    p.add_argument("--count-only", action="store_true")
     p = sub.add_parser("pair")
     p.add_argument("--n", type=int, default=2_000_000_000)
     p.add_argument("--dist", default="stride")
