@@ -1688,6 +1688,7 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
         if (lane == 0) publish_u32 (&agg[cur], AGG_READY | tile_total);
       }
       if (MODE == NWAY_COUNT && tid == 0 && p.tile_totals) p.tile_totals[cur] = tile_total;
+      PHASE_STAMP (16); /* (diagnostics, wavefronts other than the service one: the bitmap scan) */
       if (nway_staged (MODE) && has_rec) {
         u32 before = incl - c;
 #pragma unroll
@@ -1702,6 +1703,7 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
           pw[k] = sh.wpre[wid][pos[k] >> 5];
           lw[k] = sh.lead[it & 1][pos[k] >> 5];
         }
+        PHASE_STAMP (17); /* (diagnostics: prefix table written, words asked for) */
 #pragma unroll
         for (int k = 0; k < RPT; k++) { /* (what is not kept goes to the lane's trash record) */
           const u32 slot = nway_pick (0u - ((lead_bits >> k) & 1u), pw[k] + (u32) __popc (lw[k] & ((1u << (pos[k] & 31u)) - 1u)), (u32) CAP + 2u + (u32) lane);
