@@ -20,11 +20,17 @@
  *      smaller keys there -- a handful of INDEPENDENT 8-byte LDS reads (no dependent chain), all
  *      lanes running the same number of steps;
  *   4. position = bucket start + rank = number of smaller keys in the tile.  Equal keys of different
- *      lists get the same position: the key is stored there once and the counts are FOLDED by an LDS
- *      atomic (add: u32 wrap as the reference's unsigned sum; max), a byte marks the position live;
- *   5. positions in order: live ones with count >= cutoff are the tile's output -- ballots and prefix
- *      sums compact them into a staging area, written out during the next tile at the offset the
- *      chained scan of tile totals (gt4hip_device.h) has published by then.
+ *      lists get the same position: the counts are FOLDED there by an LDS atomic (add: u32 wrap as the
+ *      reference's unsigned sum; max);
+ *   5. (union, count-only: GT4_NWAY_LEAD) the first record to set its position's bit in a bitmap LEADS
+ *      the position: it reads the folded count, applies the cutoff, and its place in the staging area is
+ *      the number of bits below its own (popcount prefix, worked out by every wavefront for itself);
+ *      (merged samples, count tables) the key is stored once per position, a byte marks the position
+ *      live, positions in order: live ones are the tile's output, ballots and prefix sums compact them;
+ *      the staging area is written out during the next tile at the offset the chained scan of tile
+ *      totals (gt4hip_device.h) has published by then.
+ *   Every per-record step is straight-line code: all LDS reads of a thread's records before the first
+ *   wait, lanes without a (kept) record store into trash rows instead of branching around the store.
  *
  * The interpolation is only a heuristic for SPEED: a tile whose keys cluster (a bucket with more than
  * NWAY_TRY0 keys) is bucketed again by rank in its longest run (NWAY_LIMIT), and one that defeats that
