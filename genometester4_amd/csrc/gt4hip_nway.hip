@@ -1436,7 +1436,14 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
      * tile per workgroup is all that is in flight. */
     {
       const u32 nxt = uniform32 (sh.hdr[tb1][0]);
-      if (nxt < ntl && (u32) (wid * RPT) < uniform32 (sh.hdr[tb1][2])) fetch (tb1);
+      if (nxt < ntl && (u32) (wid * RPT) < uniform32 (sh.hdr[tb1][2])) {
+        fetch (tb1);
+      } else {
+        /* nothing to fetch: the fetch registers may hold anything (said so, or the compiler keeps their old values alive
+         * through this arm and copies all twelve on both arms: 24 moves per wavefront and tile) */
+#pragma unroll
+        for (int k = 0; k < RPT; k++) asm volatile ("" : "=v"(pre[k].x), "=v"(pre[k].y), "=v"(pre[k].z));
+      }
     }
     PHASE_STAMP (22); /* (the next tile's fetch issued) */
     /* the ordered tile: counts 0, nothing live */
