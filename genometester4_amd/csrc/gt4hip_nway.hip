@@ -100,6 +100,9 @@ __host__ __device__ constexpr bool nway_staged (int mode) { return mode == NWAY_
 #ifndef GT4_NWAY_LEAD
 #define GT4_NWAY_LEAD 1
 #endif
+#ifndef GT4_NWAY_LEAD_BITS
+#define GT4_NWAY_LEAD_BITS 16
+#endif
 __host__ __device__ constexpr bool nway_lead (int mode) { return GT4_NWAY_LEAD && (mode == NWAY_UNION || mode == NWAY_COUNT); }
 
 struct NwayParams {
@@ -829,8 +832,14 @@ struct NwayShared {
   static constexpr int CAPS = CAP + CAP / 32;                 /* skewed positions */
   static constexpr int GSZ = (CAPS + NWAY_LIMIT + 5) & ~1;    /* grouped keys: + the longest bucket walk behind the last key */
   static constexpr bool LEAD = nway_lead (MODE);
-  static constexpr int LWL = (CAP / 32 + WAVE - 1) / WAVE;    /* LEAD: bitmap words per lane of a scanning wavefront */
-  static constexpr int LW = LWL * WAVE;                       /* ... bitmap words (one bit per position, padded) */
+  /* LEAD: the bitmap holds GT4_NWAY_LEAD_BITS positions per 32-bit word.  The 64 records of a wave-instruction come
+   * from one sorted list and lie about as many positions apart as there are lists, so with 32 positions per word four
+   * lanes claim bits of the SAME word in one atomic instruction, which the LDS serialises; fewer positions per word
+   * make the claims cheaper and the scan behind B6 longer.  Measured (8 x 5e8 stride lists, tile kernel ms): 32 bits
+   * 28.72, 16 bits 28.59, 8 bits 28.84, 4 bits 29.98; independent / genomic keys gain 1 - 2 % from 8 against 32. */
+  static constexpr int LBP = GT4_NWAY_LEAD_BITS;              /* positions per bitmap word (a power of two) */
+  static constexpr int LWL = (CAP / LBP + WAVE - 1) / WAVE;   /* bitmap words per lane of a scanning wavefront */
+  static constexpr int LW = LWL * WAVE;                       /* ... bitmap words (padded) */
   union {
     struct {
       alignas (16) u64 skey[LEAD ? GSZ + WAVE : CAPS];        /* LEAD: the grouped keys live here (+ a row nobody reads: see the trash rows) */
@@ -929,6 +938,12 @@ __device__ __forceinline__ u64 readlane_u64 (u64 v, int l)
  * GT4_NWAY_INJ_AT -- what a saturated unit charges for them is how the tile's time is told apart) */
 #ifndef GT4_NWAY_INJ_VALU
 #define GT4_NWAY_INJ_VALU 0
+#endif
+/* (diagnostics, results INVALID: bit mask of LDS access classes that go to lane-linear, conflict-free addresses instead of
+ * their own -- 1 bucket-count atomics, 2 grouped-key stores, 4 bucket walks, 8 fold atomics, 16 bitmap claims, 32 staging
+ * stores, 64 leaders' count reads -- to tell which of them the LDS bank conflicts belong to) */
+#ifndef GT4_NWAY_NOCONF
+#define GT4_NWAY_NOCONF 0
 #endif
 #ifndef GT4_NWAY_INJ_SALU
 #define GT4_NWAY_INJ_SALU 0
@@ -1225,7 +1240,7 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
         for (int k = 0; k < RPT; k++) { /* the atomics one behind the other: one wait for all of them */
           const u32 b = bk[k] < (u32) NB ? bk[k] : (u32) NB - 1u;
           const u32 vm = (u32) lane < c[k] ? ~0u : 0u;
-          old[k] = atomicAdd (&sh.cnt[nway_pick (vm, b >> 1, (u32) (NB / 2 + 4) + (u32) lane)], 1u << ((b & 1u) * 16u));
+          old[k] = atomicAdd (&sh.cnt[(GT4_NWAY_NOCONF & 1) ? (u32) (NB / 2 + 4) + (u32) lane : nway_pick (vm, b >> 1, (u32) (NB / 2 + 4) + (u32) lane)], 1u << ((b & 1u) * 16u));
         }
 #pragma unroll
         for (int k = 0; k < RPT; k++) {
@@ -1380,7 +1395,7 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
           const u32 s = (b & 1u) ? w0[k] >> 16 : w0[k]; /* start of the bucket */
           const u32 vm = nway_valid_mask (ba[k]);
           st[k] = s & 0xffffu & vm;
-          sh.g ()[nway_pick (vm, nway_skew (st[k]) + ((ba[k] >> 16) & 0x7fffu), (u32) Shared::GSZ + (u32) lane)] = key[k]; /* a bucket's keys stay together */
+          sh.g ()[(GT4_NWAY_NOCONF & 2) ? (u32) Shared::GSZ + (u32) lane : nway_pick (vm, nway_skew (st[k]) + ((ba[k] >> 16) & 0x7fffu), (u32) Shared::GSZ + (u32) lane)] = key[k]; /* a bucket's keys stay together */
         }
       }
       PHASE_STAMP (6);
@@ -1480,7 +1495,10 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
       if (tid < (CAPS - CAPS / (4 * NT) * (4 * NT)) / 4) *reinterpret_cast<u32x4 *> (&sh.s.scnt[CAPS / (4 * NT) * (4 * NT) + 4 * tid]) = u32x4 { 0, 0, 0, 0 };
     }
     if (!LEAD) for (int i = tid; i < (CAPS + 3) / 4; i += NT) sh.live[i] = 0;
-    if (LEAD && tid < Shared::LW) sh.lead[it & 1][tid] = 0; /* (last read two tiles ago) */
+    if (LEAD) { /* (last read two tiles ago) */
+      static_assert (!LEAD || Shared::LW % 4 == 0, "the bitmap is zeroed 16 bytes at a time");
+      for (int i = tid; i < Shared::LW / 4; i += NT) *reinterpret_cast<u32x4 *> (&sh.lead[it & 1][4 * i]) = u32x4 { 0, 0, 0, 0 };
+    }
     /* service: the chain words of the tile staged one iteration ago are asked for; they are looked at
      * behind B4 at the earliest (the memory counter retires in order: a look waits for every older
      * operation of this wavefront, the previous write-out's stores included) */
@@ -1520,7 +1538,7 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
 #pragma unroll
         for (int k = 0; k < RPT; k++) {
           lt[k] = 0;
-          ga[k] = g0 + 8u * nway_skew (st[k]);
+          ga[k] = (GT4_NWAY_NOCONF & 4) ? g0 + 8u * (u32) lane : g0 + 8u * nway_skew (st[k]);
         }
         /* every lane runs the longest bucket's length (rounded up to even): behind its own bucket a lane
          * meets larger keys or all-ones */
@@ -1582,6 +1600,10 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
       for (int i = 4 * tid; i < CAPS; i += 4 * NT) *reinterpret_cast<u32x4 *> (&sh.s.scnt[i]) = u32x4 { 0, 0, 0, 0 }; /* (the runs lay over the counts) */
       __syncthreads ();
     }
+    if (GT4_NWAY_NOCONF) { /* (diagnostics: whatever the misdirected accesses made of the positions stays inside the tile) */
+#pragma unroll
+      for (int k = 0; k < RPT; k++) pos[k] = pos[k] < (u32) CAP ? pos[k] : (u32) CAP - 1u;
+    }
     PHASE_STAMP (8);
 
     /* ---- the key once per position, the counts folded by LDS atomics */
@@ -1591,14 +1613,14 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
       /* straight-line: the folds, then the claims (a lane without a record adds 0 to a word of its own and claims nothing) */
       if (p.rule == 1u) {
 #pragma unroll
-        for (int k = 0; k < RPT; k++) atomicAdd (&sh.s.scnt[nway_pick (nway_valid_mask (ba[k]), nway_skew (pos[k]), (u32) lane)], cnt[k] & nway_valid_mask (ba[k]));
+        for (int k = 0; k < RPT; k++) atomicAdd (&sh.s.scnt[(GT4_NWAY_NOCONF & 8) ? (u32) lane : nway_pick (nway_valid_mask (ba[k]), nway_skew (pos[k]), (u32) lane)], cnt[k] & nway_valid_mask (ba[k]));
       } else if (p.rule == 4u) {
 #pragma unroll
         for (int k = 0; k < RPT; k++) atomicMax (&sh.s.scnt[nway_pick (nway_valid_mask (ba[k]), nway_skew (pos[k]), (u32) lane)], cnt[k] & nway_valid_mask (ba[k]));
       }
 #pragma unroll
       for (int k = 0; k < RPT; k++)
-        lead_before[k] = atomicOr (&sh.lead[it & 1][nway_pick (nway_valid_mask (ba[k]), pos[k] >> 5, (u32) lane)], (1u << (pos[k] & 31u)) & nway_valid_mask (ba[k]));
+        lead_before[k] = atomicOr (&sh.lead[it & 1][(GT4_NWAY_NOCONF & 16) ? (u32) lane : nway_pick (nway_valid_mask (ba[k]), pos[k] / (u32) Shared::LBP, (u32) lane)], (1u << (pos[k] % (u32) Shared::LBP)) & nway_valid_mask (ba[k]));
     }
     if (!LEAD && has_rec) {
 #pragma unroll
@@ -1690,13 +1712,13 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
           for (int k = 0; k < RPT; k++) lf[k] = p.count_override;
         } else {
 #pragma unroll
-          for (int k = 0; k < RPT; k++) lf[k] = lds_load<u32> (lds_offset (&sh.s.scnt[0]) + 4u * nway_skew (pos[k]));
+          for (int k = 0; k < RPT; k++) lf[k] = lds_load<u32> (lds_offset (&sh.s.scnt[0]) + 4u * ((GT4_NWAY_NOCONF & 64) ? (u32) lane : nway_skew (pos[k])));
         }
         const u32 least = p.filter == FILTER_RAW ? 0u : p.cutoff; /* kept iff the folded count reaches it */
         u32 drop = 0;
 #pragma unroll
         for (int k = 0; k < RPT; k++) { /* (masks, not conditions: see nway_pick) */
-          const u32 leads = nway_valid_mask (ba[k]) & (((lead_before[k] >> (pos[k] & 31u)) & 1u) - 1u);
+          const u32 leads = nway_valid_mask (ba[k]) & (((lead_before[k] >> (pos[k] % (u32) Shared::LBP)) & 1u) - 1u);
           const u32 enough = lf[k] >= least ? ~0u : 0u;
           acc_sum += lf[k] & leads & enough;
           lead_bits |= leads & enough & (1u << k);
@@ -1705,7 +1727,7 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
         if (drop) { /* (rare: a cutoff above the counts) */
 #pragma unroll
           for (int k = 0; k < RPT; k++)
-            if ((drop >> k) & 1u) atomicAnd (&sh.lead[it & 1][pos[k] >> 5], ~(1u << (pos[k] & 31u)));
+            if ((drop >> k) & 1u) atomicAnd (&sh.lead[it & 1][pos[k] / (u32) Shared::LBP], ~(1u << (pos[k] % (u32) Shared::LBP)));
         }
       }
       PHASE_STAMP (13);
@@ -1716,10 +1738,9 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
       constexpr int LWL = Shared::LWL;
       u32 w[LWL], c = 0;
 #pragma unroll
-      for (int j = 0; j < LWL; j++) {
-        w[j] = sh.lead[it & 1][lane * LWL + j];
-        c += (u32) __popc (w[j]);
-      }
+      for (int j = 0; j < LWL; j++) w[j] = sh.lead[it & 1][lane * LWL + j]; /* (consecutive: 16-byte reads) */
+#pragma unroll
+      for (int j = 0; j < LWL; j++) c += (u32) __popc (w[j]);
       const u32 incl = dpp_inclusive_scan_u32 (c);
       tile_total = (u32) __builtin_amdgcn_readlane ((int) incl, WAVE - 1);
       blk_cnt += tile_total;
@@ -1730,22 +1751,29 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
       PHASE_STAMP (16); /* (diagnostics, wavefronts other than the service one: the bitmap scan) */
       if (nway_staged (MODE) && has_rec) {
         u32 before = incl - c;
+        u32 pre16[LWL]; /* (every lane its words, whether it holds a leader or not) */
 #pragma unroll
-        for (int j = 0; j < LWL; j++) { /* (every lane its words, whether it holds a leader or not) */
-          sh.wpre[wid][lane * LWL + j] = (unsigned short) before;
+        for (int j = 0; j < LWL; j++) {
+          pre16[j] = before;
           before += (u32) __popc (w[j]);
+        }
+        if constexpr (LWL == 8) { /* eight 16-bit prefixes: one 16-byte store */
+          *reinterpret_cast<u32x4 *> (&sh.wpre[wid][lane * LWL]) = u32x4 { pre16[0] | (pre16[1] << 16), pre16[2] | (pre16[3] << 16), pre16[4] | (pre16[5] << 16), pre16[6] | (pre16[7] << 16) };
+        } else {
+#pragma unroll
+          for (int j = 0; j < LWL; j++) sh.wpre[wid][lane * LWL + j] = (unsigned short) pre16[j];
         }
         /* (the table is this wavefront's own: LDS operations of one wavefront complete in order) */
         u32 pw[RPT], lw[RPT];
 #pragma unroll
         for (int k = 0; k < RPT; k++) {
-          pw[k] = sh.wpre[wid][pos[k] >> 5];
-          lw[k] = sh.lead[it & 1][pos[k] >> 5];
+          pw[k] = sh.wpre[wid][pos[k] / (u32) Shared::LBP];
+          lw[k] = sh.lead[it & 1][pos[k] / (u32) Shared::LBP];
         }
         PHASE_STAMP (17); /* (diagnostics: prefix table written, words asked for) */
 #pragma unroll
         for (int k = 0; k < RPT; k++) { /* (what is not kept goes to the lane's trash record) */
-          const u32 slot = nway_pick (0u - ((lead_bits >> k) & 1u), pw[k] + (u32) __popc (lw[k] & ((1u << (pos[k] & 31u)) - 1u)), (u32) CAP + 2u + (u32) lane);
+          const u32 slot = (GT4_NWAY_NOCONF & 32) ? (u32) CAP + 2u + (u32) lane : nway_pick (0u - ((lead_bits >> k) & 1u), pw[k] + (u32) __popc (lw[k] & ((1u << (pos[k] % (u32) Shared::LBP)) - 1u)), (u32) CAP + 2u + (u32) lane);
           sh.stage[3 * slot] = (u32) key[k];
           sh.stage[3 * slot + 1] = (u32) (key[k] >> 32);
           sh.stage[3 * slot + 2] = lf[k];
