@@ -90,6 +90,7 @@ extern "C" int gt4hip_create (int device, gt4hip_context **out)
     const char *e = getenv ("GT4HIP_DYNAMIC"); /* diagnostic: the whole test-suite through the other dealing */
     ctx->dynamic = e ? atoi (e) : 0; /* 0: automatic */
   }
+  ctx->kway_sub = 1;
   ctx->kway_enabled = 1; /* N-way unions of three lists or more take the one-pass tile kernel (gt4hip_nway.hip); option "kway": 0 the pairwise tree, 2 also two lists */
   snprintf (ctx->info, sizeof ctx->info, "%s|%s|%d|%zu", prop.name, prop.gcnArchName, prop.multiProcessorCount, prop.totalGlobalMem);
   if ((e = hipStreamCreateWithFlags (&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
@@ -168,6 +169,7 @@ extern "C" int gt4hip_set_option (gt4hip_context *ctx, const char *name, int64_t
   else if (!strcmp (name, "scan_group")) ctx->scan_group = (int) value;
   else if (!strcmp (name, "dynamic")) ctx->dynamic = (int) value;
   else if (!strcmp (name, "kway")) ctx->kway_enabled = (int) value;
+  else if (!strcmp (name, "kway_sub")) ctx->kway_sub = (int) value;
   else if (!strcmp (name, "kway_g")) ctx->kway_g = value;
   else if (!strcmp (name, "kway_vt")) ctx->kway_vt = value;
   else if (!strcmp (name, "spin_limit")) ctx->spin_limit = value > 0 ? (uint32_t) value : 0u;

@@ -552,29 +552,32 @@ __device__ __forceinline__ u64 nway_bucket_consts (u64 lo, u64 hi, u32 n_buckets
   return (u64) sh | (direct ? 1ull << 8 : (u64) mul << 32);
 }
 
-__device__ __forceinline__ u32 nway_tile_slots (const u64 *__restrict__ part, u64 t, bool *mono)
+__device__ __forceinline__ u32 nway_tile_slots (const u64 *__restrict__ part, u64 t, bool *mono, u32 *records)
 {
-  u64 slots = 0;
+  u64 slots = 0, recs = 0;
   for (int i = 0; i < NWAY_MAX; i++) {
     const u64 a = part[t * NWAY_PSTRIDE + i], b = part[(t + 1) * NWAY_PSTRIDE + i];
     *mono &= b >= a;
     slots += (b - a + WAVE - 1) / WAVE;
+    recs += b >= a ? b - a : 0;
   }
+  *records = recs > 0xffffffffull ? 0xffffffffu : (u32) recs;
   return slots > 0xffffffffull ? 0xffffffffu : (u32) slots;
 }
 
 /* flag[0]: a tile needs more than two pieces (or the table is not monotone); flag[1]: tiles whose samples look
  * clustered; flag[2]: tiles cut in two */
-__global__ __launch_bounds__ (NWAY_SPLIT_BLOCK) void k_nway_need (const u64 *__restrict__ part, u32 num_tiles, u32 nch, u32 *__restrict__ need, u32 *__restrict__ block_sums, u32 *flag)
+__global__ __launch_bounds__ (NWAY_SPLIT_BLOCK) void k_nway_need (const u64 *__restrict__ part, u32 num_tiles, u32 nch, u32 max_rec, u32 *__restrict__ need, u32 *__restrict__ block_sums, u32 *flag)
 {
   __shared__ u32 ws[NWAY_SPLIT_BLOCK / WAVE];
   const u64 t = (u64) blockIdx.x * NWAY_SPLIT_BLOCK + threadIdx.x;
   u32 v = 0;
   if (t < num_tiles) {
     bool mono = true;
-    const u32 slots = nway_tile_slots (part, t, &mono);
-    v = slots <= nch ? 1u : 2u;
-    if (!mono || slots > 2 * nch - 2 * NWAY_MAX) atomicOr (flag, 1u); /* (each half rounds every run up once more) */
+    u32 recs;
+    const u32 slots = nway_tile_slots (part, t, &mono, &recs);
+    v = slots <= nch && recs <= max_rec ? 1u : 2u; /* (max_rec: the records the kernel's wavefronts take between them; k_nway_sub) */
+    if (!mono || slots > 2 * nch - 2 * NWAY_MAX || recs / 2 > max_rec) atomicOr (flag, 1u); /* (each half rounds every run up once more) */
     if ((part[t * NWAY_PSTRIDE + NWAY_MAX + 1] >> 9) & 1ull) atomicAdd (flag + 1, 1u);
     if (v == 2u) atomicAdd (flag + 2, 1u);
     need[t] = v;
@@ -618,7 +621,7 @@ __global__ __launch_bounds__ (1024) void k_nway_need_scan (u32 *__restrict__ blo
 }
 
 __global__ __launch_bounds__ (NWAY_SPLIT_BLOCK) void k_nway_emit (NwayParams p, const u64 *__restrict__ part, u32 num_tiles, const u32 *__restrict__ need, const u32 *__restrict__ block_base,
-                                                                 u32 n_buckets, u32 nch, u64 *__restrict__ out, u32 *flag)
+                                                                 u32 n_buckets, u32 nch, u32 max_rec, u64 *__restrict__ out, u32 *flag)
 {
   __shared__ u32 ws[NWAY_SPLIT_BLOCK / WAVE];
   const u64 t = (u64) blockIdx.x * NWAY_SPLIT_BLOCK + threadIdx.x;
@@ -689,12 +692,14 @@ __global__ __launch_bounds__ (NWAY_SPLIT_BLOCK) void k_nway_emit (NwayParams p, 
   out[(at + 1) * NWAY_PSTRIDE + NWAY_MAX + 1] = nway_bucket_consts (pivot + 1ull, hi_key, n_buckets) | clustered;
   /* a piece that still does not fit (runs of very different length: the pivot halves the longest only) sends the
    * call back to fewer samples per tile */
-  u64 s0 = 0, s1 = 0;
+  u64 s0 = 0, s1 = 0, r0 = 0, r1 = 0;
   for (int i = 0; i < NWAY_MAX; i++) {
     s0 += (mid[i] - row[i] + WAVE - 1) / WAVE;
     s1 += (end[i] - mid[i] + WAVE - 1) / WAVE;
+    r0 += mid[i] - row[i];
+    r1 += end[i] - mid[i];
   }
-  if (s0 > nch || s1 > nch) atomicOr (flag, 1u);
+  if (s0 > nch || s1 > nch || r0 > max_rec || r1 > max_rec) atomicOr (flag, 1u);
 }
 
 /* where every tile's rows start in the ragged table = the records in front of the tile (the sum of its cuts) */
@@ -1921,6 +1926,8 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
   if (MODE == NWAY_TABLE && tid == 0 && blk_cnt) atomicAdd (&ctl->n_words[0], blk_cnt); /* the table's rows */
 }
 
+#include "gt4hip_nsub.h"
+
 constexpr int NWAY_NT = GT4_NWAY_NT;
 constexpr int NWAY_NBF = GT4_NWAY_NBF;
 /* positions per thread: the modes that keep no ordered copy of the tile (GT4_NWAY_LEAD) have LDS for one more */
@@ -1938,8 +1945,16 @@ hipError_t launch_nway (hipStream_t s, int grid, const NwayParams &p, const u64 
   return hipGetLastError ();
 }
 
-hipError_t launch_nway_mode (hipStream_t s, int mode, int grid, const NwayParams &p, const u64 *part, u32 *out, u64 *desc, PairControl *ctl)
+hipError_t launch_nway_mode (hipStream_t s, int mode, int grid, const NwayParams &p, const u64 *part, u32 *out, u64 *desc, PairControl *ctl, bool sub)
 {
+  if (sub && mode == NWAY_UNION) {
+    hipLaunchKernelGGL ((k_nway_sub<NWAY_UNION>), dim3 (grid), dim3 (SUB_NT), 0, s, p, part, out, desc, ctl);
+    return hipGetLastError ();
+  }
+  if (sub && mode == NWAY_COUNT) {
+    hipLaunchKernelGGL ((k_nway_sub<NWAY_COUNT>), dim3 (grid), dim3 (SUB_NT), 0, s, p, part, out, desc, ctl);
+    return hipGetLastError ();
+  }
   if (mode == NWAY_DUPS) return launch_nway<NWAY_DUPS> (s, grid, p, part, out, desc, ctl);
   if (mode == NWAY_COUNT) return launch_nway<NWAY_COUNT> (s, grid, p, part, out, desc, ctl);
   if (mode == NWAY_TABLE) return launch_nway<NWAY_TABLE> (s, grid, p, part, out, desc, ctl);
@@ -2008,12 +2023,17 @@ int nway_grow (gt4hip_context *ctx, void **p, size_t *have, size_t need)
  * to whole wavefronts.  `sure`: the G for which no tile can overflow; the first try takes the expected
  * tile (G * S records) plus GT4_NWAY_MARGIN (five) standard deviations of the lists' offsets against their sample grids; tiles beyond the
  * capacity are cut in two (k_nway_emit). */
-void nway_samples_per_tile (u32 k, int positions, u32 *first_try, u32 *sure)
+void nway_samples_per_tile (u32 k, int positions, long max_records, u32 *first_try, u32 *sure)
 {
   const double cap = (double) positions - 32.0 * k; /* half a wavefront of padding per run, on average */
   const double margin = GT4_NWAY_MARGIN * NWAY_SAMPLE * sqrt ((double) k / 6.0);
   long g1 = (long) ((cap - margin) / NWAY_SAMPLE);
   long g0 = ((long) positions - 64L * k) / NWAY_SAMPLE - (2L * k - 1);
+  if (max_records > 0) { /* k_nway_sub: the records its workers take between them */
+    const long r1 = (long) (((double) max_records - margin) / NWAY_SAMPLE), r0 = max_records / NWAY_SAMPLE - (2L * k - 1);
+    if (r1 < g1) g1 = r1;
+    if (r0 < g0) g0 = r0;
+  }
   if (g0 < 1) g0 = 1;
   if (g1 < g0) g1 = g0;
   *first_try = (u32) g1;
@@ -2106,7 +2126,9 @@ static int nway_run (gt4hip_context *ctx, const gt4hip_list *const lists[], uint
     const int cap = nway_cap (mode); /* positions of a tile */
     const u32 n_buckets = (u32) nway_buckets (NWAY_NBF * cap);
     u32 g_try, g_sure;
-    nway_samples_per_tile (k, cap, &g_try, &g_sure);
+    const bool sub = ctx->kway_sub != 0 && (mode == NWAY_UNION || mode == NWAY_COUNT); /* option "kway_sub" = 0: k_nway_merge for every mode */
+    const u32 max_rec = sub ? (u32) SUB_MAXREC : 0xffffffffu;
+    nway_samples_per_tile (k, cap, sub ? (long) SUB_MAXREC : 0L, &g_try, &g_sure);
     if (ctx->kway_g > 0) g_try = (u32) ctx->kway_g;
     u32 G = g_try;
     u64 tiles = 1;
@@ -2139,7 +2161,7 @@ static int nway_run (gt4hip_context *ctx, const gt4hip_list *const lists[], uint
       if ((rc = nway_grow (ctx, (void **) &ctx->kway_need, &ctx->kway_need_bytes, (size_t) (tiles + 1 + n_blocks + 4) * 4))) break;
       u32 *const need = (u32 *) ctx->kway_need, *const block_sums = need + tiles + 1;
       hipMemsetAsync (ctx->scratch, 0, 64, st);
-      hipLaunchKernelGGL (k_nway_need, dim3 ((unsigned) n_blocks), dim3 (NWAY_SPLIT_BLOCK), 0, st, (const u64 *) ctx->kway_part, (u32) tiles, (u32) (cap / WAVE), need, block_sums,
+      hipLaunchKernelGGL (k_nway_need, dim3 ((unsigned) n_blocks), dim3 (NWAY_SPLIT_BLOCK), 0, st, (const u64 *) ctx->kway_part, (u32) tiles, (u32) (cap / WAVE), max_rec, need, block_sums,
                           (u32 *) ctx->scratch);
       hipLaunchKernelGGL (k_nway_need_scan, dim3 (1), dim3 (1024), 0, st, block_sums, (u32) n_blocks, (u32 *) ctx->scratch + 3);
       hipError_t e = hipMemcpyAsync (ctx->scratch_host, ctx->scratch, 16, hipMemcpyDeviceToHost, st);
@@ -2155,7 +2177,7 @@ static int nway_run (gt4hip_context *ctx, const gt4hip_list *const lists[], uint
         const u64 tiles2 = fl[3];
         if ((rc = nway_grow (ctx, (void **) &ctx->kway_part2, &ctx->kway_part2_bytes, (size_t) (tiles2 + 1) * NWAY_PSTRIDE * 8))) break;
         hipLaunchKernelGGL (k_nway_emit, dim3 ((unsigned) n_blocks), dim3 (NWAY_SPLIT_BLOCK), 0, st, lv.p, (const u64 *) ctx->kway_part, (u32) tiles, need, block_sums,
-                            n_buckets, (u32) (cap / WAVE), (u64 *) ctx->kway_part2, (u32 *) ctx->scratch);
+                            n_buckets, (u32) (cap / WAVE), max_rec, (u64 *) ctx->kway_part2, (u32 *) ctx->scratch);
         e = hipMemcpyAsync (ctx->scratch_host + 4, ctx->scratch, 4, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize (st);
         if (e != hipSuccess) {
@@ -2212,7 +2234,7 @@ static int nway_run (gt4hip_context *ctx, const gt4hip_list *const lists[], uint
     } else if (!count_only) {
       dst = (u32 *) out->dev;
     }
-    int grid = ctx->n_cus * nway_blocks_per_cu (mode);
+    int grid = ctx->n_cus * (sub ? 1 : nway_blocks_per_cu (mode));
     if (ctx->grid_override > 0) grid = (int) ctx->grid_override;
     if (mode == NWAY_UNION) {
       if ((rc = nway_grow (ctx, (void **) &ctx->desc, &ctx->desc_bytes, nway_desc_bytes (tiles)))) break;
@@ -2244,7 +2266,7 @@ static int nway_run (gt4hip_context *ctx, const gt4hip_list *const lists[], uint
     }
     hipMemsetAsync (ctx->ctl, 0, sizeof (PairControl), st);
     if (l == 0) hipEventRecord (ctx->ev[1], st);
-    hipError_t e = launch_nway_mode (st, mode, grid, lv.p, part_final, dst, (u64 *) ctx->desc, ctx->ctl);
+    hipError_t e = launch_nway_mode (st, mode, grid, lv.p, part_final, dst, (u64 *) ctx->desc, ctx->ctl, sub);
     if (e != hipSuccess) {
       rc = gt4hip_fail (ctx, GT4HIP_EHIP, "N-way merge launch failed: %s", hipGetErrorString (e));
       break;
