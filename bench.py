@@ -167,21 +167,43 @@ def cpu_baseline(ctx, capi, a, b, k, sample_records, ops, cutoff):
     return res, ora_totals == gpu_totals, dict(oracle=ora_totals, gpu=gpu_totals)
 
 
-def load_traffic(workload, n):
+def csrc_sha16():
+    """What the replayed PMC traffic is tied to: a hash over the device sources (csrc/*.hip, *.h) as they lie in
+    the tree -- the GPU box has no .git.  tools/summarize_profiles.py records the same value with the passes."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "genometester4_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def load_traffic(workload, n, kernel=None):
     """HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/
-    (tools/collect_profiles.sh: FETCH_SIZE and WRITE_SIZE cannot be collected inside this run)."""
+    (tools/collect_profiles.sh: FETCH_SIZE and WRITE_SIZE cannot be collected inside this run).
+    REFUSED (traffic stays unmeasured, the reason is in traffic_source) when the kernel sources have changed since
+    the passes ran, or the recorded dominant kernel is not the one this run names."""
     tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % workload)
     if not os.path.exists(tpath) and workload == "intersect":
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
     try:
         tj = json.load(open(tpath))
-        if tj.get("n_per_list") == n:
-            return tj.get("hbm_bytes_per_launch"), {"file": os.path.relpath(tpath, ROOT), "commit": tj.get("commit"),
-                                                     "kernel": tj.get("kernel"),
-                                                     "note": "replayed from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE), not measured in this run"}
     except Exception:
-        pass
-    return None, None
+        return None, None
+    src = {"file": os.path.relpath(tpath, ROOT), "commit": tj.get("commit"), "kernel": tj.get("kernel"), "csrc_sha16": tj.get("csrc_sha16")}
+    if tj.get("n_per_list") != n:
+        return None, None
+    now = csrc_sha16()
+    if tj.get("csrc_sha16") != now:
+        src["note"] = "REFUSED: the PMC passes ran on kernel sources %s, this tree has %s (re-run tools/collect_profiles.sh)" % (tj.get("csrc_sha16"), now)
+        return None, src
+    if kernel and tj.get("kernel") and tj["kernel"].split("<")[0] != kernel.split("<")[0].split(" ")[0]:
+        src["note"] = "REFUSED: the PMC passes name %s as the dominant kernel, this run %s" % (tj.get("kernel"), kernel)
+        return None, src
+    src["note"] = "replayed from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE), not measured in this run"
+    return tj.get("hbm_bytes_per_launch"), src
 
 
 MULTI = {
@@ -202,13 +224,15 @@ def multi_roofline(ctx, kind, n_in_local, n_out_local, device_ms, kernel_ms, one
     alg = 12 * (n_in_local + n_out_local)
     t_ms = kernel_ms if one_pass and kernel_ms > 0 else device_ms
     achieved = alg / (t_ms * 1e-3) / 1e9
-    traffic, traffic_source = load_traffic(kind if dist == "stride" else "%s_%s" % (kind, dist), workload_n)
     if one_pass:
-        kernel = "k_nway_merge<1024, 4, 1, NWAY_UNION> (one pass over up to eight lists per launch)"
+        sub = os.environ.get("GT4HIP_KWAY_SUB", "0") != "0"
+        kernel = ("k_nway_sub<NWAY_UNION> (wave-private sub-tiles; one pass over up to eight lists per launch)" if sub
+                  else "k_nway_merge<1024, 4, 1, NWAY_UNION> (one pass over up to eight lists per launch)")
     elif MULTI[kind]["op"] == "intersect":
         kernel = "k_pair_merge<1024, 6, MODE_LOOKBACK, intersection> (left-to-right chain, one launch per list after the first)"
     else:
         kernel = "k_pair_merge<1024, 4, 1, 1> (pairwise union tree)"
+    traffic, traffic_source = load_traffic(kind if dist == "stride" else "%s_%s" % (kind, dist), workload_n, kernel)
     return {"bound": "hbm", "kernel": kernel,
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "frac_definition": "algorithmic bytes / average launch of the tile kernel" if one_pass and kernel_ms > 0 else "algorithmic bytes / device time of the whole call",
@@ -310,6 +334,7 @@ def bench_multi(args, ctx, capi, rank, local_rank, world, kind="union8"):
         dist.broadcast_object_list(box, src=0)
         comm_id = box[0]
     sh = D.DeviceShards(ctx, rank, world, comm_id)
+    cuts = sh.plan(full, sampled=args.splitters == "sampled")
     shards = [sh.shard_of(l, args.k) for l in full]
     n_local_in = sum(s.n_words for s in shards)
     # rank 0 of a sharded job writes its result into the list the payload is gathered in: its extent is the first
@@ -385,7 +410,7 @@ def bench_multi(args, ctx, capi, rank, local_rank, world, kind="union8"):
             "dtype": "u64 keys + u32 counts", "data": "synthetic",
             "config": {"workload": "%s, %d lists of %d entries (%s keys), ONE job key-range sharded over %d GPU(s), RCCL gatherv to rank 0" % (spec["what"] % args.k, n_lists, n8, args.dist, world),
                        "reference": spec["ref"], "lists": n_lists, "entries_per_list": n8, "input_records": n_in, "dist": args.dist, "output_records": n_out, "output_total_count": total_out,
-                       "device": ctx.device_info(), "per_rank": per_rank, "path": path,
+                       "device": ctx.device_info(), "per_rank": per_rank, "path": path, "splitters": args.splitters, "shard_first_keys": cuts,
                        "merge_only_k_mers_per_s": n_in * args.steps / merge_only,
                        "merge_only_ms_per_step": merge_only / args.steps * 1e3,
                        "gathered_bytes_per_step": 12 * (n_out - totals[0][0]) if has_comm else 0,
@@ -398,6 +423,108 @@ def bench_multi(args, ctx, capi, rank, local_rank, world, kind="union8"):
     sh.close()
     out.free()
     for l in shards + full:
+        l.free()
+    return res
+
+
+def project_shards(args, ctx, capi):
+    """Single-GPU evidence for the N-GPU number (BASELINE: >= 6x at 8 GPUs on the 8-way union): the job's N key-range
+    shards -- exactly the views rank g of an N-GPU run would merge (DeviceShards.plan / shard_of) -- run ONE AFTER
+    ANOTHER on this GPU, each as its own timed call, next to the whole job as one call.  An N-GPU step takes the
+    slowest shard plus the totals exchange (no payload moves in the merge_only form: every rank keeps or writes its
+    extent), so  projected_speedup = t(N = 1) / (max shard + exchange).  What this cannot see: the other ranks'
+    skew at the barrier, xGMI, host jitter of eight processes -- the driver's SCALE run measures those."""
+    from genometester4_amd import distributed as D
+    from genometester4_amd import synth
+    N = args.project_shards
+    kind = args.workload if args.workload in ("union8", "intersect8") else "intersect"
+    if kind == "union8":
+        full = synth.make_lists8(ctx, args.n8, args.k, args.dist, 8)
+        op = D.gpu_union_multi_op(ctx)
+        what = "8-way k=%d union, 8 lists of %d entries (%s keys)" % (args.k, args.n8, args.dist)
+    elif kind == "intersect8":
+        full = synth.make_lists_shared(ctx, args.n8, args.k, args.dist, 8)
+        op = D.gpu_intersect_multi_op(ctx)
+        what = "8-way k=%d intersection, 8 lists of %d entries (%s keys)" % (args.k, args.n8, args.dist)
+    else:
+        a, b = build_lists(ctx, capi, args.n, args.k, 0, args.dist)
+        full = [a, b]
+        what = "2-list k=%d intersection, 2 lists of %d entries (%s keys)" % (args.k, args.n, args.dist)
+
+        def op(shards, out=None):
+            st, outs, timing = ctx.compare(shards[0], shards[1], 2, out={2: out})
+            last_pair["kernel_ms"] = timing["merge_kernel_ms"]
+            return st[2][0], st[2][1], outs[2]
+    last_pair = {"kernel_ms": 0.0}
+    n_in = sum(l.n_words for l in full)
+
+    def timed(lists, out, steps, warmup):
+        for _ in range(warmup):
+            op(lists, out)
+        ctx.synchronize()
+        ms, ker = [], []
+        r = None
+        for _ in range(steps):
+            t0 = time.perf_counter()
+            r = op(lists, out)
+            ctx.synchronize()
+            ms.append((time.perf_counter() - t0) * 1e3)
+            ker.append(ctx.get_counter("nway_kernel_us") / 1000.0 if kind == "union8" else ctx.last_multi_device_ms if kind == "intersect8" else last_pair["kernel_ms"])
+        return statistics.mean(ms), statistics.mean(ker), r
+
+    union = kind == "union8"
+    out = ctx.alloc(max(1, n_in if union else min(l.n_words for l in full)), args.k)
+    t1_ms, t1_ker, r1 = timed(full, out, args.steps, args.warmup)
+    rows = []
+    n_sum = t_sum = 0
+    for splitters in (["sampled", "equal"] if args.splitters == "sampled" else ["equal"]):
+        sh = D.DeviceShards(ctx, 0, N, None)
+        cuts = sh.plan(full, sampled=splitters == "sampled")
+        per = []
+        n_sum = t_sum = 0
+        for g in range(N):
+            shards = [sh.shard_of(l, args.k, rank=g) for l in full]
+            ms, ker, r = timed(shards, out, args.steps, max(1, args.warmup))
+            n_sum += r[0]
+            t_sum = (t_sum + r[1]) & 0xFFFFFFFFFFFFFFFF
+            per.append({"shard": g, "first_key": cuts[g], "input_records": sum(x.n_words for x in shards), "output_records": r[0], "call_ms": ms, "kernel_ms": ker})
+            for x in shards:
+                x.free()
+        rows.append({"splitters": splitters, "per_shard": per, "max_call_ms": max(p["call_ms"] for p in per), "sum_call_ms": sum(p["call_ms"] for p in per),
+                     "input_imbalance": max(p["input_records"] for p in per) * N / max(1, n_in), "outputs_add_up": (n_sum, t_sum) == (r1[0], r1[1])})
+    # the totals exchange: measured where a communicator can be made (one rank: the latency floor of the call itself)
+    exch = args.exchange_ms
+    exch_how = "given (--exchange-ms)"
+    if exch is None:
+        try:
+            comm = ctx.comm_create(capi.comm_unique_id(), 1, 0)
+            for _ in range(5):
+                ctx.comm_allgather_totals(comm, 1, 1, 1)
+            t0 = time.perf_counter()
+            for _ in range(50):
+                ctx.comm_allgather_totals(comm, 1, 1, 1)
+            exch = (time.perf_counter() - t0) / 50 * 1e3
+            capi.comm_destroy(comm)
+            exch_how = "gt4hip_comm_allgather_totals on a communicator of ONE rank (H2D + ncclAllGather + D2H + synchronise): the call's floor, not eight ranks' skew"
+        except Exception as e:  # noqa
+            exch, exch_how = 0.1, "assumed (no RCCL communicator here: %s)" % e
+    best = rows[0]
+    res = {
+        "metric": "projected %d-GPU speed-up of ONE job from its key-range shards timed one after another on one GPU" % N,
+        "value": t1_ms / (best["max_call_ms"] + exch), "unit": "x", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": t1_ms, "higher_is_better": True, "scaling": "strong (projected)", "vs_baseline": None,
+        "dtype": "u64 keys + u32 counts", "data": "synthetic",
+        "config": {"workload": what + ", %d key-range shards" % N, "device": ctx.device_info(), "input_records": n_in,
+                   "whole_job_call_ms": t1_ms, "whole_job_kernel_ms": t1_ker, "whole_job_output_records": r1[0],
+                   "exchange_ms": exch, "exchange_measured": exch_how,
+                   "projection": [{"splitters": r["splitters"], "projected_speedup": t1_ms / (r["max_call_ms"] + exch), "shard_efficiency": t1_ms / r["sum_call_ms"],
+                                   "max_call_ms": r["max_call_ms"], "sum_call_ms": r["sum_call_ms"], "input_imbalance": r["input_imbalance"],
+                                   "outputs_add_up": r["outputs_add_up"], "per_shard": r["per_shard"]} for r in rows],
+                   "note": "projected_speedup = whole job / (slowest shard + totals exchange); shard_efficiency = whole job / sum of the shards (1.0: no per-call fixed cost); merge_only form (no payload gather)"},
+        "self_check": "ok" if all(r["outputs_add_up"] for r in rows) else "FAILED: the shards' outputs do not add up to the whole job's",
+    }
+    out.free()
+    for l in full:
         l.free()
     return res
 
@@ -536,6 +663,7 @@ def bench_pair(args, ctx, capi, rank, world, torch, dist):
                 from genometester4_amd import distributed as D
                 sh = D.DeviceShards(ctx, rank, world, None)
                 full_a, full_b = a, b
+                sh.plan([full_a, full_b], sampled=args.splitters == "sampled")
                 a, b = sh.shard_of(full_a, args.k), sh.shard_of(full_b, args.k)
             outs = {bit: ctx.alloc(max(1, {1: a.n_words + b.n_words, 2: min(a.n_words, b.n_words), 4: a.n_words}[bit]), args.k) for bit in op_bits}
         except capi.Gt4HipError as e:
@@ -715,6 +843,11 @@ def main():
     ap.add_argument("--n8", "--entries8", dest="n8", type=int, default=500_000_000, help="union8: entries per list (whole job)")
     ap.add_argument("--tree", action="store_true", help="union8: the pairwise tree instead of what the library chooses")
     ap.add_argument("--dist", choices=["stride", "iid", "clustered", "genomic"], default="stride", help="key distribution of the synthetic lists (genometester4_amd/synth.py)")
+    ap.add_argument("--splitters", choices=["sampled", "equal"], default="sampled",
+                    help="how a sharded job cuts the key space: sampled from the lists (gt4hip_shard_cuts: equal input records per shard) or equal-width ranges (gt4hip_shard_first_key)")
+    ap.add_argument("--project-shards", type=int, default=0, metavar="N",
+                    help="ONE GPU: run each of the N key-range shards of the job (union8 or intersect) as its own timed call and project the N-GPU speed-up")
+    ap.add_argument("--exchange-ms", type=float, default=None, help="--project-shards: totals-exchange latency per step to add (default: measured with a one-rank RCCL all-gather)")
     ap.add_argument("--no-union8", action="store_true", help="intersect: leave the union8 record out of the line")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="strong",
                     help="intersect / c2 with --gpus N > 1: strong (default) = ONE pair of --n entries, every rank merges its key range "
@@ -745,7 +878,9 @@ def main():
     if args.two_pass:
         ctx.set_option("two_pass", 1)
     res = None
-    if args.workload in MULTI:
+    if args.project_shards:
+        res = project_shards(args, ctx, capi)
+    elif args.workload in MULTI:
         res = bench_multi(args, ctx, capi, rank, local_rank, world, args.workload)
     elif args.workload == "sort":
         res = bench_sort(args, ctx, capi)

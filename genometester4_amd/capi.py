@@ -51,7 +51,7 @@ SYMBOLS = [
     "gt4hip_union_multi", "gt4hip_intersect_multi", "gt4hip_union_table", "gt4hip_probe_table", "gt4hip_probe_table_ex", "gt4hip_table_compact", "gt4hip_table_download",
     "gt4hip_table_free", "gt4hip_generate", "gt4hip_generate_ex", "gt4hip_synchronize", "gt4hip_set_option",
     "gt4hip_get_counter", "gt4hip_device_memory", "gt4hip_list_upload_fd", "gt4hip_list_load_fd", "gt4hip_list_load",
-    "gt4hip_list_write_fd", "gt4hip_lists_write_fd", "gt4hip_shard_first_key", "gt4hip_comm_unique_id", "gt4hip_comm_create", "gt4hip_comm_destroy",
+    "gt4hip_list_write_fd", "gt4hip_lists_write_fd", "gt4hip_shard_first_key", "gt4hip_shard_cuts", "gt4hip_comm_unique_id", "gt4hip_comm_create", "gt4hip_comm_destroy", "gt4hip_comm_allgather_totals",
     "gt4hip_comm_rank", "gt4hip_comm_size", "gt4hip_comm_last_error", "gt4hip_comm_gatherv", "gt4hip_sort_words", "gt4hip_words_to_list",
     "gt4hip_device_words_to_list",
 ]
@@ -117,6 +117,7 @@ def lib():
             "gt4hip_list_write_fd": (C.c_int, [vp, vp, u64, u64, C.c_int, u64]),
             "gt4hip_lists_write_fd": (C.c_int, [vp, u32, C.POINTER(vp), C.POINTER(u64), C.POINTER(u64), C.POINTER(C.c_int), C.POINTER(u64)]),
             "gt4hip_shard_first_key": (u64, [u32, u32, u32]),
+            "gt4hip_shard_cuts": (C.c_int, [vp, C.POINTER(vp), u32, u32, C.POINTER(u64)]),
             "gt4hip_comm_unique_id": (C.c_int, [vp]),
             "gt4hip_comm_create": (C.c_int, [vp, vp, C.c_int, C.c_int, C.POINTER(vp)]),
             "gt4hip_comm_destroy": (None, [vp]),
@@ -124,6 +125,7 @@ def lib():
             "gt4hip_comm_size": (C.c_int, [vp]),
             "gt4hip_comm_last_error": (C.c_char_p, []),
             "gt4hip_comm_gatherv": (C.c_int, [vp, vp, C.POINTER(u64), C.c_int, vp]),
+            "gt4hip_comm_allgather_totals": (C.c_int, [vp, u64, u64, C.POINTER(u64)]),
             "gt4hip_sort_words": (C.c_int, [vp, vp, u64, u32]),
             "gt4hip_words_to_list": (C.c_int, [vp, vp, u64, u32, C.POINTER(vp)]),
             "gt4hip_device_words_to_list": (C.c_int, [vp, vp, u64, u32, C.POINTER(vp)]),
@@ -252,6 +254,13 @@ class Context:
     def synchronize(self):
         self._chk(lib().gt4hip_synchronize(self.h))
 
+    def shard_cuts(self, lists, n_shards):
+        """First key of every key-range shard, from samples of the lists themselves (gt4hip_shard_cuts)."""
+        arr = (C.c_void_p * len(lists))(*[l.h for l in lists])
+        out = (C.c_uint64 * n_shards)()
+        self._chk(lib().gt4hip_shard_cuts(self.h, arr, len(lists), n_shards, out))
+        return [int(x) for x in out]
+
     def words_to_list(self, words, word_length) -> "DeviceList":
         """Packed k-mer words (any order, repeats) -> sorted (word, occurrences) list on the device."""
         w = np.ascontiguousarray(words, dtype=np.uint64)
@@ -297,6 +306,12 @@ class Context:
         buf = C.create_string_buffer(bytes(comm_id), 128)
         self._chk(lib().gt4hip_comm_create(self.h, buf, n_ranks, rank, C.byref(h)))
         return h
+
+    def comm_allgather_totals(self, comm, world, n_words, total_count):
+        """[(n_words, total_count)] by rank: one ncclAllGather on the library's stream (gt4hip_comm_allgather_totals)."""
+        out = (C.c_uint64 * (2 * world))()
+        self._chk(lib().gt4hip_comm_allgather_totals(comm, n_words, total_count, out))
+        return [(int(out[2 * r]), int(out[2 * r + 1])) for r in range(world)]
 
     def comm_gatherv(self, comm, local, counts, root=0, gathered=None):
         arr = (C.c_uint64 * len(counts))(*counts)

@@ -10,6 +10,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 
 #include <chrono>
 #include <new>
@@ -90,7 +91,10 @@ extern "C" int gt4hip_create (int device, gt4hip_context **out)
     const char *e = getenv ("GT4HIP_DYNAMIC"); /* diagnostic: the whole test-suite through the other dealing */
     ctx->dynamic = e ? atoi (e) : 0; /* 0: automatic */
   }
-  ctx->kway_sub = 1;
+  {
+    const char *e = getenv ("GT4HIP_KWAY_SUB"); /* diagnostic: A/B of the two tile kernels without touching the caller */
+    ctx->kway_sub = e ? atoi (e) : 0; /* (round 5: k_nway_sub loses the A/B -- profiles/round5/r5_nsub_ab.log; k_nway_merge stays) */
+  }
   ctx->kway_enabled = 1; /* N-way unions of three lists or more take the one-pass tile kernel (gt4hip_nway.hip); option "kway": 0 the pairwise tree, 2 also two lists */
   snprintf (ctx->info, sizeof ctx->info, "%s|%s|%d|%zu", prop.name, prop.gcnArchName, prop.multiProcessorCount, prop.totalGlobalMem);
   if ((e = hipStreamCreateWithFlags (&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
@@ -479,6 +483,67 @@ extern "C" int gt4hip_generate_ex (gt4hip_context *ctx, gt4hip_list *l, uint64_t
 extern "C" int gt4hip_generate (gt4hip_context *ctx, gt4hip_list *l, uint64_t n, uint64_t seed, uint32_t max_count)
 {
   return gt4hip_generate_ex (ctx, l, n, seed, seed + 1, max_count, 1, 0);
+}
+
+/* every stride-th key of a list (the last key of every full block of `stride` records) -> out[0 .. n / stride) */
+__global__ void k_sample_stride (const uint32_t *__restrict__ rec, uint64_t n, uint64_t stride, unsigned long long *__restrict__ out)
+{
+  const uint64_t m = n / stride;
+  for (uint64_t j = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; j < m; j += (uint64_t) gridDim.x * blockDim.x) {
+    const uint32_t *q = rec + 3 * ((j + 1) * stride - 1);
+    out[j] = (unsigned long long) q[0] | ((unsigned long long) q[1] << 32);
+  }
+}
+
+/* SAMPLED splitters: equal-width key ranges balance the shards only for uniformly spread keys;
+ * 2-bit packed k-mers of a real genome are not (src/sequence.c:116-130: the word IS the sequence, low-complexity and
+ * GC-poor prefixes are crowded).  Every S-th key of every list (S = all records / 65536), merged on the host; the
+ * first key of shard g is the merged sample at g / n_shards: the shards' INPUT records then differ by at most
+ * n_lists * S.  Every rank that holds the same lists computes the same cuts.  first_keys[0] = 0. */
+extern "C" int gt4hip_shard_cuts (gt4hip_context *ctx, const gt4hip_list *const lists[], uint32_t n, uint32_t n_shards, uint64_t *first_keys)
+{
+  if (!ctx || !lists || !n || !n_shards || !first_keys) return GT4HIP_EINVAL;
+  HIPCHK (ctx, hipSetDevice (ctx->device));
+  uint64_t total = 0;
+  uint32_t wl = 0;
+  for (uint32_t i = 0; i < n; i++) {
+    if (!lists[i]) return GT4HIP_EINVAL;
+    total += lists[i]->n_words;
+    wl = lists[i]->word_length > wl ? lists[i]->word_length : wl;
+  }
+  const uint64_t target = 65536;
+  const uint64_t stride = total / target ? total / target : 1;
+  uint64_t m_total = 0;
+  for (uint32_t i = 0; i < n; i++) m_total += lists[i]->n_words / stride;
+  first_keys[0] = 0;
+  if (m_total < (uint64_t) n_shards) { /* (hardly any records: equal-width ranges) */
+    for (uint32_t g = 1; g < n_shards; g++) first_keys[g] = gt4hip_shard_first_key (wl, n_shards, g);
+    return GT4HIP_OK;
+  }
+  void *dev = NULL, *owner = NULL;
+  int rc = gt4hip_block_alloc (ctx, (size_t) m_total * 8, &dev, &owner);
+  if (rc) return rc;
+  std::vector<unsigned long long> host ((size_t) m_total);
+  uint64_t at = 0;
+  for (uint32_t i = 0; i < n; i++) {
+    const uint64_t m = lists[i]->n_words / stride;
+    if (!m) continue;
+    const unsigned grid = (unsigned) ((m + 255) / 256 < 4096 ? (m + 255) / 256 : 4096);
+    hipLaunchKernelGGL (k_sample_stride, dim3 (grid), dim3 (256), 0, ctx->stream, (const uint32_t *) lists[i]->dev, lists[i]->n_words, stride, (unsigned long long *) dev + at);
+    at += m;
+  }
+  hipError_t e = hipMemcpyAsync (host.data (), dev, (size_t) m_total * 8, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize (ctx->stream);
+  gt4hip_block_free (owner);
+  if (e != hipSuccess) return gt4hip_fail (ctx, GT4HIP_EHIP, "gt4hip_shard_cuts: %s", hipGetErrorString (e));
+  std::sort (host.begin (), host.end ());
+  for (uint32_t g = 1; g < n_shards; g++) {
+    /* (the sample itself goes to the shard on its left: the cut is one above it) */
+    const unsigned long long sk = host[(size_t) (((unsigned __int128) m_total * g) / n_shards) - 1];
+    const uint64_t cut = sk == ~0ull ? sk : sk + 1;
+    first_keys[g] = cut > first_keys[g - 1] ? cut : first_keys[g - 1];
+  }
+  return GT4HIP_OK;
 }
 
 extern "C" uint64_t gt4hip_shard_first_key (uint32_t word_length, uint32_t n_shards, uint32_t g)

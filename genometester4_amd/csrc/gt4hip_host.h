@@ -52,7 +52,7 @@ struct gt4hip_context {
   size_t kway_need_bytes;
   uint64_t kway_splits;      /* counter "kway_splits": tiles cut in two by the last N-way call */
   int kway_enabled;          /* option "kway": 0 = always the pairwise tree, 1 = the one-pass kernel unless the keys are clustered, 2 = always, also for two lists, 3 = always (three lists and more) */
-  int kway_sub;              /* option "kway_sub": 1 (default) unions and counts take k_nway_sub (wave-private sub-tiles), 0 k_nway_merge */
+  int kway_sub;              /* option "kway_sub": 1 unions and counts take k_nway_sub (wave-private sub-tiles: round 5's structural experiment, 40 % slower), 0 (default) k_nway_merge */
   int64_t kway_g;            /* option "kway_g": samples per tile (0 = automatic) */
   int64_t kway_vt;           /* option "kway_vt": positions per thread in a merge pass, at least (0 = default) */
   uint64_t kway_overflows;   /* calls that fell back to the tree because a tile would not fit LDS */

@@ -87,7 +87,7 @@ struct SubShared {
   u32 wpre[2][SUB_NW];                 /* ... kept by the workers before it */
   u64 excl[2];                         /* records in front of the tile in the output */
   /* hand-offs: monotonic counters */
-  u32 c_raw, c_cuts, c_gath, c_end, c_x, c_tab, c_sb, c_abort;
+  u32 c_raw, c_cuts, c_gath, c_end, c_x, c_tab, c_sb, c_abort, c_kept, c_pad[3];
   u32 tick;
 };
 
@@ -108,11 +108,18 @@ __device__ __forceinline__ void sub_signal (u32 *p, u32 v, int lane)
   asm volatile ("" ::: "memory");
 }
 /* wait until *p >= target (wrap-safe); false: gave up (the launch is over: ctl->error) */
+#ifndef GT4_SUB_SLEEP
+#define GT4_SUB_SLEEP 2
+#endif
 __device__ __forceinline__ bool sub_wait (u32 *p, u32 target, u32 *abort_word, u32 limit)
 {
+  /* the CU has ONE scalar unit: a polling wavefront's loop is paid by everybody (measured: 625 scalar instructions per
+   * wavefront and tile with a ten-instruction loop and s_sleep 1, five times k_nway_merge's).  The loop is the look,
+   * one compare, the sleep; the bound and the abort word are looked at every 256th round only. */
   asm volatile ("" ::: "memory");
-  u32 spins = 0;
   bool ok = true;
+#ifdef GT4_SUB_OLDWAIT
+  u32 spins = 0;
   for (;;) {
     const u32 v = uniform32 (sub_peek (p));
     if ((int) (v - target) >= 0) break;
@@ -124,7 +131,31 @@ __device__ __forceinline__ bool sub_wait (u32 *p, u32 target, u32 *abort_word, u
   }
   asm volatile ("" ::: "memory");
   return ok;
+#endif
+  u32 rounds = 0;
+  for (;;) {
+    u32 v = 0;
+#pragma unroll 1
+    for (u32 i = 0; i < 256u; i++) {
+      v = uniform32 (sub_peek (p));
+      if ((int) (v - target) >= 0) break;
+      __builtin_amdgcn_s_sleep (GT4_SUB_SLEEP);
+    }
+    if ((int) (v - target) >= 0) break;
+    if (++rounds > (limit >> 8) || uniform32 (sub_peek (abort_word))) {
+      ok = false;
+      break;
+    }
+  }
+  asm volatile ("" ::: "memory");
+  return ok;
 }
+
+/* The worker's LDS area is written and read under several types (u64 keys, 16-byte positions, 64-bit atomics on
+ * their halves, 16-bit counters): type-based alias analysis would let the compiler move, say, the zeroing stores of
+ * the positions behind the atomics that fold into them (it did).  A compiler fence -- no instruction -- at every
+ * phase boundary keeps the program order the hardware then honours (one wavefront's LDS operations complete in order). */
+__device__ __forceinline__ void sub_fence () { asm volatile ("" ::: "memory"); }
 
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Wint-to-pointer-cast"
@@ -287,7 +318,7 @@ k_nway_sub (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out, u
   /* ---- prologue */
   u32 sv_t2 = 0xffffffffu, sv_tk = 0xffffffffu;
   u64 sv_row = 0;
-  if (tid < 8) (&sh.c_raw)[tid] = 0;
+  if (tid < 12) (&sh.c_raw)[tid] = 0;
   if (service) {
     u32 d[4] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu };
     if (lane == 0)
@@ -315,6 +346,15 @@ k_nway_sub (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out, u
   u64 blk_cnt = 0; /* records kept by this wavefront (the same in every lane) */
   int tb = 0, tb1 = 1, tb2 = 2;
   u32 it = 0;
+#ifdef GT4_PROFILE_PHASES
+  u64 ph[24];
+  for (int i = 0; i < 24; i++) ph[i] = 0;
+  u64 t_last;
+  asm volatile ("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_last) :: "memory");
+#define SUB_STAMPS_OUT() do { if (tid == GT4_STAMP_TID) for (int i = 0; i < 24; i++) atomicAdd (&ctl->phase_cycles[i], ph[i]); } while (0)
+#else
+#define SUB_STAMPS_OUT() do { } while (0)
+#endif
 
   if (service) {
     /* =============================================================== the service wavefront */
@@ -389,8 +429,15 @@ k_nway_sub (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out, u
     if (uniform32 (sh.hdr[0][0]) < ntl) compute_cuts (0, 0u);
     sub_signal (&sh.c_tab, 2u, lane);
     sub_signal (&sh.c_cuts, 1u, lane);
+    /* Order of an iteration (tile `it` is with the workers): table of it + 2; the records of it + 1 to the raw area
+     * once everybody has gathered it; the cuts of it + 1; the offset of it - 1 (its chain words were asked for an
+     * iteration ago); then the workers' totals of tile `it` -- known behind their folds, well before the tile ends --
+     * are added up and published, and the chain words of `it` asked for. */
     u32 prev_tile = 0xffffffffu;
+    u32 xagg = 0;
+    u64 xcarry = 0;
     for (;; it++) {
+      PHASE_STAMP (23);
       const u32 cur = uniform32 (sh.hdr[tb][0]);
       if (cur >= ntl || dead) break;
       /* the table of the tile after next, the ticket behind it, its partition entries */
@@ -402,48 +449,85 @@ k_nway_sub (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out, u
         sv_row = load_row (t3);
         if (lane == 0) sv_tk = deal ((int) it + 4);
       }
-      /* the tile before: every worker has its total */
-      if (it > 0) {
-        SUB_WAIT (c_end, (u32) NSUB * it);
-        finish_tile (it - 1u, prev_tile);
+      if (MODE == NWAY_UNION && it > 0) { /* (asked for again: the look an iteration ago was early) */
+        const u64 prow = prev_tile / WAVE;
+        const bool mine = (u32) lane < prev_tile % WAVE;
+        if (mine && !(xagg & AGG_READY)) xagg = peek_u32 (&agg[prow * WAVE + lane]);
+        if (!(xcarry & CARRY_READY)) xcarry = peek_u64 (&carry[prow]);
       }
+      PHASE_STAMP (13);
       /* everybody has gathered this tile: the next one's records go to the raw area */
       SUB_WAIT (c_gath, (u32) NSUB * (it + 1u));
+      PHASE_STAMP (16);
       const u32 nxt = uniform32 (sh.hdr[tb1][0]);
       if (nxt < ntl) {
         write_raw (tb1);
         sub_arrive (&sh.c_raw, lane);
         fetch_or_not (tb2);
       }
-      /* the offset of the tile before */
+      PHASE_STAMP (17);
+      /* the offset of the tile before, if the chain has it by now (the workers ask for it behind their folds) */
+      bool x_done = it == 0;
+#ifdef GT4_SUB_LATEX
+      if (false) {
+#else
       if (it > 0) {
+#endif
         if (MODE == NWAY_UNION) {
-          const u64 x = resolve_offset (agg, carry, prev_tile, lane, 0, 0, ctl, spin_limit);
-          if (lane == 0) sh.excl[(it - 1u) & 1u] = x;
+          const bool mine = (u32) lane < prev_tile % WAVE;
+          if (__all (!mine || (xagg & AGG_READY) != 0) && (xcarry & CARRY_READY)) {
+            const u64 x = (xcarry & ~CARRY_READY) + dpp_wave_sum_u32 (mine ? (xagg & ~AGG_READY) : 0u);
+            if (lane == 0) sh.excl[(it - 1u) & 1u] = x;
+            x_done = true;
+          } else { /* asked for once more; looked at behind the cuts */
+            const u64 prow = prev_tile / WAVE;
+            if (mine && !(xagg & AGG_READY)) xagg = peek_u32 (&agg[prow * WAVE + lane]);
+            if (!(xcarry & CARRY_READY)) xcarry = peek_u64 (&carry[prow]);
+          }
+        } else {
+          x_done = true;
         }
-        sub_signal (&sh.c_x, it, lane);
+        if (x_done) sub_signal (&sh.c_x, it, lane);
       }
+      PHASE_STAMP (18);
       /* the next tile's cuts, as soon as all sixteen wavefronts have stored their slots */
       if (nxt < ntl) {
         SUB_WAIT (c_raw, (u32) NW * (it + 1u));
+        PHASE_STAMP (19);
         compute_cuts (tb1, (it + 1u) & 1u);
         sub_signal (&sh.c_cuts, it + 2u, lane);
+        PHASE_STAMP (20);
       }
+      if (!x_done) {
+        const u64 x = resolve_offset (agg, carry, prev_tile, lane, xagg, xcarry, ctl, spin_limit);
+        if (lane == 0) sh.excl[(it - 1u) & 1u] = x;
+        sub_signal (&sh.c_x, it, lane);
+        PHASE_STAMP (21);
+      }
+      /* this tile: every worker knows what it keeps */
+      SUB_WAIT (c_kept, (u32) NSUB * (it + 1u));
+      PHASE_STAMP (14);
+      finish_tile (it, cur);
+      if (MODE == NWAY_UNION) {
+        const u64 prow = cur / WAVE;
+        xagg = (u32) lane < cur % WAVE ? peek_u32 (&agg[prow * WAVE + lane]) : 0u;
+        xcarry = peek_u64 (&carry[prow]);
+      }
+      PHASE_STAMP (15);
       prev_tile = cur;
       const int t0 = tb;
       tb = tb1;
       tb1 = tb2;
       tb2 = t0;
     }
-    if (it > 0 && !dead) { /* the last tile */
-      SUB_WAIT (c_end, (u32) NSUB * it);
-      finish_tile (it - 1u, prev_tile);
+    if (it > 0 && !dead) { /* the last tile's offset */
       if (MODE == NWAY_UNION) {
-        const u64 x = resolve_offset (agg, carry, prev_tile, lane, 0, 0, ctl, spin_limit);
+        const u64 x = resolve_offset (agg, carry, prev_tile, lane, xagg, xcarry, ctl, spin_limit);
         if (lane == 0) sh.excl[(it - 1u) & 1u] = x;
       }
       sub_signal (&sh.c_x, it, lane);
     }
+    SUB_STAMPS_OUT ();
     return;
   }
 
@@ -472,10 +556,12 @@ k_nway_sub (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out, u
    * the fetch of the one after starts */
   auto mid = [&] () {
     SUB_WAIT (c_gath, (u32) NSUB * (it + 1u));
+    PHASE_STAMP (5);
     const u32 nxt = uniform32 (sh.hdr[tb1][0]);
     if (nxt < ntl) {
       write_raw (tb1);
       sub_arrive (&sh.c_raw, lane);
+      PHASE_STAMP (6);
       SUB_WAIT (c_tab, it + 3u);
       fetch_or_not (tb2);
     }
@@ -484,8 +570,9 @@ k_nway_sub (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out, u
   auto write_out_prev = [&] () {
     if (MODE == NWAY_UNION && have_prev) {
       SUB_WAIT (c_x, it);
+      PHASE_STAMP (9);
       const u64 base = uniform64 (sh.excl[(it - 1u) & 1u]) + (u64) uniform32 (sh.wpre[(it - 1u) & 1u][wid]);
-      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc ((void *) (out + 3 * base), 0, (int) (12 * oprev_kept), 0x00020000);
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc ((void *) (out + 3 * base), 0, (int) (12 * uniform32 (oprev_kept)), 0x00020000); /* (said to be uniform: a waterfall loop around every store otherwise) */
 #pragma unroll
       for (int i = 0; i < RW; i++) {
         if ((okeep >> i) & 1u) {
@@ -496,7 +583,7 @@ k_nway_sub (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out, u
     }
   };
   /* positions p0 .. p0 + c of the array at rb, in order: cutoff, ballots; the kept records stay in the registers */
-  auto ordered = [&] (u32 rb, u32 p0, u32 c) {
+  auto ordered = [&] (u32 rb, u32 p0, u32 c, bool publish) {
     u32 wave_kept = 0;
     okeep = 0;
     oslots = 0;
@@ -521,7 +608,10 @@ k_nway_sub (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out, u
     oprev_kept = wave_kept;
     blk_cnt += wave_kept;
     have_prev = true;
-    if (lane == 0) sh.kept[it & 1u][wid] = wave_kept;
+    if (publish) { /* (slow tiles: the fast path knows what it keeps behind its folds) */
+      if (lane == 0) sh.kept[it & 1u][wid] = wave_kept;
+      sub_arrive (&sh.c_kept, lane);
+    }
     /* (the caller arrives at c_end once its own area is ready for the next tile: a slow tile lies over it) */
   };
   /* {sum, arrivals} of a position += {count, 1}; the first arrival leaves the key */
@@ -543,7 +633,9 @@ k_nway_sub (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out, u
       break;
     }
     const u32 par = it & 1u;
+    PHASE_STAMP (12);
     SUB_WAIT (c_cuts, it + 1u);
+    PHASE_STAMP (0);
     if (dead) break;
     const bool slow_tile = uniform32 (sh.slow[par]) != 0u;
 
@@ -560,6 +652,7 @@ k_nway_sub (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out, u
       const u32 n_w = (u32) __builtin_amdgcn_readlane ((int) incl, WAVE - 1);
       const u32 pre_r = incl - len;
       if (lane < NWAY_MAX) pv.wtab[lane] = pb + lo_c - pre_r; /* raw position of lane slot j of run r: j + this */
+      sub_fence ();
       u32 pf[NWAY_MAX];
 #pragma unroll
       for (int r = 1; r < NWAY_MAX; r++) pf[r] = (u32) __builtin_amdgcn_readlane ((int) pre_r, r);
@@ -588,6 +681,12 @@ k_nway_sub (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out, u
           cnt[k] = lds_load<u32> (rawc_off + 4u * idx[k]);
         }
       }
+      /* the raw area is not looked at again (the arrival is seen behind the reads: in order) */
+#ifdef GT4_SUB_LATEGATH
+      asm volatile ("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+      sub_arrive (&sh.c_gath, lane);
+      PHASE_STAMP (1);
       /* ---- buckets: interpolation inside the sub-range's key range */
       const u64 k_lo = uniform64 (sh.cutkey[par][wid]) + 1ull, k_hi = uniform64 (sh.cutkey[par][wid + 1]);
       u32 bk_sh = 0, bk_mul = 0xffffffffu;
@@ -616,6 +715,8 @@ k_nway_sub (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out, u
 #pragma unroll
         for (int k = 0; k < RW; k++) ba[k] = (b[k] | (((old[k] >> ((b[k] & 1u) * 16u)) & 0x7fffu) << 16) | 0x80000000u) & vmask[k];
       }
+      sub_fence ();
+      PHASE_STAMP (2);
       /* ---- scan of the counters: four per lane */
       {
         const u64 w2 = lds_load<u64> (cnt_off + 8u * (u32) lane);
@@ -627,10 +728,10 @@ k_nway_sub (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out, u
         const u32 s0 = inc - tsum, s1 = s0 + c0, s2 = s1 + c1, s3 = s2 + c2;
         *reinterpret_cast<u64 *> (&pv.cntw[2 * lane]) = (u64) (s0 | (s1 << 16)) | ((u64) (s2 | (s3 << 16)) << 32);
       }
+      sub_fence ();
+      PHASE_STAMP (3);
       const bool walk = mx <= (u32) SUB_LIMIT && p.force_fallback != 2u;
       if (__builtin_expect (walk, 1)) {
-        /* the raw area is not looked at again */
-        sub_arrive (&sh.c_gath, lane);
         /* ---- keys grouped by bucket, rank = bucket start + smaller keys in the bucket */
         u32 h0[RW], st[RW];
 #pragma unroll
@@ -640,7 +741,9 @@ k_nway_sub (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out, u
           st[k] = h0[k] & nway_valid_mask (ba[k]);
           if (ba[k] >> 31) pv.gk[nway_skew (st[k]) + ((ba[k] >> 16) & 0x7fffu)] = key[k];
         }
+        sub_fence ();
         *reinterpret_cast<u64 *> (&pv.cntw[2 * lane]) = 0ull; /* the next tile's counters */
+        sub_fence ();
         u32 lt[RW], ga[RW];
 #pragma unroll
         for (int k = 0; k < RW; k++) {
@@ -652,12 +755,17 @@ k_nway_sub (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out, u
 #pragma unroll
         for (int k = 0; k < RW; k++) pos[k] = (st[k] + lt[k]) | (ba[k] & 0x80000000u);
       } else {
-        /* clustered keys: every record adds up its lower bounds in the worker's eight sub-runs */
+        /* clustered keys: every record adds up its lower bounds in the worker's eight sub-runs -- which are the
+         * worker's own records in the order it gathered them: lane slot j of run r is key prefix_r + j of its area */
         *reinterpret_cast<u64 *> (&pv.cntw[2 * lane]) = 0ull;
+#pragma unroll
+        for (int k = 0; k < RW; k++)
+          if (ba[k] >> 31) pv.gk[(u32) (WAVE * k) + (u32) lane] = key[k];
+        sub_fence ();
 #pragma unroll
         for (int k = 0; k < RW; k++) pos[k] = 0;
         for (int r = 0; r < NWAY_MAX; r++) {
-          const u32 len_r = (u32) __builtin_amdgcn_readlane ((int) len, r), start_r = (u32) __builtin_amdgcn_readlane ((int) (pb + lo_c), r);
+          const u32 len_r = (u32) __builtin_amdgcn_readlane ((int) len, r), start_r = (u32) __builtin_amdgcn_readlane ((int) pre_r, r);
           if (!len_r) continue;
           const u32 steps = 32u - (u32) __builtin_clz (len_r);
           u32 lo[RW], hi[RW];
@@ -671,7 +779,7 @@ k_nway_sub (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out, u
             for (int k = 0; k < RW; k++) {
               const bool act = lo[k] < hi[k];
               const u32 mid_ = (lo[k] + hi[k]) >> 1;
-              const u64 km = lds_load<u64> (rawk_off + 8u * (start_r + (act ? mid_ : 0u)));
+              const u64 km = lds_load<u64> (gk_off + 8u * (start_r + (act ? mid_ : 0u)));
               const bool c = km < key[k];
               lo[k] = (act && c) ? mid_ + 1u : lo[k];
               hi[k] = (act && !c) ? mid_ : hi[k];
@@ -682,10 +790,12 @@ k_nway_sub (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out, u
         }
 #pragma unroll
         for (int k = 0; k < RW; k++) pos[k] = (pos[k] & nway_valid_mask (ba[k])) | (ba[k] & 0x80000000u);
-        sub_arrive (&sh.c_gath, lane);
       }
+      sub_fence ();
+      PHASE_STAMP (4);
       /* ---- the next tile's records to the raw area, the fetch of the one after */
       mid ();
+      PHASE_STAMP (7);
       /* ---- fold: the positions start from zero (the grouped keys lay there) */
       static_assert (SUB_PN <= 5 * WAVE, "the positions are zeroed in five rounds");
       {
@@ -694,10 +804,12 @@ k_nway_sub (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out, u
         for (int r = 0; r < 5; r++)
           if (r * WAVE + lane < SUB_PN) pv.pos[r * WAVE + lane] = u32x4 { z, z, z, z };
       }
+      sub_fence ();
       {
         u64 old[RW];
 #pragma unroll
         for (int k = 0; k < RW; k++) old[k] = fold (pp_off, pos[k] & 0x7fffffffu, (pos[k] >> 31) != 0u, key[k], cnt[k], (u32) lane);
+        sub_fence ();
 #pragma unroll
         for (int k = 0; k < RW; k++)
           if ((pos[k] >> 31) && (u32) (old[k] >> 32) == 0u) *reinterpret_cast<u64 *> (&pv.pos[sub_phys (pos[k] & 0x7fffffffu)]) = key[k];
@@ -706,9 +818,30 @@ k_nway_sub (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out, u
           for (int k = 0; k < RW; k++)
             if (pos[k] >> 31) atomicMax (&reinterpret_cast<u32 *> (&pv.pos[sub_phys (pos[k] & 0x7fffffffu)])[2], cnt[k]);
         }
+        sub_fence ();
+        /* ---- what the worker keeps is known here already: the first arrivals look at the folded counts (this
+         * wavefront's LDS operations complete in order).  The tile's total goes to the chained scan half a tile
+         * before the records are put in order. */
+        u32 fs[RW];
+#pragma unroll
+        for (int k = 0; k < RW; k++) fs[k] = lds_load<u32> (pp_off + 16u * sub_phys (pos[k] & 0x7fffffffu) + 8u);
+        const u32 least = p.filter == FILTER_RAW ? 0u : p.cutoff;
+        u32 kept_w = 0;
+#pragma unroll
+        for (int k = 0; k < RW; k++) {
+          const u32 f = p.rule == 7u ? p.count_override : fs[k];
+          kept_w += (u32) __popcll (__builtin_amdgcn_ballot_w64 ((pos[k] >> 31) && (u32) (old[k] >> 32) == 0u && f >= least));
+        }
+        if (lane == 0) sh.kept[it & 1u][wid] = kept_w;
+        sub_arrive (&sh.c_kept, lane);
       }
+      PHASE_STAMP (8);
       write_out_prev ();
-      ordered (pp_off, 0u, n_w);
+      PHASE_STAMP (10);
+      sub_fence ();
+      ordered (pp_off, 0u, n_w, false);
+      sub_fence ();
+      PHASE_STAMP (11);
       /* the grouped keys of the next tile start from all-ones */
       static_assert (SUB_GKN % 2 == 0 && SUB_GKN / 2 <= 3 * WAVE, "the grouped keys are filled 16 bytes at a time, in three rounds");
       {
@@ -746,9 +879,12 @@ k_nway_sub (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out, u
           }
           pos += lo;
         }
+        sub_fence ();
         const u64 old = fold (tpos_off, pos, valid, key, cnt, (u32) lane);
+        sub_fence ();
         if (valid && (u32) (old >> 32) == 0u) *reinterpret_cast<u64 *> (&sh.tpos[sub_phys (pos)]) = key;
         if (valid && p.rule == 4u) atomicMax (&reinterpret_cast<u32 *> (&sh.tpos[sub_phys (pos)])[2], cnt);
+        sub_fence ();
       }
       sub_arrive (&sh.c_gath, lane);
       soft_barrier (); /* every record is folded */
@@ -756,7 +892,7 @@ k_nway_sub (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out, u
       write_out_prev ();
       {
         const u32 p0 = (u32) (wid * SUB_CAPW);
-        ordered (tpos_off, p0, n > p0 ? (n - p0 < (u32) SUB_CAPW ? n - p0 : (u32) SUB_CAPW) : 0u);
+        ordered (tpos_off, p0, n > p0 ? (n - p0 < (u32) SUB_CAPW ? n - p0 : (u32) SUB_CAPW) : 0u, true);
       }
       soft_barrier (); /* everybody has read its positions: the workers' own areas again */
       pv.cntw[lane] = 0;
@@ -771,6 +907,7 @@ k_nway_sub (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out, u
   }
   /* the last tile leaves the registers */
   if (!dead) write_out_prev ();
+  SUB_STAMPS_OUT ();
   {
     const u64 v = wave_sum (acc_sum);
     if (lane == 0 && v) atomicAdd (&ctl->total_count[0], v);

@@ -2296,10 +2296,12 @@ static int nway_run (gt4hip_context *ctx, const gt4hip_list *const lists[], uint
     if (l == 0) {
 #ifdef GT4_PROFILE_PHASES
       {
-        static const char *names[24] = { "p0: zeroing", "B1", "scan1", "B2", "scan2", "B3", "group", "B4", "rank", "fold", "service", "B5", "writeout+fill", "order", "B6", "stage+publish", "sv:-", "sv:table", "sv:ticket+row", "sv:try writeout | header", "p0: wait for records", "p0: buckets+atomics", "p0: fetch issue", "back edge" };
+        static const char *sub_names[24] = { "w:wait cuts", "w:gather", "w:buckets+count", "w:scan", "w:group+walk", "w:wait gathered", "w:raw store", "w:wait table+fetch", "w:zero+fold", "w:wait offset", "w:stores", "w:ordered", "w:fill+back edge", "s:table+ticket", "s:wait end", "s:totals", "s:wait gathered", "s:raw store+fetch", "s:offset (ready)", "s:wait raw", "s:cuts", "s:offset (waited)", "-", "s:back edge" };
+        static const char *old_names[24] = { "p0: zeroing", "B1", "scan1", "B2", "scan2", "B3", "group", "B4", "rank", "fold", "service", "B5", "writeout+fill", "order", "B6", "stage+publish", "sv:-", "sv:table", "sv:ticket+row", "sv:try writeout | header", "p0: wait for records", "p0: buckets+atomics", "p0: fetch issue", "back edge" };
         unsigned long long tot = 0;
         for (int i = 0; i < 24; i++) tot += ctx->ctl_host->phase_cycles[i];
         fprintf (stderr, "[nway phases] tiles %llu:", (unsigned long long) tiles);
+        const char **names = sub ? sub_names : old_names;
         for (int i = 0; i < 24; i++) fprintf (stderr, " %s %.1f%%", names[i], tot ? 100.0 * ctx->ctl_host->phase_cycles[i] / tot : 0.0);
         fprintf (stderr, " | avg cycles/tile %.0f\n", tiles ? (double) tot / tiles : 0.0);
       }

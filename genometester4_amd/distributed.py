@@ -155,15 +155,31 @@ class DeviceShards:
             capi.comm_destroy(self.comm)
             self.comm = None
 
-    def shard_of(self, lst, word_length):
-        """This rank's key range of a device list, as a view."""
+    def plan(self, lists, sampled=True):
+        """The shards' first keys for a job over `lists` (all ranks hold the same lists and get the same cuts):
+        SAMPLED from the lists (gt4hip_shard_cuts: equal numbers of input records per shard whatever the keys'
+        distribution) or, `sampled=False`, equal-width ranges of the key space (gt4hip_shard_first_key: balanced
+        for uniformly spread keys only)."""
         from . import capi
-        lo = capi.lib().gt4hip_shard_first_key(word_length, self.world, self.rank)
-        first = lst.lower_bound(lo) if self.rank else 0
-        if self.rank + 1 < self.world:
-            last = lst.lower_bound(capi.lib().gt4hip_shard_first_key(word_length, self.world, self.rank + 1))
+        if self.world == 1:
+            self.cuts = [0]
+        elif sampled:
+            self.cuts = self.ctx.shard_cuts(lists, self.world)
         else:
-            last = lst.n_words
+            wl = max(l.word_length for l in lists)
+            self.cuts = [int(capi.lib().gt4hip_shard_first_key(wl, self.world, g)) for g in range(self.world)]
+        return self.cuts
+
+    def shard_of(self, lst, word_length, rank=None):
+        """Rank `rank`'s (default: this rank's) key range of a device list, as a view.  The cuts come from plan();
+        without one: equal-width ranges."""
+        from . import capi
+        g = self.rank if rank is None else rank
+        cuts = getattr(self, "cuts", None)
+        if cuts is None:
+            cuts = [int(capi.lib().gt4hip_shard_first_key(word_length, self.world, r)) for r in range(self.world)]
+        first = lst.lower_bound(cuts[g]) if g else 0
+        last = lst.lower_bound(cuts[g + 1]) if g + 1 < self.world else lst.n_words
         return lst.slice(first, last - first)
 
     def run(self, shards, op, totals_exchange, root=0, out=None, gathered=None, gather=True):
@@ -172,10 +188,16 @@ class DeviceShards:
         Returns (n_words, total_count, gathered device list or None, per-rank totals)."""
         import time
         t0 = time.perf_counter()
-        n, total, local = op(shards, out)
-        self.ctx.synchronize()
+        n, total, local = op(shards, out)  # (returns with the totals read back: the library's stream is idle)
         t1 = time.perf_counter()
-        totals = totals_exchange(n, total) if self.world > 1 else [(n, total)]
+        if self.world == 1:
+            totals = [(n, total)]
+        elif self.comm is not None:
+            # over RCCL through the C ABI: one all-gather on the library's stream, one synchronisation (round 5; the
+            # torch.distributed form below costs a Python collective and a device-to-host copy per step)
+            totals = self.ctx.comm_allgather_totals(self.comm, self.world, n, total)
+        else:
+            totals = totals_exchange(n, total)
         res = local
         if gather and self.comm is not None:
             counts = [t[0] for t in totals]

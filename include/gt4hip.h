@@ -247,6 +247,11 @@ void gt4hip_table_free (gt4hip_count_table *table);
  * First key of shard g of n_shards equal-width ranges of the 4^word_length key space (2^64 for
  * k = 32); shard g covers [first(g), first(g+1)), the last one everything from first(n_shards-1). */
 uint64_t gt4hip_shard_first_key (uint32_t word_length, uint32_t n_shards, uint32_t g);
+/* SAMPLED cuts for lists resident in HBM (equal-width ranges balance only uniformly spread keys: the packed word IS
+ * the sequence, reference src/sequence.c:116-130): first_keys[g], g < n_shards, is the first key of shard g
+ * (first_keys[0] = 0) such that the shards hold about the same number of INPUT records of the n lists together
+ * (every (total / 65536)-th key of every list, merged).  Deterministic: ranks holding the same lists get the same cuts. */
+int gt4hip_shard_cuts (gt4hip_context *ctx, const gt4hip_list *const lists[], uint32_t n, uint32_t n_shards, uint64_t *first_keys);
 
 /* The exchange step: gatherv of the shards' records on `root` over RCCL (xGMI inside a node), as
  * grouped ncclSend / ncclRecv (RCCL has no native gatherv).  librccl.so is loaded by the first call
@@ -261,6 +266,11 @@ int gt4hip_comm_rank (const gt4hip_comm *comm);
 int gt4hip_comm_size (const gt4hip_comm *comm);
 /* Message of the last failed gt4hip_comm_unique_id (no context yet at that point). */
 const char *gt4hip_comm_last_error (void);
+/* The other exchange of a sharded step: every rank's (n_words, total_count) to every rank (header totals, output
+ * offsets): one ncclAllGather of two 64-bit words per rank on the library's stream, one synchronisation.
+ * totals[2 r], totals[2 r + 1] = rank r's pair (2 * gt4hip_comm_size words). */
+int gt4hip_comm_allgather_totals (gt4hip_comm *c, uint64_t n_words, uint64_t total_count, uint64_t *totals);
+
 /* counts[r] = records rank r contributes (every rank passes the same array: the all-gathered header
  * totals).  Rank r sends the first counts[r] records of `local`; on `root`, `gathered` (capacity >=
  * the sum) receives them in rank order and its n_words is set; other ranks pass NULL.  Blocks until

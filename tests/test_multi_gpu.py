@@ -88,6 +88,46 @@ def test_two_ranks_on_one_device_default_line():
     assert sum(r["shard_input_records"] for r in two["union8"]["per_rank"]) == 8 * 1500000
 
 
+def test_eight_ranks_on_one_device_default_line():
+    """the driver's N = 8 command with all eight ranks on device 0 (gloo): the totals of one GPU, every record in
+    exactly one shard, empty shards included (equal-width ranges of a clustered list leave ranks without records)"""
+    small = ["--entries", "1600000", "--entries8", "400000", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
+    one = _bench(1, small)
+    eight = _bench(8, small, {"GT4_BENCH_ONE_DEVICE": "1"})
+    assert eight["scaling"] == "strong" and eight["n_gpus"] == 8 and eight["self_check"] == "ok"
+    assert eight["config"]["output_records"] == one["config"]["output_records"]["intrsec"]
+    u = eight["union8"]
+    assert u["self_check"] == "ok"
+    assert (u["output_records"], u["output_total_count"]) == (one["union8"]["output_records"], one["union8"]["output_total_count"])
+    assert len(u["per_rank"]) == 8 and sum(r["shard_input_records"] for r in u["per_rank"]) == 8 * 400000
+
+
+@pytest.mark.parametrize("dist", ["clustered", "genomic"])
+def test_sampled_splitters_balance_the_shards(dist):
+    """gt4hip_shard_cuts: eight shards of lists whose keys are NOT spread evenly hold the same number of
+    input records within 5 %; equal-width ranges of the key space do not (that is what the option is for)"""
+    args = ["--workload", "union8", "--entries8", "400000", "--dist", dist, "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
+    r = _bench(8, args, {"GT4_BENCH_ONE_DEVICE": "1"})
+    assert r["self_check"] == "ok" and r["config"]["splitters"] == "sampled"
+    loads = [x["shard_input_records"] for x in r["config"]["per_rank"]]
+    mean = sum(loads) / 8.0
+    assert max(loads) <= 1.05 * mean and min(loads) >= 0.95 * mean, loads
+    e = _bench(8, args + ["--splitters", "equal"], {"GT4_BENCH_ONE_DEVICE": "1"})
+    assert e["self_check"] == "ok"
+    assert (e["config"]["output_records"], e["config"]["output_total_count"]) == (r["config"]["output_records"], r["config"]["output_total_count"])
+
+
+def test_projection_from_one_gpu_adds_up():
+    """bench.py --project-shards 8: the eight shards' outputs add up to the whole job's, the line says what it projects"""
+    r = _bench(1, ["--workload", "union8", "--entries8", "400000", "--steps", "2", "--warmup", "1", "--project-shards", "8"])
+    assert r["self_check"] == "ok" and r["unit"] == "x" and r["value"] > 0
+    proj = r["config"]["projection"]
+    assert [p["splitters"] for p in proj] == ["sampled", "equal"]
+    for p in proj:
+        assert p["outputs_add_up"] and len(p["per_shard"]) == 8
+        assert sum(x["input_records"] for x in p["per_shard"]) == 8 * 400000
+
+
 def test_self_check_failure_exits_non_zero():
     """a line whose totals contradict the generator's closed form must not exit 0 (GT4_BENCH_BREAK_CHECK: test hook)"""
     env = dict(os.environ, GT4_BENCH_BREAK_CHECK="1")

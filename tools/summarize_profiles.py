@@ -11,9 +11,20 @@ import csv, glob, json, os, sys
 
 src, tag = sys.argv[1], sys.argv[2]
 workload = sys.argv[3] if len(sys.argv) > 3 else "intersect"
-ROUND = os.environ.get("GT4_ROUND", "round4")
+ROUND = os.environ.get("GT4_ROUND", "round5")
 dst = os.path.join(src, "summary")
 os.makedirs(dst, exist_ok=True)
+
+
+def csrc_sha16():
+    """the hash bench.py ties the replayed traffic to (same function there)"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "genometester4_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def find(sub, suffix):
@@ -84,6 +95,7 @@ if fetch and write:
     tj = {
         "workload": workload,
         "commit": os.environ.get("GT4_COMMIT"),
+        "csrc_sha16": csrc_sha16(),  # bench.py refuses the replay when the kernel sources differ
         "n_per_list": cfg.get("entries_per_list_per_gpu", cfg.get("entries_per_list")),
         "merge_kernels_hbm_bytes_per_step_incl_list_generation": (all_f + all_w) / steps,
         "kernel": dom,
