@@ -51,7 +51,7 @@ SYMBOLS = [
     "gt4hip_union_multi", "gt4hip_intersect_multi", "gt4hip_union_table", "gt4hip_probe_table", "gt4hip_probe_table_ex", "gt4hip_table_compact", "gt4hip_table_download",
     "gt4hip_table_free", "gt4hip_generate", "gt4hip_generate_ex", "gt4hip_synchronize", "gt4hip_set_option",
     "gt4hip_get_counter", "gt4hip_device_memory", "gt4hip_list_upload_fd", "gt4hip_list_load_fd", "gt4hip_list_load",
-    "gt4hip_list_write_fd", "gt4hip_lists_write_fd", "gt4hip_shard_first_key", "gt4hip_shard_cuts", "gt4hip_comm_unique_id", "gt4hip_comm_create", "gt4hip_comm_destroy", "gt4hip_comm_allgather_totals",
+    "gt4hip_list_write_fd", "gt4hip_lists_write_fd", "gt4hip_shard_first_key", "gt4hip_shard_cuts", "gt4hip_comm_unique_id", "gt4hip_comm_create", "gt4hip_comm_destroy", "gt4hip_comm_allgather_totals", "gt4hip_context_device", "gt4hip_trim",
     "gt4hip_comm_rank", "gt4hip_comm_size", "gt4hip_comm_last_error", "gt4hip_comm_gatherv", "gt4hip_sort_words", "gt4hip_words_to_list",
     "gt4hip_device_words_to_list",
 ]

@@ -23,7 +23,8 @@ struct _GT4HipWordList {
    * key-range chunks (gt4_shard.c: loader / merger / writer threads, the plan of the command-line tool); every
    * other entry point uploads the list on first use and fails with a message if it does not fit. */
   GT4ListFile file;
-  int file_backed;
+  int file_backed;   /* `file` is open (round 5: also for uploaded lists that came from a file, so that a union which does
+                      * not fit beside them can still stream every input from its mapping) */
 };
 
 #include "gt4_shard.h"
@@ -39,10 +40,10 @@ static uint64_t resident_limit (gt4hip_context *ctx)
     if (end && (*end == 'K' || *end == 'k')) v *= 1024.0;
     else if (end && (*end == 'M' || *end == 'm')) v *= 1024.0 * 1024.0;
     else if (end && (*end == 'G' || *end == 'g')) v *= 1024.0 * 1024.0 * 1024.0;
-    return v > 0 ? (uint64_t) v : 0;
+    if (v > 0) return (uint64_t) v; /* ("0" or something unparsable: as if unset, like the command-line tool) */
   }
   uint64_t free_b = 0, total_b = 0;
-  if (gt4hip_device_memory (ctx, &free_b, &total_b)) return 0;
+  if (gt4hip_device_memory (ctx, &free_b, &total_b)) return UINT64_MAX; /* (no answer: upload as before rather than map everything) */
   return free_b / 4;
 }
 
@@ -133,12 +134,21 @@ GT4HipWordList *gt4_hip_word_list_new (const char *listfilename, unsigned int ma
                     : gt4hip_list_upload (ctx, lf.records, lf.header.n_words, lf.header.word_length, &dev);
   const uint64_t n = lf.header.n_words, total = lf.header.total_count;
   const unsigned int wl = lf.header.word_length;
-  gt4_listfile_close (&lf);
   if (rc) {
+    gt4_listfile_close (&lf);
     fprintf (stderr, "gt4_hip_word_list_new: upload of %s failed: %s\n", listfilename, gt4hip_last_error (ctx));
     return NULL;
   }
-  return wrap_uploaded (ctx, dev, n, wl, total, 1);
+  GT4HipWordList *l = wrap_uploaded (ctx, dev, n, wl, total, 1);
+  if (!l) {
+    gt4_listfile_close (&lf);
+    return NULL;
+  }
+  /* the mapping stays (costs address space only): a union too big to sit beside the uploaded lists streams every
+   * input from its file (gt4_write_union) */
+  l->file = lf;
+  l->file_backed = 1;
+  return l;
 }
 
 GT4HipWordList *gt4_hip_word_list_new_from_records (const void *records, uint64_t n_words, unsigned int word_length)
@@ -171,6 +181,8 @@ int gt4_hip_word_list_is_file_backed (const GT4HipWordList *list) { return list 
 
 #define ITER_BLOCK (1u << 20)
 
+static void iter_remember (GT4HipWordSListIter *it, void *block);
+
 /* makes record it->idx the current one; 1 = ok */
 static unsigned int iter_load (GT4HipWordSListIter *it)
 {
@@ -182,7 +194,10 @@ static unsigned int iter_load (GT4HipWordSListIter *it)
     if (it->idx < it->block_first || it->idx >= it->block_first + it->block_count || !it->block) {
       gt4hip_context *ctx = gt4_hip_default_context ();
       if (!ctx || ensure_device (ctx, l, "gt4_hip_word_slist")) return 0;
-      if (!it->block) it->block = malloc ((size_t) ITER_BLOCK * 12u);
+      if (!it->block) {
+        it->block = malloc ((size_t) ITER_BLOCK * 12u);
+        if (it->block) iter_remember (it, it->block);
+      }
       if (!it->block) return 0;
       const uint64_t cnt = l->num_words - it->idx < ITER_BLOCK ? l->num_words - it->idx : ITER_BLOCK;
       if (gt4hip_list_download_range (ctx, l->dev, it->idx, cnt, it->block)) {
@@ -199,9 +214,38 @@ static unsigned int iter_load (GT4HipWordSListIter *it)
   return 1;
 }
 
+/* Blocks of iterators that are walked again without a release in between (the reference's idiom: get_first_word on
+ * the same iterator restarts the walk, src/word-list-sorted.c:59-68, and there is no release there).  The iterator
+ * itself may be uninitialised stack memory on its first use, so what it holds cannot be looked at: the blocks handed
+ * out are remembered by the iterator's ADDRESS instead. */
+#define ITER_SLOTS 64
+static struct { GT4HipWordSListIter *it; void *block; } g_iter_blocks[ITER_SLOTS];
+
+static void iter_forget (GT4HipWordSListIter *it, int free_block)
+{
+  for (int i = 0; i < ITER_SLOTS; i++)
+    if (g_iter_blocks[i].it == it) {
+      if (free_block) free (g_iter_blocks[i].block);
+      g_iter_blocks[i].it = NULL;
+      g_iter_blocks[i].block = NULL;
+    }
+}
+
+static void iter_remember (GT4HipWordSListIter *it, void *block)
+{
+  for (int i = 0; i < ITER_SLOTS; i++)
+    if (!g_iter_blocks[i].it) {
+      g_iter_blocks[i].it = it;
+      g_iter_blocks[i].block = block;
+      return;
+    }
+  /* (more than ITER_SLOTS live iterators with blocks: the oldest idiom applies -- release them) */
+}
+
 unsigned int gt4_hip_word_slist_get_first_word (GT4HipWordList *list, GT4HipWordSListIter *it)
 {
   if (!list || !it) return 0;
+  iter_forget (it, 1); /* a walk restarted on this iterator: its block of the walk before goes */
   memset (it, 0, sizeof *it);
   it->list = list;
   it->num_words = list->num_words;
@@ -224,6 +268,7 @@ unsigned int gt4_hip_word_slist_get_next_word (GT4HipWordSListIter *it)
 void gt4_hip_word_slist_iter_release (GT4HipWordSListIter *it)
 {
   if (!it) return;
+  iter_forget (it, 0);
   free (it->block);
   it->block = NULL;
   it->block_count = 0;
@@ -256,9 +301,29 @@ unsigned int gt4_write_union (GT4HipWordList *arrays[], unsigned int n_arrays, u
    * the device in key-range chunks -- the command-line tool's pipeline (gt4_shard.c), reading the mapped files and
    * writing `ofile` behind its header -- so neither the inputs nor the output have to fit HBM; glistmaker's
    * collation of up to 32 temporary lists (reference src/glistmaker.c:787-835) is this call. */
-  unsigned int n_backed = 0;
-  for (unsigned int j = 0; j < n_arrays; j++) n_backed += arrays[j] && arrays[j]->file_backed && !arrays[j]->dev;
-  if (n_backed == n_arrays && n_arrays <= 1024) {
+  /* Round 5 (ADVICE): decided per CALL.  Every handle that came from a file keeps its mapping, uploaded or not; when
+   * all inputs have one, the union streams whenever some input is not resident, or the inputs still to upload plus the
+   * worst-case output (plus the intermediate levels of more than eight lists) would not fit what the device has free --
+   * and again as the fallback when the resident union runs out of memory after all. */
+  unsigned int n_backed = 0, n_files = 0;
+  uint64_t in_bytes = 0, missing_bytes = 0;
+  for (unsigned int j = 0; j < n_arrays; j++) {
+    if (!arrays[j]) return 1;
+    n_files += arrays[j]->file_backed != 0;
+    n_backed += arrays[j]->file_backed && !arrays[j]->dev;
+    in_bytes += 12u * arrays[j]->num_words;
+    if (!arrays[j]->dev) missing_bytes += 12u * arrays[j]->num_words;
+  }
+  int stream = n_backed == n_arrays;
+  if (!stream && n_files == n_arrays) {
+    uint64_t free_b = 0, total_b = 0;
+    const uint64_t need = missing_bytes + in_bytes + (n_arrays > 8 ? in_bytes : 0);
+    if (n_backed > 0) stream = 1; /* (a mixed set: the lists that did not fit alone will not fit beside the others) */
+    else if (!gt4hip_device_memory (ctx, &free_b, &total_b) && need > free_b - free_b / 5) stream = 1;
+  }
+  int tried_resident = 0;
+stream_it:
+  if (stream && n_files == n_arrays && n_arrays <= 1024) {
     GT4ListFile *files = (GT4ListFile *) malloc (n_arrays * sizeof *files);
     if (!files) return 1;
     for (unsigned int j = 0; j < n_arrays; j++) files[j] = arrays[j]->file;
@@ -274,7 +339,11 @@ unsigned int gt4_write_union (GT4HipWordList *arrays[], unsigned int n_arrays, u
     job.prm.cutoff = cutoff;
     job.prm.count_only = ofile ? 0 : 1;
     job.n_ranks = 1;
-    job.hbm_limit = resident_limit (ctx);
+    /* the worker creates its own contexts: on the device the budget is measured on, with the pooled blocks of this
+     * context given back first (they would count as used) */
+    gt4hip_trim (ctx);
+    job.device_plus_1 = gt4hip_context_device (ctx) + 1;
+    job.hbm_limit = resident_limit (ctx) == UINT64_MAX ? 0 : resident_limit (ctx);
     job.debug = getenv ("GT4HIP_VERBOSE") && atoi (getenv ("GT4HIP_VERBOSE"));
     unsigned int bad = 0;
     off_t pos = 0;
@@ -313,6 +382,11 @@ unsigned int gt4_write_union (GT4HipWordList *arrays[], unsigned int n_arrays, u
   memset (&res, 0, sizeof res);
   int rc = gt4hip_union_multi (ctx, devs, n_arrays, cutoff, GT4HIP_RULE_ADD, 0, ofile ? 0 : 1, &res);
   free (devs);
+  if (rc == GT4HIP_ENOMEM && n_files == n_arrays && n_arrays <= 1024 && !tried_resident) {
+    tried_resident = 1;
+    stream = 1;
+    goto stream_it;
+  }
   if (rc) {
     fprintf (stderr, "gt4_write_union: %s\n", gt4hip_last_error (ctx));
     return 1;

@@ -414,6 +414,7 @@ static int worker_main (const GT4ShardJob *job, Shared *sh, int rank)
     const int n_dev = gt4hip_device_count ();
     const char *dev = getenv ("GT4HIP_DEVICE");
     w->device = n_dev > 0 ? ((dev ? atoi (dev) : 0) + rank) % n_dev : 0;
+    if (G == 1 && job->device_plus_1 > 0 && job->device_plus_1 <= n_dev) w->device = job->device_plus_1 - 1; /* (the device the caller measured its budget on) */
     if (gt4hip_create (w->device, &ctx)) worker_fail (w, "Error: %s", gt4hip_last_error (NULL));
     if (ctx && job->debug) fprintf (errf, "Worker %d of %d: device %d: %s\n", rank, G, w->device, gt4hip_device_info (ctx));
   }

@@ -38,6 +38,7 @@ typedef struct {
   int n_ranks;                   /* worker processes = GPUs (1: no fork, runs in the caller)     */
   uint64_t hbm_limit;            /* device bytes a worker may hold in flight; 0: 70 % of what is free */
   int auto_budget;               /* hbm_limit 0 and inputs that fit the device: the budget by mode (see worker_main) */
+  int device_plus_1;             /* single worker: the device to run on + 1 (0: $GT4HIP_DEVICE, else device 0) -- the caller's context may live elsewhere */
   int gather_rccl;               /* 0: every rank pwrites its extents; 1: RCCL gatherv to rank 0 */
   int debug;
 } GT4ShardJob;

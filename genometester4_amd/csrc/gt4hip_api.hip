@@ -145,6 +145,17 @@ extern "C" const char *gt4hip_device_info (const gt4hip_context *ctx)
   return ctx ? ctx->info : "";
 }
 
+extern "C" int gt4hip_context_device (const gt4hip_context *ctx) { return ctx ? ctx->device : -1; }
+
+extern "C" int gt4hip_trim (gt4hip_context *ctx)
+{
+  if (!ctx) return GT4HIP_EINVAL;
+  HIPCHK (ctx, hipSetDevice (ctx->device));
+  HIPCHK (ctx, hipStreamSynchronize (ctx->stream));
+  pool_flush (ctx);
+  return GT4HIP_OK;
+}
+
 extern "C" int gt4hip_device_memory (gt4hip_context *ctx, uint64_t *free_bytes, uint64_t *total_bytes)
 {
   if (!ctx) return GT4HIP_EINVAL;
@@ -1237,7 +1248,8 @@ extern "C" int gt4hip_union_table (gt4hip_context *ctx, const gt4hip_list *const
   } stamp = { ctx, t_begin };
   memset (table, 0, sizeof *table);
   table->n_lists = n_lists;
-  /* up to eight non-empty lists: two launches of the N-way tile kernel write keys and counts directly */
+  /* up to eight non-empty lists: ONE launch of the N-way tile kernel writes keys and counts directly, every tile's rows
+   * where its records start (a ragged table: one row slot per input RECORD, up to n_lists times the distinct keys) */
   if (ctx->kway_enabled) {
     const gt4hip_list *work[8];
     uint32_t cols[8], k = 0;
@@ -1255,7 +1267,12 @@ extern "C" int gt4hip_union_table (gt4hip_context *ctx, const gt4hip_list *const
       HIPCHK (ctx, hipSetDevice (ctx->device));
       int used = 0;
       const int rc = gt4hip_nway_table (ctx, work, k, cols, table, 0, 0, &used);
-      if (rc) return rc;
+      /* the ragged table did not fit: the path below needs one row per DISTINCT key only */
+      if (rc && rc != GT4HIP_ENOMEM) return rc;
+      if (rc == GT4HIP_ENOMEM) {
+        used = 0;
+        ctx->err[0] = 0;
+      }
       if (used) {
         ctx->kway_calls++;
         return GT4HIP_OK;

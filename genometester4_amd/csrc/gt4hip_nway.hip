@@ -2349,8 +2349,8 @@ int gt4hip_nway_union (gt4hip_context *ctx, const gt4hip_list *const lists[], ui
 }
 
 /* The count table of 2..8 non-empty lists (all their distinct keys ascending; column cols[i] = list i's
- * count of the key, 0 where it has none) by two launches of the tile kernel over one partition: distinct
- * keys per tile, then keys and counts written at every tile's rows.  table->n_lists columns (those no list
+ * count of the key, 0 where it has none) by ONE launch of the tile kernel: keys and counts written where every
+ * tile's records start (a ragged table, allocated for the lists' records; GT4HIP_ENOMEM: the caller builds it by merges).  table->n_lists columns (those no list
  * is given for stay 0).  *used = 0: nothing was done, the caller builds the table by merges. */
 int gt4hip_nway_table (gt4hip_context *ctx, const gt4hip_list *const lists[], uint32_t k, const uint32_t cols[], gt4hip_count_table *table, int probe,
                        int presence, int *used)

@@ -80,6 +80,9 @@ const char *gt4hip_last_error (const gt4hip_context *ctx);
 const char *gt4hip_strerror (int code);
 /* Number of HIP devices visible; 0 when there is none or the runtime is unusable. */
 int gt4hip_device_count (void);
+/* The device a context lives on, and: give the context's pooled (freed, kept for reuse) blocks back to the driver. */
+int gt4hip_context_device (const gt4hip_context *ctx);
+int gt4hip_trim (gt4hip_context *ctx);
 /* Free and total bytes of the context's device memory right now (hipMemGetInfo). */
 int gt4hip_device_memory (gt4hip_context *ctx, uint64_t *free_bytes, uint64_t *total_bytes);
 /* "name|gcnArch|CUs|HBM bytes" of the context's device, for logs. */
