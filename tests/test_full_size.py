@@ -174,15 +174,18 @@ def _check_multi_windows(lists, out, n_words, total, cutoff, rule, ovr=1):
     assert out.n_words == n_words and out.sum_counts() == total and out.is_sorted()
 
 
-@pytest.mark.parametrize("dist", ["stride", "iid", "clustered"])
+@pytest.mark.parametrize("dist", ["stride", "iid", "clustered", "genomic"])
 def test_config3_eight_way_union_full_size(ctx, dist):
     """BASELINE config 3 on one GPU: the union of eight 5e8-entry k=25 lists (the bench's construction:
     even lists share one key set, odd lists own disjoint ones; genometester4_amd/synth.py) -- by the library's
     own choice (the one-pass N-way tile kernel; the pairwise tree for clustered keys), by the tile kernel
     whatever the keys, and by the pairwise tree (whose intermediate levels keep every key and add raw counts,
     src/glistcompare.c:545-591), each against the oracle on key windows, and against each other.  Key
-    distributions: one key per stride of the key space (the bench's default), independent uniform draws, and
-    stretches of adjacent keys between wide gaps (which the default setting hands to the tree)."""
+    distributions: one key per stride of the key space (the bench's default), independent uniform draws,
+    stretches of adjacent keys between wide gaps (which the default setting hands to the tree), and GENOMIC
+    k-mers (round 5: canonical k-mers of mutated copies of one sequence with planted repeats, made by the
+    repo's own sort + fold -- the shape glistmaker's lists have, src/glistmaker.c:914-924; which path the
+    library chooses for them is printed)."""
     from genometester4_amd import synth
     n = 500_000_000
     lists = synth.make_lists8(ctx, n, 25, dist)
@@ -196,6 +199,10 @@ def test_config3_eight_way_union_full_size(ctx, dist):
         assert nw == 5 * n
     if dist == "clustered":
         assert ctx.get_counter("kway_declined") == declined + 1 and ctx.get_counter("nway_one_pass") == 0
+    elif dist == "genomic":  # the library's own choice for real-shaped keys: recorded, either is exact
+        one = ctx.get_counter("nway_one_pass")
+        assert (ctx.get_counter("kway_declined") == declined + 1) != (one == 1)
+        print("genomic keys, 8 x %d records: %s" % (n_in // 8, "one pass of the tile kernel" if one else "declined: pairwise tree"))
     else:
         assert ctx.get_counter("kway_calls") == calls + 1 and ctx.get_counter("nway_one_pass") == 1
     _check_multi_windows(lists, out, nw, tot, 1, 0)
@@ -209,21 +216,22 @@ def test_config3_eight_way_union_full_size(ctx, dist):
             ctx.set_option("kway", 1)
         assert (rc, nw_t, tot_t) == (0, nw, tot)
         assert ctx.get_counter("nway_one_pass") == (1 if kway else 0)
-        if kway == 0 or dist == "clustered":
+        if kway == 0 or dist in ("clustered", "genomic"):
             _check_multi_windows(lists, out_t, nw, tot, 1, 0)
         assert out_t.download_range(nw // 3, 200000).tobytes() == probe
         out_t.free()
     # rule MAX with a cutoff on the result (union_multi :574): both paths again
+    cut = 2 if dist == "genomic" else 5  # (k-mer occurrences are 1 almost everywhere: the planted repeats reach 2 and more)
     ctx.set_option("kway", 3)
     try:
-        rc, nw2, tot2, out2 = ctx.union_multi(lists, 5, 4)
+        rc, nw2, tot2, out2 = ctx.union_multi(lists, cut, 4)
     finally:
         ctx.set_option("kway", 1)
     assert rc == 0
-    _check_multi_windows(lists, out2, nw2, tot2, 5, 4)
+    _check_multi_windows(lists, out2, nw2, tot2, cut, 4)
     ctx.set_option("kway", 0)
     try:
-        rc, nw3, tot3, _ = ctx.union_multi(lists, 5, 4, 1, True)
+        rc, nw3, tot3, _ = ctx.union_multi(lists, cut, 4, 1, True)
     finally:
         ctx.set_option("kway", 1)
     assert (nw3, tot3) == (nw2, tot2)
@@ -254,7 +262,8 @@ def test_sort_and_fold_beyond_2_pow_32_words(ctx):
     lst.free()
 
 
-def test_count_tables_at_bench_size(ctx):
+@pytest.mark.parametrize("dist", ["stride", "genomic"])
+def test_count_tables_at_bench_size(ctx, dist):
     """N3 at the size bench.py --workload table runs: six 1e8-entry k=25 lists (even lists share one key
     set).  The union table (4e8 rows x 6) and the table restricted to the keys of list 0, by the N-way tile
     kernel: row count and key column against the N-way union's own output, every column against
@@ -264,7 +273,11 @@ def test_count_tables_at_bench_size(ctx):
     import ctypes as C
     n, nl = 100_000_000, 6
     lists = []
-    for j in range(nl):
+    if dist == "genomic":  # (round 5) k-mer lists of mutated copies of one sequence: most keys in all six lists
+        from genometester4_amd import synth
+        lists = synth.make_lists8(ctx, n, 25, "genomic", nl)
+        n = lists[0].n_words
+    for j in range(nl if dist == "stride" else 0):
         lst = ctx.alloc(n, 25)
         shared = j % 2 == 0
         ctx.generate_ex(lst, n, 7 if shared else 100 + j, 50 + j, 8, 16, 0 if shared else 1 + j)
