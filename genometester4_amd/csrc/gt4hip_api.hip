@@ -95,6 +95,7 @@ extern "C" int gt4hip_create (int device, gt4hip_context **out)
     const char *e = getenv ("GT4HIP_KWAY_SUB"); /* diagnostic: A/B of the two tile kernels without touching the caller */
     ctx->kway_sub = e ? atoi (e) : 0; /* (round 5: k_nway_sub loses the A/B -- profiles/round5/r5_nsub_ab.log; k_nway_merge stays) */
   }
+  ctx->kway_max = 32;
   ctx->kway_enabled = 1; /* N-way unions of three lists or more take the one-pass tile kernel (gt4hip_nway.hip); option "kway": 0 the pairwise tree, 2 also two lists */
   snprintf (ctx->info, sizeof ctx->info, "%s|%s|%d|%zu", prop.name, prop.gcnArchName, prop.multiProcessorCount, prop.totalGlobalMem);
   if ((e = hipStreamCreateWithFlags (&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
@@ -185,6 +186,7 @@ extern "C" int gt4hip_set_option (gt4hip_context *ctx, const char *name, int64_t
   else if (!strcmp (name, "dynamic")) ctx->dynamic = (int) value;
   else if (!strcmp (name, "kway")) ctx->kway_enabled = (int) value;
   else if (!strcmp (name, "kway_sub")) ctx->kway_sub = (int) value;
+  else if (!strcmp (name, "kway_max")) ctx->kway_max = value == 8 ? 8 : (value == 33 ? 33 : 32);
   else if (!strcmp (name, "kway_g")) ctx->kway_g = value;
   else if (!strcmp (name, "kway_vt")) ctx->kway_vt = value;
   else if (!strcmp (name, "spin_limit")) ctx->spin_limit = value > 0 ? (uint32_t) value : 0u;
@@ -202,6 +204,8 @@ extern "C" int gt4hip_get_counter (gt4hip_context *ctx, const char *name, uint64
   else if (!strcmp (name, "kway_overflows")) *value = ctx->kway_overflows;
   else if (!strcmp (name, "kway_declined")) *value = ctx->kway_declined;
   else if (!strcmp (name, "kway_splits")) *value = ctx->kway_splits;
+  else if (!strcmp (name, "kway_shared_x100")) *value = ctx->kway_shared_x100;
+  else if (!strcmp (name, "kway_width")) *value = ctx->kway_width;
   else if (!strcmp (name, "nway_kernel_us")) *value = (uint64_t) (ctx->nway_kernel_ms * 1000.0);
   else if (!strcmp (name, "nway_tiles")) *value = ctx->nway_tiles;
   else if (!strcmp (name, "nway_one_pass")) *value = (uint64_t) ctx->last_multi_one_pass;
@@ -861,6 +865,65 @@ static int empty_result (gt4hip_context *ctx, uint32_t word_length, bool count_o
  * more than eight lists take levels of eight-way merges that keep every key (ADD / MAX are
  * associative, NUMBER ignores the counts), the cutoff is applied once, at the last level (:574).
  * *done = 0: nothing was produced, the caller takes the pairwise tree. */
+/* In how many of the lists does a key of the lists lie?  256 keys of each of four probe lists, looked up in every list
+ * (binary searches): matches[0] += lists holding the key.  One pass over 9 .. 32 lists ranks a key among everything in its
+ * bucket, and a key that sixteen lists share puts sixteen records there: measured (32 x 1.25e8 records, profiles/round5):
+ * one pass 47.9 ms against 67.7 for levels of eight-way merges where few keys are shared, 64.6 against 54.1 where sixteen
+ * of the lists are the same. */
+struct ShareProbe {
+  const uint32_t *list[32];
+  uint64_t n[32];
+  uint32_t k;
+  uint32_t probe[4];
+};
+
+__global__ __launch_bounds__ (256) void k_share_probe (ShareProbe sp, unsigned long long *matches)
+{
+  const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t b = id % sp.k, j = (id / sp.k) % 256u, a = sp.probe[(id / sp.k) / 256u];
+  if (id >= 4u * 256u * sp.k || !sp.n[a] || !sp.n[b]) return;
+  const uint32_t *pa = sp.list[a] + 3 * (uint64_t) (((unsigned __int128) sp.n[a] * j) / 256u);
+  const uint64_t key = (uint64_t) pa[0] | ((uint64_t) pa[1] << 32);
+  uint64_t lo = 0, hi = sp.n[b];
+  while (lo < hi) {
+    const uint64_t mid = (lo + hi) >> 1;
+    const uint32_t *q = sp.list[b] + 3 * mid;
+    if (((uint64_t) q[0] | ((uint64_t) q[1] << 32)) < key) lo = mid + 1;
+    else hi = mid;
+  }
+  bool hit = false;
+  if (lo < sp.n[b]) {
+    const uint32_t *q = sp.list[b] + 3 * lo;
+    hit = ((uint64_t) q[0] | ((uint64_t) q[1] << 32)) == key;
+  }
+  const unsigned long long m = __builtin_amdgcn_ballot_w64 (hit);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd (matches, (unsigned long long) __popcll (m));
+}
+
+/* the mean number of lists a probed key lies in (1: the lists share nothing) */
+static int shared_key_multiplicity (gt4hip_context *ctx, const std::vector<const gt4hip_list *> &lists, double *mean)
+{
+  ShareProbe sp;
+  memset (&sp, 0, sizeof sp);
+  sp.k = (uint32_t) (lists.size () < 32 ? lists.size () : 32);
+  for (uint32_t i = 0; i < sp.k; i++) {
+    sp.list[i] = (const uint32_t *) lists[i]->dev;
+    sp.n[i] = lists[i]->n_words;
+  }
+  sp.probe[0] = 0;
+  sp.probe[1] = (sp.k / 4 + 1) % sp.k;
+  sp.probe[2] = sp.k / 2;
+  sp.probe[3] = (3 * sp.k / 4 + 1) % sp.k;
+  HIPCHK (ctx, hipMemsetAsync (ctx->scratch, 0, 8, ctx->stream));
+  hipLaunchKernelGGL (k_share_probe, dim3 ((4 * 256 * sp.k + 255) / 256), dim3 (256), 0, ctx->stream, sp, ctx->scratch);
+  const int rc = read_scratch (ctx, 1);
+  if (rc) return rc;
+  uint32_t probed = 0;
+  for (int q = 0; q < 4; q++) probed += sp.n[sp.probe[q]] ? 256u : 0u;
+  *mean = probed ? (double) ctx->scratch_host[0] / probed : 1.0;
+  return GT4HIP_OK;
+}
+
 static int union_multi_kway (gt4hip_context *ctx, const std::vector<const gt4hip_list *> &work, uint32_t rule, uint32_t cutoff, uint32_t ovr,
                              bool count_only, gt4hip_multi_result *res, int *done)
 {
@@ -875,11 +938,21 @@ static int union_multi_kway (gt4hip_context *ctx, const std::vector<const gt4hip
     for (gt4hip_list *l : owned) gt4hip_list_free (l);
     owned.clear ();
   };
-  while (cur.size () > 8 && !rc) {
+  /* lists per launch of the tile kernel: up to 32 in ONE pass (round 5; glistmaker's collation width, reference
+   * src/glistmaker.c:787-835), option "kway_max" = 8 restores the levels of eight-way merges */
+  size_t W = ctx->kway_max == 8 ? 8 : 32;
+  if (W == 32 && cur.size () > 8 && ctx->kway_max != 33) { /* ("kway_max" = 33: one pass whatever the keys; tests) */
+    double m = 1.0;
+    if ((rc = shared_key_multiplicity (ctx, cur, &m))) return rc;
+    ctx->kway_shared_x100 = (uint64_t) (100.0 * m);
+    if (m > 5.0) W = 8; /* keys that many lists share: levels of eight-way merges fold them step by step */
+  }
+  ctx->kway_width = (uint64_t) W;
+  while (cur.size () > W && !rc) {
     std::vector<const gt4hip_list *> next;
     std::vector<gt4hip_list *> next_owned;
-    for (size_t i = 0; i < cur.size () && !rc; i += 8) {
-      const size_t g = cur.size () - i < 8 ? cur.size () - i : 8;
+    for (size_t i = 0; i < cur.size () && !rc; i += W) {
+      const size_t g = cur.size () - i < W ? cur.size () - i : W;
       if (g < 3) { /* one or two left over: carried to the next level as they are */
         for (size_t j = 0; j < g; j++) next.push_back (cur[i + j]);
         continue;

@@ -113,8 +113,40 @@ def test_more_than_eight_lists(ctx, n_lists):
     rng = np.random.default_rng(n_lists)
     lists = _random_lists(rng, n_lists, 40000)
     lists.insert(3, lists[0][:0])  # an empty member is skipped (:525-532)
-    _check(ctx, lists, rule=1, cutoff=2)
-    _check(ctx, lists, rule=4, cutoff=0)
+    # one pass over up to 32 lists (round 5), levels of eight-way merges, and the library's choice between the two
+    # (a probe of how many lists share a key; option "kway_max": 33 / 8 / 32)
+    for kmax in (33, 8, 32):
+        ctx.set_option("kway_max", kmax)
+        try:
+            _check(ctx, lists, rule=1, cutoff=2)
+            _check(ctx, lists, rule=4, cutoff=0)
+            assert kmax == 32 or ctx.get_counter("kway_width") == (32 if kmax == 33 else 8)
+        finally:
+            ctx.set_option("kway_max", 32)
+
+
+def test_thirty_two_lists_in_one_pass(ctx):
+    """glistmaker's collation width (reference src/glistmaker.c:787-835) as ONE launch of the tile kernel: lists of very
+    different lengths that share little, lists of which sixteen are the same (the library then takes levels of eight),
+    thirty-three lists (a level of 32, then the pair kernel)"""
+    rng = np.random.default_rng(32)
+    keys = np.unique(rng.integers(0, 1 << 44, size=400000, dtype=np.uint64))
+    lists = []
+    for j in range(32):
+        m = rng.random(len(keys)) < (0.02 if j % 3 else 0.2)
+        lists.append(U.make_records(keys[m], rng.integers(0, 9, size=int(m.sum()), dtype=np.uint32)))
+    _check(ctx, lists, k=22, rule=1, cutoff=1)
+    assert ctx.get_counter("kway_width") == 32 and ctx.get_counter("kway_shared_x100") < 500
+    same = U.make_records(keys[::2], rng.integers(1, 9, size=len(keys[::2]), dtype=np.uint32))
+    shared = [same if j % 2 == 0 else lists[j] for j in range(32)]
+    _check(ctx, shared, k=22, rule=1, cutoff=3)
+    assert ctx.get_counter("kway_width") == 8 and ctx.get_counter("kway_shared_x100") > 500
+    ctx.set_option("kway_max", 33)
+    try:
+        _check(ctx, shared, k=22, rule=4, cutoff=2)
+        _check(ctx, lists + [same], k=22, rule=1, cutoff=2)
+    finally:
+        ctx.set_option("kway_max", 32)
 
 
 def test_every_tile_through_the_search_path(ctx):
