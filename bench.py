@@ -69,6 +69,9 @@ EXPECTED_TOTALS = {
 
 def self_check(kind, dist, n, k, n_words, total_count):
     """Closed forms of the stride generator + the committed totals of the default sizes -> None or a message."""
+    if dist == "disjoint":
+        want = MULTI[kind]["lists"] * n if kind in MULTI and MULTI[kind]["op"] == "union" else None
+        return None if want is None or n_words == want else "union holds %d records, generator says %d" % (n_words, want)
     if dist != "stride":
         return None
     if os.environ.get("GT4_BENCH_BREAK_CHECK"):  # test hook: the failure path itself
@@ -228,6 +231,8 @@ def multi_roofline(ctx, kind, n_in_local, n_out_local, device_ms, kernel_ms, one
         sub = os.environ.get("GT4HIP_KWAY_SUB", "0") != "0"
         kernel = ("k_nway_sub<NWAY_UNION> (wave-private sub-tiles; one pass over up to eight lists per launch)" if sub
                   else "k_nway_merge<1024, 4, 1, NWAY_UNION> (one pass over up to eight lists per launch)")
+        if MULTI[kind]["lists"] > 8:
+            kernel = "km32::k_nway_merge<1024, 4, 1, NWAY_UNION> (one pass over up to 32 lists per launch: runs end to end in the tile, samples every 64 records)"
     elif MULTI[kind]["op"] == "intersect":
         kernel = "k_pair_merge<1024, 6, MODE_LOOKBACK, intersection> (left-to-right chain, one launch per list after the first)"
     else:
@@ -397,10 +402,11 @@ def bench_multi(args, ctx, capi, rank, local_rank, world, kind="union8"):
             cpu = ({"value": None, "unit": "k-mers/s", "cores": 0, "kind": "reference", "sample": "failed: %s" % e}, False)
     res = None
     if rank == 0:
-        if one_pass and n_lists <= 8:
-            path = "one pass of the N-way tile kernel"
+        width = ctx.get_counter("kway_width") if n_lists > 8 else 8
+        if one_pass and n_lists <= width:
+            path = "one pass of the N-way tile kernel" + (" (up to 32 lists per launch; a key lies in %.2f of the lists)" % (ctx.get_counter("kway_shared_x100") / 100.0) if n_lists > 8 else "")
         elif one_pass:
-            path = "levels of eight-way passes of the N-way tile kernel"
+            path = "levels of eight-way passes of the N-way tile kernel (a key lies in %.2f of the lists: the one-pass form would rank every copy)" % (ctx.get_counter("kway_shared_x100") / 100.0)
         else:
             path = "left-to-right chain of pair intersections" if spec["op"] == "intersect" else "pairwise tree of the pair kernel"
         res = {
@@ -415,7 +421,7 @@ def bench_multi(args, ctx, capi, rank, local_rank, world, kind="union8"):
                        "merge_only_ms_per_step": merge_only / args.steps * 1e3,
                        "gathered_bytes_per_step": 12 * (n_out - totals[0][0]) if has_comm else 0,
                        "note": "value includes the RCCL gatherv of the payload to rank 0; merge_only_* is the same job with every rank keeping (or writing) its own extent: BASELINE's >= 6x at 8 GPUs refers to merge_only"},
-            "roofline": multi_roofline(ctx, kind, n_local_in, totals[0][0], statistics.mean(dev_ms), statistics.mean(ker_ms), one_pass and n_lists <= 8, n8, args.dist, moved),
+            "roofline": multi_roofline(ctx, kind, n_local_in, totals[0][0], statistics.mean(dev_ms), statistics.mean(ker_ms), one_pass and n_lists <= width, n8, args.dist, moved),
             **({"cpu_baseline": cpu[0], "verified": cpu[1]} if cpu else {}),
         }
         bad = self_check(kind, args.dist, n8, args.k, n_out, total_out)
@@ -842,7 +848,7 @@ def main():
     ap.add_argument("--n32", "--entries32", dest="n32", type=int, default=125_000_000, help="union32: entries per list (whole job)")
     ap.add_argument("--n8", "--entries8", dest="n8", type=int, default=500_000_000, help="union8: entries per list (whole job)")
     ap.add_argument("--tree", action="store_true", help="union8: the pairwise tree instead of what the library chooses")
-    ap.add_argument("--dist", choices=["stride", "iid", "clustered", "genomic"], default="stride", help="key distribution of the synthetic lists (genometester4_amd/synth.py)")
+    ap.add_argument("--dist", choices=["stride", "iid", "clustered", "genomic", "disjoint"], default="stride", help="key distribution of the synthetic lists (genometester4_amd/synth.py)")
     ap.add_argument("--splitters", choices=["sampled", "equal"], default="sampled",
                     help="how a sharded job cuts the key space: sampled from the lists (gt4hip_shard_cuts: equal input records per shard) or equal-width ranges (gt4hip_shard_first_key)")
     ap.add_argument("--project-shards", type=int, default=0, metavar="N",

@@ -237,11 +237,13 @@ def make_pair(ctx, n, k, dist="stride", seed=0):
 
 def make_lists8(ctx, n8, k, dist="stride", n_lists=8):
     """The union bench's lists: even lists share their keys, odd lists have keys of their own."""
-    if dist == "stride":
+    if dist in ("stride", "disjoint"):
+        # "disjoint" (round 5): every list has keys of its own -- what glistmaker collates (temporary lists of different
+        # stretches of the input share few k-mers, reference src/glistmaker.c:787-835); "stride": even lists share theirs
         lists = []
         for j in range(n_lists):
             lst = ctx.alloc(n8, k)
-            shared = j % 2 == 0
+            shared = j % 2 == 0 and dist == "stride"
             ctx.generate_ex(lst, n8, 7 if shared else 100 + j, 50 + j, 8, 2 * n_lists, 0 if shared else 1 + j)
             lists.append(lst)
         return lists
