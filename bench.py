@@ -202,7 +202,7 @@ def load_traffic(workload, n, kernel=None):
     if tj.get("csrc_sha16") != now:
         src["note"] = "REFUSED: the PMC passes ran on kernel sources %s, this tree has %s (re-run tools/collect_profiles.sh)" % (tj.get("csrc_sha16"), now)
         return None, src
-    if kernel and tj.get("kernel") and tj["kernel"].split("<")[0] != kernel.split("<")[0].split(" ")[0]:
+    if kernel and tj.get("kernel") and tj["kernel"].split("<")[0].replace("k_nway32_", "k_nway_") != kernel.split("<")[0].split(" ")[0].replace("km32::", ""):
         src["note"] = "REFUSED: the PMC passes name %s as the dominant kernel, this run %s" % (tj.get("kernel"), kernel)
         return None, src
     src["note"] = "replayed from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE), not measured in this run"

@@ -2346,7 +2346,15 @@ int nway_run (gt4hip_context *ctx, const gt4hip_list *const lists[], uint32_t k,
     if (e0 != hipSuccess) return gt4hip_fail (ctx, GT4HIP_EHIP, "hipEventRecord failed: %s", hipGetErrorString (e0)); /* (nothing is owned yet) */
   }
   /* option "kway" = 1 (the default) lets the call decline clustered keys: *used = 0, the caller takes the tree */
+  /* Host read-backs (round 5: nine per call of three levels -> three; each is a drained stream plus 20 - 30 us, 0.3 ms of
+   * a 4.7 ms call on an eighth of the bench's lists, i.e. of one GPU's shard at 8 GPUs).  The probe's answer is read with
+   * the first partition read-back (its sampling work is wasted where the call then declines: rare); a top level of one
+   * tile reads nothing back; the sample levels' control blocks are not read back (their error word stays set through
+   * the later launches and is seen with the last one). */
   const bool may_decline = ctx->kway_enabled == 1 && !table && ctx->kway_vt == 0;
+  u32 probe_windows = 0;
+  bool probe_pending = false;
+  hipMemsetAsync (ctx->ctl, 0, sizeof (PairControl), st);
   if (may_decline) {
     uint32_t longest = 0;
     for (uint32_t i = 1; i < k; i++)
@@ -2354,17 +2362,11 @@ int nway_run (gt4hip_context *ctx, const gt4hip_list *const lists[], uint32_t k,
     const u64 nl = lists[longest]->n_words;
     if (nl >= 16ull * NWAY_PROBE_KEYS) {
       const u32 windows = (u32) (nl / (4 * NWAY_PROBE_KEYS) < NWAY_PROBE_WINDOWS ? nl / (4 * NWAY_PROBE_KEYS) : NWAY_PROBE_WINDOWS);
-      hipError_t e = hipMemsetAsync (ctx->scratch, 0, 64, st);
-      if (e == hipSuccess) {
-        hipLaunchKernelGGL (k_nway_probe, dim3 (windows), dim3 (256), 0, st, (const u32 *) lists[longest]->dev, nl, windows, (u32) nway_buckets (NWAY_NBF * nway_cap (NWAY_UNION)), (u32 *) ctx->scratch);
-        e = hipMemcpyAsync (ctx->scratch_host, ctx->scratch, 8, hipMemcpyDeviceToHost, st);
-      }
-      if (e == hipSuccess) e = hipStreamSynchronize (st);
+      const hipError_t e = hipMemsetAsync ((char *) ctx->scratch + 32, 0, 8, st);
       if (e != hipSuccess) return gt4hip_fail (ctx, GT4HIP_EHIP, "N-way key probe failed: %s", hipGetErrorString (e));
-      if (5ull * (u32) ctx->scratch_host[0] > windows) {
-        ctx->kway_declined++;
-        return GT4HIP_OK; /* *used = 0 */
-      }
+      hipLaunchKernelGGL (k_nway_probe, dim3 (windows), dim3 (256), 0, st, (const u32 *) lists[longest]->dev, nl, windows, (u32) nway_buckets (NWAY_NBF * nway_cap (NWAY_UNION)), (u32 *) ctx->scratch + 8);
+      probe_windows = windows;
+      probe_pending = true;
     }
   }
   /* sample levels until one fits a single tile */
@@ -2442,17 +2444,32 @@ int nway_run (gt4hip_context *ctx, const gt4hip_list *const lists[], uint32_t k,
       const u64 n_blocks = (tiles + 1 + NWAY_SPLIT_BLOCK - 1) / NWAY_SPLIT_BLOCK;
       if ((rc = nway_grow (ctx, (void **) &ctx->kway_need, &ctx->kway_need_bytes, (size_t) (tiles + 1 + n_blocks + 4) * 4))) break;
       u32 *const need = (u32 *) ctx->kway_need, *const block_sums = need + tiles + 1;
-      hipMemsetAsync (ctx->scratch, 0, 64, st);
+      if (tiles == 1 && !merged && levels[l].total <= one_tile) {
+        /* the top level: one tile that fits by construction -- nothing to cut, nothing to read back */
+        part_final = (const u64 *) ctx->kway_part;
+        if (l == 0) ctx->kway_splits = 0;
+        break;
+      }
+      hipMemsetAsync (ctx->scratch, 0, 32, st);
       hipLaunchKernelGGL (k_nway_need, dim3 ((unsigned) n_blocks), dim3 (NWAY_SPLIT_BLOCK), 0, st, (const u64 *) ctx->kway_part, (u32) tiles, (u32) (cap / NWAY_HS), max_rec, need, block_sums,
                           (u32 *) ctx->scratch);
       hipLaunchKernelGGL (k_nway_need_scan, dim3 (1), dim3 (1024), 0, st, block_sums, (u32) n_blocks, (u32 *) ctx->scratch + 3);
-      hipError_t e = hipMemcpyAsync (ctx->scratch_host, ctx->scratch, 16, hipMemcpyDeviceToHost, st);
+      hipError_t e = hipMemcpyAsync (ctx->scratch_host, ctx->scratch, 40, hipMemcpyDeviceToHost, st);
       if (e == hipSuccess) e = hipStreamSynchronize (st);
       if (e != hipSuccess) {
         rc = gt4hip_fail (ctx, GT4HIP_EHIP, "N-way partition failed: %s", hipGetErrorString (e));
         break;
       }
       const u32 *const fl = (const u32 *) ctx->scratch_host;
+      if (probe_pending) { /* (the probe ran in front of everything else on this stream) */
+        probe_pending = false;
+        if (5ull * fl[8] > probe_windows) {
+          ctx->kway_declined++;
+          if (merged) gt4hip_list_free (merged);
+          cleanup ();
+          return GT4HIP_OK; /* *used = 0 */
+        }
+      }
       bool overflow = fl[0] != 0;
       part_final = (const u64 *) ctx->kway_part;
       if (!overflow && fl[2]) {
@@ -2546,7 +2563,8 @@ int nway_run (gt4hip_context *ctx, const gt4hip_list *const lists[], uint32_t k,
       lv.p.table_cols = table->n_lists;
       for (uint32_t i = 0; i < k; i++) lv.p.table_col[i] = cols[i];
     }
-    hipMemsetAsync (ctx->ctl, 0, sizeof (PairControl), st);
+    hipMemsetAsync (ctx->ctl, 0, offsetof (PairControl, error), st); /* (totals, ticket; the error word stays) */
+    hipMemsetAsync (&ctx->ctl->role, 0, sizeof (PairControl) - offsetof (PairControl, role), st);
     if (l == 0) hipEventRecord (ctx->ev[1], st);
     hipError_t e = launch_nway_mode (st, mode, grid, lv.p, part_final, dst, (u64 *) ctx->desc, ctx->ctl, sub);
     if (e != hipSuccess) {
@@ -2560,6 +2578,7 @@ int nway_run (gt4hip_context *ctx, const gt4hip_list *const lists[], uint32_t k,
       rc = gt4hip_fail (ctx, GT4HIP_EHIP, "hipEventRecord failed: %s", hipGetErrorString (e));
       break;
     }
+    if (l > 0) continue; /* (a sample level: its error word, if any, is still there behind the last launch) */
     e = hipMemcpyAsync (ctx->ctl_host, ctx->ctl, sizeof (PairControl), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize (st);
     if (e != hipSuccess) {

@@ -192,10 +192,14 @@ class DeviceShards:
         t1 = time.perf_counter()
         if self.world == 1:
             totals = [(n, total)]
-        elif self.comm is not None:
+        elif self.comm is not None and not getattr(self, "_no_c_allgather", False):
             # over RCCL through the C ABI: one all-gather on the library's stream, one synchronisation (round 5; the
             # torch.distributed form below costs a Python collective and a device-to-host copy per step)
-            totals = self.ctx.comm_allgather_totals(self.comm, self.world, n, total)
+            try:
+                totals = self.ctx.comm_allgather_totals(self.comm, self.world, n, total)
+            except Exception:  # (the same code on every rank: all of them take the other form from here on)
+                self._no_c_allgather = True
+                totals = totals_exchange(n, total)
         else:
             totals = totals_exchange(n, total)
         res = local

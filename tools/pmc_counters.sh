@@ -11,7 +11,7 @@ if not p:
     print("no counter file"); print(open(sys.argv[1] + "/c.log").read()[-2000:]); sys.exit()
 acc = collections.OrderedDict()
 for row in csv.DictReader(open(p[0])):
-    name = row["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").replace("gt4::", "").split("(")[0]
+    name = row["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").replace("gt4::", "").replace("km8::", "").replace("km32::", "").split("(")[0]
     if not (name.startswith("k_pair_merge") or name.startswith("k_nway_merge") or name.startswith("k_nway_sub")): continue
     key = (row["Dispatch_Id"], name)
     acc.setdefault(key, {}).setdefault(row["Counter_Name"], 0.0)

@@ -62,6 +62,10 @@ def pmc(sub, counter):
                 continue
             name = row["Kernel_Name"]
             short = name.replace("(anonymous namespace)::", "").replace("void ", "").replace("gt4::", "").split("(")[0]
+            if short.startswith("km32::"):  # (the N-way sources are compiled twice: 8 and 32 lists per launch)
+                short = short[len("km32::"):].replace("k_nway_", "k_nway32_", 1)
+            elif short.startswith("km8::"):
+                short = short[len("km8::"):]
             per.setdefault(short, {}).setdefault(row.get("Dispatch_Id"), 0.0)
             per[short][row.get("Dispatch_Id")] += float(row["Counter_Value"])
     out = os.path.join(dst, "%s_pmc_%s.csv" % (tag, counter.lower()))
@@ -79,7 +83,7 @@ if fetch and write:
     cand = [k for k in fetch if k.startswith("k_pair_merge") or k.startswith("k_nway") or k.startswith("k_radix")]
     if workload == "sort":
         cand = [k for k in cand if k.startswith("k_radix")]
-    if workload.startswith(("union", "table")) and any(k.startswith("k_nway_merge") for k in cand):
+    if workload.startswith(("union", "table")) and any(k.startswith(("k_nway_merge", "k_nway32_merge")) for k in cand):
         # the N-way workloads build their lists with the pair kernel (class unions): the tile kernel is what is measured
         cand = [k for k in cand if k.startswith("k_nway")] or cand
     dom = max(cand, key=lambda k: sum(fetch[k].values()))
@@ -108,7 +112,7 @@ if fetch and write:
                   "correction of MI355X_MICROARCH.md (HBM section); WRITE_SIZE as is",
         "source": ["profiles/%s/" % ROUND + os.path.basename(fpath), "profiles/%s/" % ROUND + os.path.basename(wpath)],
     }
-    if workload.startswith("union") and dom.startswith("k_nway_merge"):
+    if workload.startswith("union") and dom.startswith(("k_nway_merge", "k_nway32_merge")):
         # one launch of the dominant instantiation per union; the call's other kernels (key samples, their
         # merges, the tile partition) are counted into the per-union figure
         unions = max(1, len(fv))
