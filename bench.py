@@ -640,14 +640,51 @@ def bench_table(args, ctx, capi):
     if not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as O
-        m = min(n, args.cpu_sample // (4 * nl))
+        m = min(n, args.cpu_sample // (16 * nl))  # (the reference formats every row as text: ~1e7 rows keep the leg at ~10 s)
         last_key, _ = lists[0].get_word(m - 1)
         host = [l.download_range(0, l.lower_bound(last_key + 1)) for l in lists]
-        t0 = time.perf_counter()
-        rc, n_u, _, _ = O.union_multi(host, 0, 4, 1)
-        dt = time.perf_counter() - t0
-        res["cpu_baseline"] = {"value": sum(len(h) for h in host) / dt, "unit": "k-mers/s", "cores": 1, "host_nproc": os.cpu_count(), "kind": "port",
-                               "sample": "oracle/gt4_oracle.c union_multi walk (the loop gt4_union shares, set-operations.c:153-181) over the first %d records of every list, one thread" % m}
+        ref = os.path.join(ROOT, "oracle", "_ref", "glistquery")
+        done = False
+        if os.path.exists(ref):
+            # the REFERENCE's own multi-list dump (glistquery L1 .. LN -> dump_lists -> gt4_union, src/glistquery.c:82-106,
+            # src/set-operations.c:131-183) on the sample, its text thrown away; one row per distinct key
+            import shutil
+            import subprocess
+            import tempfile
+            from genometester4_amd.listio import write_list
+            d = tempfile.mkdtemp(prefix="gt4tab_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+            try:
+                names = []
+                for j, h in enumerate(host):
+                    write_list(os.path.join(d, "L%d.list" % j), h, k)
+                    names.append("L%d.list" % j)
+                t0 = time.perf_counter()
+                p = subprocess.run("%s %s | wc -l" % (ref, " ".join(names)), shell=True, cwd=d, capture_output=True, text=True)
+                dt = time.perf_counter() - t0
+                rows = int(p.stdout.strip() or 0)
+                rc_g, n_g, _, _ = ctx.union_multi([ctx.upload(h, k) for h in host], 0, 4, 1, True)
+                # the product's own dump (examples/setops_driver.c dump = gt4_union + the same print loop) on the same files:
+                # the SAME text, the reference's all-zero visits behind an exhausted list's last key included
+                drv = os.path.join(ROOT, "genometester4_amd", "setops_driver")
+                same_text = None
+                if os.path.exists(drv):
+                    q = subprocess.run("%s dump %s | md5sum; %s %s | md5sum" % (drv, " ".join(names), ref, " ".join(names)), shell=True, cwd=d, capture_output=True, text=True)
+                    sums = [l.split()[0] for l in q.stdout.strip().splitlines() if l.strip()]
+                    same_text = len(sums) == 2 and sums[0] == sums[1]
+                res["cpu_baseline"] = {"value": sum(len(h) for h in host) / dt, "unit": "k-mers/s", "cores": 1, "host_nproc": os.cpu_count(), "kind": "reference",
+                                       "sample": "oracle/_ref/glistquery L1 .. L%d | wc -l (dump_lists -> gt4_union; the reference formats every row as text) over the first %d records of every list, files in %s, one thread" % (nl, m, "tmpfs" if d.startswith("/dev/shm") else "the temp dir")}
+                res["verified"] = bool(p.returncode == 0 and rc_g == 0 and 0 <= rows - n_g < nl and same_text is not False)
+                res["verified_rows"] = {"reference_lines": rows, "gpu_distinct_keys": n_g, "gpu_dump_text_equals_reference": same_text,
+                                        "note": "the reference visits an exhausted list's last key once more with all-zero counts (src/set-operations.c:166-170): up to lists - 1 lines more than distinct keys"}
+                done = p.returncode == 0
+            finally:
+                shutil.rmtree(d, ignore_errors=True)
+        if not done:
+            t0 = time.perf_counter()
+            rc, n_u, _, _ = O.union_multi(host, 0, 4, 1)
+            dt = time.perf_counter() - t0
+            res["cpu_baseline"] = {"value": sum(len(h) for h in host) / dt, "unit": "k-mers/s", "cores": 1, "host_nproc": os.cpu_count(), "kind": "port",
+                                   "sample": "oracle/gt4_oracle.c union_multi walk (the loop gt4_union shares, set-operations.c:153-181) over the first %d records of every list, one thread" % m}
     return res
 
 
@@ -660,14 +697,21 @@ def bench_pair(args, ctx, capi, rank, world, torch, dist):
     op_bits = [bit for bit in (1, 2, 4) if ops & bit]
     sharded = strong and world > 1
     while True:
-        a = b = full_a = full_b = outs = None
+        a = b = full_a = full_b = outs = sh = None
         ok = True
         try:
             # strong scaling: every rank builds the SAME pair and keeps its key range of it
             a, b = build_lists(ctx, capi, n, args.k, 0 if strong else 1000 * rank, args.dist)
             if sharded:
                 from genometester4_amd import distributed as D
-                sh = D.DeviceShards(ctx, rank, world, None)
+                # (a communicator where the ranks are on devices of their own: the step's totals exchange is then ONE
+                # ncclAllGather on the library's stream, gt4hip_comm_allgather_u64)
+                comm_id = None
+                if _xdev() == "cuda":
+                    box = [capi.comm_unique_id() if rank == 0 else None]
+                    dist.broadcast_object_list(box, src=0)
+                    comm_id = box[0]
+                sh = D.DeviceShards(ctx, rank, world, comm_id)
                 full_a, full_b = a, b
                 sh.plan([full_a, full_b], sampled=args.splitters == "sampled")
                 a, b = sh.shard_of(full_a, args.k), sh.shard_of(full_b, args.k)
@@ -685,6 +729,8 @@ def bench_pair(args, ctx, capi, rank, world, torch, dist):
             n_next = int(t.item())
         if ok and n_next == n:
             break
+        if sharded and sh is not None:
+            sh.close()
         for l in (outs or {}).values():
             l.free()
         for l in (a, b, full_a, full_b):
@@ -695,6 +741,7 @@ def bench_pair(args, ctx, capi, rank, world, torch, dist):
     n_job = (full_a.n_words + full_b.n_words) if sharded else (n_a + n_b)
 
     exchange_ms = []
+    exchange_fallback = []
     job_stat = {}  # strong scaling: the job-wide header totals of the last step
 
     def step():
@@ -704,7 +751,15 @@ def bench_pair(args, ctx, capi, rank, world, torch, dist):
             # all-gathered over RCCL inside the step
             from genometester4_amd import distributed as D
             t0 = time.perf_counter()
-            job = {bit: tuple(sum(x[i] for x in D.exchange_totals(st[bit][0], st[bit][1], device=_xdev())) for i in (0, 1)) for bit in op_bits}
+            if sh.comm is not None and not exchange_fallback:
+                try:
+                    words = [w for bit in op_bits for w in st[bit]]
+                    rows = ctx.comm_allgather_u64(sh.comm, world, words)
+                    job = {bit: (sum(r[2 * i] for r in rows), sum(r[2 * i + 1] for r in rows)) for i, bit in enumerate(op_bits)}
+                except Exception:  # (the same on every rank: all take the torch.distributed form from here on)
+                    exchange_fallback.append(True)
+            if sh.comm is None or exchange_fallback:
+                job = {bit: tuple(sum(x[i] for x in D.exchange_totals(st[bit][0], st[bit][1], device=_xdev())) for i in (0, 1)) for bit in op_bits}
             exchange_ms.append((time.perf_counter() - t0) * 1e3)
             job_stat.update(job)
         return st, timing
@@ -820,6 +875,8 @@ def bench_pair(args, ctx, capi, rank, world, torch, dist):
                 res["verified"] = False
             if res["verified"] is False and res["cpu_baseline"].get("value") is not None:
                 log("VERIFICATION FAILED: %s" % res.get("verified_totals"))
+    if sharded:
+        sh.close()
     for l in list(outs.values()) + [a, b, full_a, full_b]:
         if l is not None:
             l.free()

@@ -51,7 +51,7 @@ SYMBOLS = [
     "gt4hip_union_multi", "gt4hip_intersect_multi", "gt4hip_union_table", "gt4hip_probe_table", "gt4hip_probe_table_ex", "gt4hip_table_compact", "gt4hip_table_download",
     "gt4hip_table_free", "gt4hip_generate", "gt4hip_generate_ex", "gt4hip_synchronize", "gt4hip_set_option",
     "gt4hip_get_counter", "gt4hip_device_memory", "gt4hip_list_upload_fd", "gt4hip_list_load_fd", "gt4hip_list_load",
-    "gt4hip_list_write_fd", "gt4hip_lists_write_fd", "gt4hip_shard_first_key", "gt4hip_shard_cuts", "gt4hip_comm_unique_id", "gt4hip_comm_create", "gt4hip_comm_destroy", "gt4hip_comm_allgather_totals", "gt4hip_context_device", "gt4hip_trim",
+    "gt4hip_list_write_fd", "gt4hip_lists_write_fd", "gt4hip_shard_first_key", "gt4hip_shard_cuts", "gt4hip_comm_unique_id", "gt4hip_comm_create", "gt4hip_comm_destroy", "gt4hip_comm_allgather_totals", "gt4hip_comm_allgather_u64", "gt4hip_context_device", "gt4hip_trim",
     "gt4hip_comm_rank", "gt4hip_comm_size", "gt4hip_comm_last_error", "gt4hip_comm_gatherv", "gt4hip_sort_words", "gt4hip_words_to_list",
     "gt4hip_device_words_to_list",
 ]
@@ -126,6 +126,7 @@ def lib():
             "gt4hip_comm_last_error": (C.c_char_p, []),
             "gt4hip_comm_gatherv": (C.c_int, [vp, vp, C.POINTER(u64), C.c_int, vp]),
             "gt4hip_comm_allgather_totals": (C.c_int, [vp, u64, u64, C.POINTER(u64)]),
+            "gt4hip_comm_allgather_u64": (C.c_int, [vp, C.POINTER(u64), u32, C.POINTER(u64)]),
             "gt4hip_sort_words": (C.c_int, [vp, vp, u64, u32]),
             "gt4hip_words_to_list": (C.c_int, [vp, vp, u64, u32, C.POINTER(vp)]),
             "gt4hip_device_words_to_list": (C.c_int, [vp, vp, u64, u32, C.POINTER(vp)]),
@@ -312,6 +313,14 @@ class Context:
         out = (C.c_uint64 * (2 * world))()
         self._chk(lib().gt4hip_comm_allgather_totals(comm, n_words, total_count, out))
         return [(int(out[2 * r]), int(out[2 * r + 1])) for r in range(world)]
+
+    def comm_allgather_u64(self, comm, world, words):
+        """every rank's `words` (at most eight u64) on every rank: [[words of rank 0], ...] (gt4hip_comm_allgather_u64)"""
+        n = len(words)
+        mine = (C.c_uint64 * n)(*[int(w) & 0xFFFFFFFFFFFFFFFF for w in words])
+        out = (C.c_uint64 * (n * world))()
+        self._chk(lib().gt4hip_comm_allgather_u64(comm, mine, n, out))
+        return [[int(out[n * r + i]) for i in range(n)] for r in range(world)]
 
     def comm_gatherv(self, comm, local, counts, root=0, gathered=None):
         arr = (C.c_uint64 * len(counts))(*counts)

@@ -147,28 +147,34 @@ extern "C" int gt4hip_comm_size (const gt4hip_comm *c) { return c ? c->n_ranks :
  * header totals and output offsets -- as ONE ncclAllGather of two 64-bit words per rank on the library's stream, with
  * one stream synchronisation for the whole exchange (the bench's torch.distributed form took a stream synchronisation,
  * a Python all_gather and a device-to-host copy per step: 0.2 - 0.4 ms against a 4 - 5 ms shard merge at 8 GPUs).
- * totals[2 r], totals[2 r + 1] = rank r's pair. */
-extern "C" int gt4hip_comm_allgather_totals (gt4hip_comm *c, uint64_t n_words, uint64_t total_count, uint64_t *totals)
+ * totals[2 r], totals[2 r + 1] = rank r's pair.  gt4hip_comm_allgather_u64: the same for n <= 8 words per rank (an
+ * operation with several outputs exchanges all their totals at once): all[n r + i] = word i of rank r. */
+extern "C" int gt4hip_comm_allgather_u64 (gt4hip_comm *c, const uint64_t *mine, uint32_t n, uint64_t *all)
 {
-  if (!c || !totals) return GT4HIP_EINVAL;
+  if (!c || !mine || !all || !n || n > 8) return GT4HIP_EINVAL;
   gt4hip_context *ctx = c->ctx;
   const Rccl *r = rccl ();
   if (!r) return gt4hip_fail (ctx, GT4HIP_ECOMM, "%s", g_comm_err);
   HIPCHK (ctx, hipSetDevice (ctx->device));
-  const size_t words = 2 + 2 * (size_t) c->n_ranks;
+  const size_t cap = 8 + 8 * (size_t) c->n_ranks; /* room for the widest exchange */
   if (!c->tot_dev) {
-    HIPCHK (ctx, hipMalloc ((void **) &c->tot_dev, words * 8));
-    HIPCHK (ctx, hipHostMalloc ((void **) &c->tot_host, words * 8, hipHostMallocDefault));
+    HIPCHK (ctx, hipMalloc ((void **) &c->tot_dev, cap * 8));
+    HIPCHK (ctx, hipHostMalloc ((void **) &c->tot_host, cap * 8, hipHostMallocDefault));
   }
-  c->tot_host[0] = n_words;
-  c->tot_host[1] = total_count;
-  HIPCHK (ctx, hipMemcpyAsync (c->tot_dev, c->tot_host, 16, hipMemcpyHostToDevice, ctx->stream));
-  const ncclResult_t e = r->AllGather (c->tot_dev, c->tot_dev + 2, 2, ncclUint64, c->comm, ctx->stream);
+  for (uint32_t i = 0; i < n; i++) c->tot_host[i] = mine[i];
+  HIPCHK (ctx, hipMemcpyAsync (c->tot_dev, c->tot_host, (size_t) n * 8, hipMemcpyHostToDevice, ctx->stream));
+  const ncclResult_t e = r->AllGather (c->tot_dev, c->tot_dev + 8, n, ncclUint64, c->comm, ctx->stream);
   if (e != ncclSuccess) return gt4hip_fail (ctx, GT4HIP_ECOMM, "totals all-gather: %s", r->GetErrorString (e));
-  HIPCHK (ctx, hipMemcpyAsync (c->tot_host + 2, c->tot_dev + 2, (words - 2) * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK (ctx, hipMemcpyAsync (c->tot_host + 8, c->tot_dev + 8, (size_t) n * c->n_ranks * 8, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK (ctx, hipStreamSynchronize (ctx->stream));
-  for (size_t i = 0; i < words - 2; i++) totals[i] = c->tot_host[2 + i];
+  for (size_t i = 0; i < (size_t) n * c->n_ranks; i++) all[i] = c->tot_host[8 + i];
   return GT4HIP_OK;
+}
+
+extern "C" int gt4hip_comm_allgather_totals (gt4hip_comm *c, uint64_t n_words, uint64_t total_count, uint64_t *totals)
+{
+  const uint64_t mine[2] = { n_words, total_count };
+  return gt4hip_comm_allgather_u64 (c, mine, 2, totals);
 }
 
 extern "C" int gt4hip_comm_gatherv (gt4hip_comm *c, const gt4hip_list *local, const uint64_t counts[], int root, gt4hip_list *gathered)

@@ -2346,11 +2346,10 @@ int nway_run (gt4hip_context *ctx, const gt4hip_list *const lists[], uint32_t k,
     if (e0 != hipSuccess) return gt4hip_fail (ctx, GT4HIP_EHIP, "hipEventRecord failed: %s", hipGetErrorString (e0)); /* (nothing is owned yet) */
   }
   /* option "kway" = 1 (the default) lets the call decline clustered keys: *used = 0, the caller takes the tree */
-  /* Host read-backs (round 5: nine per call of three levels -> three; each is a drained stream plus 20 - 30 us, 0.3 ms of
-   * a 4.7 ms call on an eighth of the bench's lists, i.e. of one GPU's shard at 8 GPUs).  The probe's answer is read with
-   * the first partition read-back (its sampling work is wasted where the call then declines: rare); a top level of one
-   * tile reads nothing back; the sample levels' control blocks are not read back (their error word stays set through
-   * the later launches and is seen with the last one). */
+  /* Host read-backs (round 5: nine per call of three levels -> four; each is a drained stream plus 20 - 30 us, 0.3 ms of
+   * a 4.7 ms call on an eighth of the bench's lists, i.e. of one GPU's shard at 8 GPUs).  A top level of one tile reads
+   * nothing back; the sample levels' control blocks are not read back (their error word stays set through the later
+   * launches and is seen with the last one). */
   const bool may_decline = ctx->kway_enabled == 1 && !table && ctx->kway_vt == 0;
   u32 probe_windows = 0;
   bool probe_pending = false;
@@ -2367,6 +2366,16 @@ int nway_run (gt4hip_context *ctx, const gt4hip_list *const lists[], uint32_t k,
       hipLaunchKernelGGL (k_nway_probe, dim3 (windows), dim3 (256), 0, st, (const u32 *) lists[longest]->dev, nl, windows, (u32) nway_buckets (NWAY_NBF * nway_cap (NWAY_UNION)), (u32 *) ctx->scratch + 8);
       probe_windows = windows;
       probe_pending = true;
+      /* (read at once after all: read with the first partition read-back, a call that declines had sampled, merged
+       * samples and partitioned for nothing -- 1.3 ms of a 53 ms tree on the clustered bench lists) */
+      hipError_t e2 = hipMemcpyAsync (ctx->scratch_host + 4, (char *) ctx->scratch + 32, 8, hipMemcpyDeviceToHost, st);
+      if (e2 == hipSuccess) e2 = hipStreamSynchronize (st);
+      if (e2 != hipSuccess) return gt4hip_fail (ctx, GT4HIP_EHIP, "N-way key probe failed: %s", hipGetErrorString (e2));
+      probe_pending = false;
+      if (5ull * (u32) ctx->scratch_host[4] > probe_windows) {
+        ctx->kway_declined++;
+        return GT4HIP_OK; /* *used = 0 */
+      }
     }
   }
   /* sample levels until one fits a single tile */

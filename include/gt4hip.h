@@ -273,6 +273,8 @@ const char *gt4hip_comm_last_error (void);
  * offsets): one ncclAllGather of two 64-bit words per rank on the library's stream, one synchronisation.
  * totals[2 r], totals[2 r + 1] = rank r's pair (2 * gt4hip_comm_size words). */
 int gt4hip_comm_allgather_totals (gt4hip_comm *c, uint64_t n_words, uint64_t total_count, uint64_t *totals);
+/* ... n <= 8 words per rank (the totals of every output of a pair operation at once): all[n r + i] = word i of rank r */
+int gt4hip_comm_allgather_u64 (gt4hip_comm *c, const uint64_t *mine, uint32_t n, uint64_t *all);
 
 /* counts[r] = records rank r contributes (every rank passes the same array: the all-gathered header
  * totals).  Rank r sends the first counts[r] records of `local`; on `root`, `gathered` (capacity >=

@@ -128,6 +128,22 @@ def test_projection_from_one_gpu_adds_up():
         assert sum(x["input_records"] for x in p["per_shard"]) == 8 * 400000
 
 
+def test_rccl_totals_exchange_with_a_communicator_of_one():
+    """gt4hip_comm_allgather_u64 / _totals (the step's totals exchange over RCCL, C ABI): the call itself, with the only
+    communicator a one-GPU box can make"""
+    from genometester4_amd import capi
+    ctx = capi.Context(0)
+    try:
+        comm = ctx.comm_create(capi.comm_unique_id(), 1, 0)
+        assert ctx.comm_allgather_u64(comm, 1, [1, 2, (1 << 64) - 1, 4]) == [[1, 2, (1 << 64) - 1, 4]]
+        assert ctx.comm_allgather_totals(comm, 1, 7, 1 << 40) == [(7, 1 << 40)]
+        for n in range(1, 9):
+            assert ctx.comm_allgather_u64(comm, 1, list(range(n))) == [list(range(n))]
+        capi.comm_destroy(comm)
+    finally:
+        ctx.close()
+
+
 def test_self_check_failure_exits_non_zero():
     """a line whose totals contradict the generator's closed form must not exit 0 (GT4_BENCH_BREAK_CHECK: test hook)"""
     env = dict(os.environ, GT4_BENCH_BREAK_CHECK="1")
