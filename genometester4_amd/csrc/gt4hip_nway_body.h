@@ -132,6 +132,8 @@ __device__ __forceinline__ u64 nway_boundary_key (const u32 *__restrict__ merged
 /* Two passes, as the pair kernel's partition: pass 0 searches every NWAY_COARSE-th boundary in the whole
  * lists, pass 1 the others between their coarse neighbours (the cuts are monotone in the boundary
  * key): half the dependent reads, and neighbouring threads probe the same few cache lines. */
+__device__ __forceinline__ u64 nway_bucket_consts (u64 lo, u64 hi, u32 n_buckets);
+
 constexpr u64 NWAY_COARSE = 64;
 
 __global__ void k_nway_partition (NwayParams p, const u32 *__restrict__ merged, u64 m_total, u32 G, u32 n_buckets, u64 *__restrict__ part, int pass)
@@ -287,20 +289,20 @@ __global__ __launch_bounds__ (1024) void k_nway_bracket_bases (u32 *__restrict__
 
 constexpr u32 NWAY_G_MAX = 64; /* samples per tile the bracket's LDS copy has room for */
 
-__global__ __launch_bounds__ (64) void k_nway_partition_rows (NwayParams p, const u32 *__restrict__ merged, u64 m_total, u32 G, u32 n_buckets, const u32 *__restrict__ bases,
+/* (many lists: only the samples' LIST NUMBERS are staged -- one byte each, 4 KB per bracket instead of 48 KB of whole
+ * samples, which held the kernel to three wavefronts per CU: 8.8 ms of a 48 ms union of 32 lists.  The tiles' own
+ * samples are not tested for clustering here; the tile kernel finds clustered tiles by their longest bucket.) */
+__global__ __launch_bounds__ (64, 5) void k_nway_partition_rows (NwayParams p, const u32 *__restrict__ merged, u64 m_total, u32 G, u32 n_buckets, const u32 *__restrict__ bases,
                                                            u64 *__restrict__ part)
 {
-  __shared__ u32x4 smp4[NWAY_BRACKET * NWAY_G_MAX * 3 / 4];
-  const u32 *const smp = reinterpret_cast<const u32 *> (smp4);
+  __shared__ unsigned char sid_s[NWAY_BRACKET * NWAY_G_MAX];
   const int lane = threadIdx.x;
   const u64 br = blockIdx.x;
   const u64 t = br * NWAY_BRACKET + lane;
   {
     const u64 f = br * NWAY_BRACKET * G;
     const u64 cnt = f >= m_total ? 0 : (m_total - f < (u64) NWAY_BRACKET * G ? m_total - f : (u64) NWAY_BRACKET * G);
-    const u32 quads = (u32) ((3 * cnt + 3) / 4);
-    const u32x4 *src = reinterpret_cast<const u32x4 *> (merged + 3 * f);
-    for (u32 i = lane; i < quads; i += WAVE) smp4[i] = src[i];
+    for (u32 i = lane; i < (u32) cnt; i += WAVE) sid_s[i] = (unsigned char) merged[3 * (f + i) + 2];
     __syncthreads ();
   }
   const u64 nt = p.num_tiles;
@@ -311,7 +313,7 @@ __global__ __launch_bounds__ (64) void k_nway_partition_rows (NwayParams p, cons
   const u32 x_list = has_x ? merged[3 * (t == nt - 1 ? m_total - 1 : t * (u64) G - 1) + 2] : 0xffffffffu;
   const bool tile = row && t < nt;
   const u64 first = t * (u64) G, end = !tile || first >= m_total ? first : (first + G < m_total ? first + G : m_total);
-  /* the tile's key range, bucket function, and whether its own samples look clustered (as k_nway_partition) */
+  /* the tile's key range and bucket function (as k_nway_partition) */
   if (tile) {
     u64 lo, hi;
     if (t == 0) {
@@ -334,31 +336,8 @@ __global__ __launch_bounds__ (64) void k_nway_partition_rows (NwayParams p, cons
     } else {
       hi = y;
     }
-    const u64 D = hi >= lo ? hi - lo : 0ull;
-    const u32 bl = D ? 64u - (u32) __builtin_clzll (D) : 0u;
-    const u32 sh = bl > 32u ? bl - 32u : 0u;
-    const u32 vmax = (u32) (D >> sh);
-    const bool direct = vmax < n_buckets;
-    const u32 mul = direct ? 0u : (u32) (((u64) n_buckets << 32) / ((u64) vmax + 1ull));
-    u64 bk = (u64) sh | (direct ? 1ull << 8 : (u64) mul << 32);
-    u32 prev = 0xffffffffu, same = 0, cnt = 0;
-    u64 prev_key = 0;
-    bool have_prev = false;
-    for (u64 j0 = first; j0 < end; j0++) {
-      const u32 j = (u32) (j0 - br * NWAY_BRACKET * G);
-      const u64 s = (u64) smp[3 * j] | ((u64) smp[3 * j + 1] << 32);
-      if (s < lo || s > hi || (have_prev && s == prev_key)) continue;
-      prev_key = s;
-      have_prev = true;
-      const u32 vv = (u32) ((s - lo) >> sh);
-      const u32 b = direct ? vv : __umulhi (vv, mul);
-      same += b == prev ? 1u : 0u;
-      prev = b;
-      cnt++;
-    }
-    if (t + 1 < nt && cnt >= 8 && 2 * same > cnt) bk |= 1ull << 9;
     part[t * NWAY_PSTRIDE + NWAY_MAX] = lo;
-    part[t * NWAY_PSTRIDE + NWAY_MAX + 1] = bk;
+    part[t * NWAY_PSTRIDE + NWAY_MAX + 1] = nway_bucket_consts (lo, hi, n_buckets);
   } else if (row) {
     part[t * NWAY_PSTRIDE + NWAY_MAX] = 0;
     part[t * NWAY_PSTRIDE + NWAY_MAX + 1] = 0;
@@ -369,7 +348,7 @@ __global__ __launch_bounds__ (64) void k_nway_partition_rows (NwayParams p, cons
     if (tile) {
       for (u64 j0 = first; j0 < end; j0++) {
         const u32 j = (u32) (j0 - br * NWAY_BRACKET * G);
-        const u32 sid = smp[3 * j + 2] - g0;
+        const u32 sid = (u32) sid_s[j] - g0;
         const u64 one = 1ull << (16 * (sid & 3u));
         c0 += sid < 4u ? one : 0ull;
         c1 += (sid >= 4u && sid < 8u) ? one : 0ull;
@@ -713,6 +692,49 @@ __device__ __forceinline__ u32 nway_tile_slots (const u64 *__restrict__ part, u6
 
 /* flag[0]: a tile needs more than two pieces (or the table is not monotone); flag[1]: tiles whose samples look
  * clustered; flag[2]: tiles cut in two */
+#if GT4_KM > 8
+/* (many lists: a partition row is 34 entries -- one HALF-wavefront per tile reads its two rows side by side, 256 bytes
+ * per load; a thread per tile read them 272 bytes apart: 0.63 ms per launch, 3.2 ms of a 46 ms union of 32 lists) */
+__global__ __launch_bounds__ (NWAY_SPLIT_BLOCK) void k_nway_need (const u64 *__restrict__ part, u32 num_tiles, u32 nch, u32 max_rec, u32 *__restrict__ need, u32 *__restrict__ block_sums, u32 *flag)
+{
+  static_assert (NWAY_MAX == 32 && NWAY_SPLIT_BLOCK == 1024, "a half-wavefront per tile, sixteen wavefronts per block of 1024 tiles");
+  __shared__ u32 ws[NWAY_SPLIT_BLOCK / WAVE];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, half = lane >> 5, li = lane & 31;
+  u32 vsum = 0;
+  for (int it = 0; it < 32; it++) {
+    const u64 t = (u64) blockIdx.x * NWAY_SPLIT_BLOCK + (u64) wid * 64 + (u64) (2 * it + half);
+    const bool in = t < num_tiles;
+    const u64 a = in ? part[t * NWAY_PSTRIDE + li] : 0ull, b = in ? part[(t + 1) * NWAY_PSTRIDE + li] : 0ull;
+    const bool mono = b >= a;
+    const u64 len = mono ? b - a : 0ull;
+    const u32 r = len > 0xffffffull ? 0xffffffu : (u32) len;               /* (a tile of more than 2^24 records of one list: refused anyway) */
+    const u32 sl = (r + (u32) NWAY_HS - 1u) / (u32) NWAY_HS;
+    const u32 ri = dpp_inclusive_scan_u32 (r), si = dpp_inclusive_scan_u32 (sl);
+    const u32 r0 = (u32) __builtin_amdgcn_readlane ((int) ri, 31), r1 = (u32) __builtin_amdgcn_readlane ((int) ri, 63) - r0;
+    const u32 s0 = (u32) __builtin_amdgcn_readlane ((int) si, 31), s1 = (u32) __builtin_amdgcn_readlane ((int) si, 63) - s0;
+    const u64 bad = __builtin_amdgcn_ballot_w64 (!mono);
+    const bool bad_h = half ? (bad >> 32) != 0 : (u32) bad != 0u;
+    const u32 recs = half ? r1 : r0, slots = half ? s1 : s0;
+    u32 v = 0;
+    if (in && li == 0) {
+      v = slots <= nch && recs <= max_rec ? 1u : 2u;
+      if (bad_h || slots > 2 * nch - 2 * NWAY_MAX || recs / 2 > max_rec) atomicOr (flag, 1u);
+      if ((part[t * NWAY_PSTRIDE + NWAY_MAX + 1] >> 9) & 1ull) atomicAdd (flag + 1, 1u);
+      if (v == 2u) atomicAdd (flag + 2, 1u);
+      need[t] = v;
+    }
+    vsum += v;
+  }
+  vsum = dpp_wave_sum_u32 (vsum);
+  if (lane == 0) ws[wid] = vsum;
+  __syncthreads ();
+  if (threadIdx.x == 0) {
+    u32 sum = 0;
+    for (u32 w = 0; w < NWAY_SPLIT_BLOCK / WAVE; w++) sum += ws[w];
+    block_sums[blockIdx.x] = sum;
+  }
+}
+#else
 __global__ __launch_bounds__ (NWAY_SPLIT_BLOCK) void k_nway_need (const u64 *__restrict__ part, u32 num_tiles, u32 nch, u32 max_rec, u32 *__restrict__ need, u32 *__restrict__ block_sums, u32 *flag)
 {
   __shared__ u32 ws[NWAY_SPLIT_BLOCK / WAVE];
@@ -737,6 +759,8 @@ __global__ __launch_bounds__ (NWAY_SPLIT_BLOCK) void k_nway_need (const u64 *__r
     block_sums[blockIdx.x] = sum;
   }
 }
+
+#endif /* GT4_KM > 8 */
 
 __global__ __launch_bounds__ (1024) void k_nway_need_scan (u32 *__restrict__ block_sums, u32 n_blocks, u32 *__restrict__ total)
 {
