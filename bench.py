@@ -217,7 +217,7 @@ MULTI = {
 }
 
 
-def multi_roofline(ctx, kind, n_in_local, n_out_local, device_ms, kernel_ms, one_pass, workload_n, dist="stride", moved=None):
+def multi_roofline(ctx, kind, n_in_local, n_out_local, device_ms, kernel_ms, one_pass, workload_n, dist="stride", moved=None, levels=False):
     """Rank 0's shard: algorithmic bytes (every input record read once, every output record written once).
     `frac` is over the average launch of the dominant kernel where ONE kernel does the work (the one-pass N-way
     tile kernel, HIP events on the library's stream); `whole_call_frac` over the whole call on the device (key
@@ -233,6 +233,8 @@ def multi_roofline(ctx, kind, n_in_local, n_out_local, device_ms, kernel_ms, one
                   else "k_nway_merge<1024, 4, 1, NWAY_UNION> (one pass over up to eight lists per launch)")
         if MULTI[kind]["lists"] > 8:
             kernel = "km32::k_nway_merge<1024, 4, 1, NWAY_UNION> (one pass over up to 32 lists per launch: runs end to end in the tile, samples every 64 records)"
+    elif levels:
+        kernel = "k_nway_merge<1024, 4, 1, NWAY_UNION> (levels of eight-way passes: every record goes through the tile kernel twice)"
     elif MULTI[kind]["op"] == "intersect":
         kernel = "k_pair_merge<1024, 6, MODE_LOOKBACK, intersection> (left-to-right chain, one launch per list after the first)"
     else:
@@ -421,7 +423,7 @@ def bench_multi(args, ctx, capi, rank, local_rank, world, kind="union8"):
                        "merge_only_ms_per_step": merge_only / args.steps * 1e3,
                        "gathered_bytes_per_step": 12 * (n_out - totals[0][0]) if has_comm else 0,
                        "note": "value includes the RCCL gatherv of the payload to rank 0; merge_only_* is the same job with every rank keeping (or writing) its own extent: BASELINE's >= 6x at 8 GPUs refers to merge_only"},
-            "roofline": multi_roofline(ctx, kind, n_local_in, totals[0][0], statistics.mean(dev_ms), statistics.mean(ker_ms), one_pass and n_lists <= width, n8, args.dist, moved),
+            "roofline": multi_roofline(ctx, kind, n_local_in, totals[0][0], statistics.mean(dev_ms), statistics.mean(ker_ms), one_pass and n_lists <= width, n8, args.dist, moved, levels=one_pass and n_lists > width),
             **({"cpu_baseline": cpu[0], "verified": cpu[1]} if cpu else {}),
         }
         bad = self_check(kind, args.dist, n8, args.k, n_out, total_out)

@@ -128,6 +128,18 @@ def test_projection_from_one_gpu_adds_up():
         assert sum(x["input_records"] for x in p["per_shard"]) == 8 * 400000
 
 
+def test_union32_lines_say_which_path_they_took():
+    """glistmaker's collation width: lists that share no key go through ONE pass of the 32-list tile kernel, the default
+    lists (even lists the same) through levels of eight-way merges -- the library probes; both check their totals"""
+    base = ["--workload", "union32", "--entries32", "300000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    d = _bench(1, base + ["--dist", "disjoint"])
+    assert d["self_check"] == "ok" and d["config"]["output_records"] == 32 * 300000
+    assert d["config"]["path"].startswith("one pass of the N-way tile kernel (up to 32 lists per launch")
+    s_ = _bench(1, base)
+    assert s_["self_check"] == "ok" and s_["config"]["output_records"] == 17 * 300000
+    assert s_["config"]["path"].startswith("levels of eight-way passes")
+
+
 def test_rccl_totals_exchange_with_a_communicator_of_one():
     """gt4hip_comm_allgather_u64 / _totals (the step's totals exchange over RCCL, C ABI): the call itself, with the only
     communicator a one-GPU box can make"""

@@ -100,7 +100,7 @@ if fetch and write:
         "workload": workload,
         "commit": os.environ.get("GT4_COMMIT"),
         "csrc_sha16": csrc_sha16(),  # bench.py refuses the replay when the kernel sources differ
-        "n_per_list": cfg.get("entries_per_list_per_gpu", cfg.get("entries_per_list")),
+        "n_per_list": cfg.get("entries_per_list_per_gpu", cfg.get("entries_per_list", cfg.get("words"))),
         "merge_kernels_hbm_bytes_per_step_incl_list_generation": (all_f + all_w) / steps,
         "kernel": dom,
         "hbm_bytes_per_launch": fb + wb,
