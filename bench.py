@@ -606,13 +606,17 @@ def bench_table(args, ctx, capi):
     """SURVEY 8f N3 (glistquery's multi-list dump): per-key count table of --nt-lists lists of --nt entries
     (gt4_union's callback rows, reference src/set-operations.c:131-183) by gt4hip_union_table: ONE launch of the
     N-way tile kernel (every tile writes its rows where its records start: a ragged table, gathered at download);
-    more than eight lists: the N-way union for the keys and one streaming merge per column."""
+    9 .. 32 lists: the 32-list instance of the kernel, one launch as well (round 5; --kway-max 8 restores round 4's path:
+    the N-way union for the keys and one streaming merge per column, which more than 32 lists still take)."""
     nl, n, k = args.nt_lists, args.nt, args.k
+    if args.kway_max:
+        ctx.set_option("kway_max", args.kway_max)
+    one_launch = nl <= (8 if args.kway_max == 8 else 32)
     lists = []
     for j in range(nl):
         lst = ctx.alloc(n, k)
         shared = j % 2 == 0
-        ctx.generate_ex(lst, n, 7 if shared else 100 + j, 50 + j, 8, 16, 0 if shared else 1 + j)
+        ctx.generate_ex(lst, n, 7 if shared else 100 + j, 50 + j, 8, 16 if nl < 16 else 64, 0 if shared else 1 + j)  # (residue 1 + j < modulus)
         lists.append(lst)
     wall, tab = [], []
     n_keys = 0
@@ -634,7 +638,7 @@ def bench_table(args, ctx, capi):
            "config": {"workload": "count table of %d lists x %d k=%d entries -> %d keys x %d counts" % (nl, n, k, n_keys, nl),
                       "lists": nl, "entries_per_list": n, "keys": n_keys, "device": ctx.device_info(),
                       "wall_ms_per_step": [round(w * 1e3, 2) for w in wall]},
-           "roofline": {"bound": "hbm", "kernel": "k_nway_merge<1024, 4, 1, NWAY_TABLE> (one launch)" if nl <= 8 else "k_nway_merge (the keys) + %d x (k_pair_merge union + k_extract_column)" % nl,
+           "roofline": {"bound": "hbm", "kernel": ("%s::k_nway_merge<1024, 4, 1, NWAY_TABLE> (one launch)" % ("km8" if nl <= 8 else "km32")) if one_launch else "k_nway_merge (the keys) + %d x (k_pair_merge union + k_extract_column)" % nl,
                         "achieved": alg / (t_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         "traffic": table_traffic, "traffic_source": table_traffic_source, "traffic_note": "the table launch of the tile kernel (the call's only pass over the records)",
                         "algorithmic_bytes_per_launch": alg, "kernel_ms_avg": t_ms,
@@ -899,6 +903,7 @@ def main():
     ap.add_argument("--ns", type=int, default=1_000_000_000, help="sort: words")
     ap.add_argument("--nt", type=int, default=100_000_000, help="table: entries per list")
     ap.add_argument("--nt-lists", type=int, default=6, help="table: lists")
+    ap.add_argument("--kway-max", type=int, default=0, choices=[0, 8, 32, 33], help="table: library option kway_max (8: lists beyond eight by merges, as in round 4)")
     ap.add_argument("--workload", choices=["intersect", "c2", "union8", "union32", "intersect8", "sort", "table"], default="intersect",
                     help="intersect: BASELINE configs[1] (default, the headline metric; the line also embeds a union8 record); c2: configs[2], "
                          "union + first complement with cutoff 3 on the same pair; union8: configs[3] alone, 8-way union sharded by key range "

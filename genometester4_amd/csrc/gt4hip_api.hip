@@ -1321,16 +1321,18 @@ extern "C" int gt4hip_union_table (gt4hip_context *ctx, const gt4hip_list *const
   } stamp = { ctx, t_begin };
   memset (table, 0, sizeof *table);
   table->n_lists = n_lists;
-  /* up to eight non-empty lists: ONE launch of the N-way tile kernel writes keys and counts directly, every tile's rows
-   * where its records start (a ragged table: one row slot per input RECORD, up to n_lists times the distinct keys) */
+  /* up to 32 non-empty lists (eight with option "kway_max" = 8): ONE launch of the N-way tile kernel writes keys and counts
+   * directly, every tile's rows where its records start (a ragged table: one row slot per input RECORD, up to n_lists
+   * times the distinct keys) */
+  const uint32_t table_width = ctx->kway_max == 8 ? 8u : 32u;
   if (ctx->kway_enabled) {
-    const gt4hip_list *work[8];
-    uint32_t cols[8], k = 0;
+    const gt4hip_list *work[32];
+    uint32_t cols[32], k = 0;
     bool fits = true;
     for (uint32_t j = 0; j < n_lists && fits; j++) {
       if (!lists[j]) return GT4HIP_EINVAL;
       if (!lists[j]->n_words) continue;
-      if (k == 8 || lists[j]->word_length != lists[0]->word_length) fits = false;
+      if (k == table_width || lists[j]->word_length != lists[0]->word_length) fits = false;
       else {
         work[k] = lists[j];
         cols[k++] = j;
@@ -1398,14 +1400,15 @@ extern "C" int gt4hip_probe_table_ex (gt4hip_context *ctx, const gt4hip_list *co
   table->n_keys = n;
   if (!n) return GT4HIP_OK;
   HIPCHK (ctx, hipSetDevice (ctx->device));
-  /* up to eight non-empty lists (the base first): one launch of the N-way tile kernel */
+  /* up to 32 non-empty lists (the base first; eight with option "kway_max" = 8): one launch of the N-way tile kernel */
   if (ctx->kway_enabled) {
-    const gt4hip_list *work[8];
-    uint32_t cols[8], k = 0;
+    const uint32_t table_width = ctx->kway_max == 8 ? 8u : 32u;
+    const gt4hip_list *work[32];
+    uint32_t cols[32], k = 0;
     bool fits = true;
     for (uint32_t j = 0; j < n_lists && fits; j++) {
       if (j && !lists[j]->n_words) continue;
-      if (k == 8 || lists[j]->word_length != base->word_length) fits = false;
+      if (k == table_width || lists[j]->word_length != base->word_length) fits = false;
       else {
         work[k] = lists[j];
         cols[k++] = j;

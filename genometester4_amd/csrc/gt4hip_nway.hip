@@ -91,7 +91,7 @@ int gt4hip_nway_union (gt4hip_context *ctx, const gt4hip_list *const lists[], ui
   return km8::nway_run (ctx, lists, k, rule, cutoff, ovr, filter, count_only, out, n_words, total_count, device_ms, used, NULL, NULL, false);
 }
 
-/* The count table of 2..8 non-empty lists (all their distinct keys ascending; column cols[i] = list i's
+/* The count table of 2..32 non-empty lists (all their distinct keys ascending; column cols[i] = list i's
  * count of the key, 0 where it has none) by ONE launch of the tile kernel: keys and counts written where every
  * tile's records start (a ragged table, allocated for the lists' records; GT4HIP_ENOMEM: the caller builds it by merges).  table->n_lists columns (those no list
  * is given for stay 0).  *used = 0: nothing was done, the caller builds the table by merges. */
@@ -102,8 +102,9 @@ int gt4hip_nway_table (gt4hip_context *ctx, const gt4hip_list *const lists[], ui
   uint64_t n = 0, t = 0;
   double ms = 0;
   *used = 0;
-  if (k > 8) return GT4HIP_OK; /* (count tables of more than eight lists: the caller builds them by merges) */
-  const int rc = km8::nway_run (ctx, lists, k, probe && presence ? 7 : 1, 0, 1, FILTER_RAW, true, NULL, &n, &t, &ms, used, table, cols, probe != 0);
+  if (k > 32) return GT4HIP_OK; /* (count tables of more than 32 lists: the caller builds them by merges) */
+  const int rc = k > 8 ? km32::nway_run (ctx, lists, k, probe && presence ? 7 : 1, 0, 1, FILTER_RAW, true, NULL, &n, &t, &ms, used, table, cols, probe != 0)
+                       : km8::nway_run (ctx, lists, k, probe && presence ? 7 : 1, 0, 1, FILTER_RAW, true, NULL, &n, &t, &ms, used, table, cols, probe != 0);
   if (rc || !*used) gt4hip_table_free (table);
   return rc;
 }

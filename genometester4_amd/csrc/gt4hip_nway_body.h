@@ -1170,7 +1170,6 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
   static_assert (CAP <= 32767 && NB <= 65536, "16-bit bucket counters and starts; bucket, arrival number and a flag share a dword");
   static_assert (NWAY_MAX > 8 || 2 * NWAY_PSTRIDE <= WAVE, "one lane per partition entry of a tile");
   static_assert (NWAY_PSTRIDE <= WAVE, "many lists: one lane per entry of ONE partition row");
-  static_assert (NWAY_MAX == 8 || (MODE != NWAY_TABLE && MODE != NWAY_PROBE), "count tables of more than eight lists are built by merges");
   __shared__ Shared sh;
   int tid = threadIdx.x, lane = tid & (WAVE - 1); /* (not const: see the top of the tile loop) */
   const int wid = __builtin_amdgcn_readfirstlane (tid / WAVE);
@@ -1264,7 +1263,9 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
       hm32[2 * (lane + WAVE) + 1] = t0 + i1 - c1;
     }
     u64 base = 0;
-    if (MODE == NWAY_DUPS) base = wave_sum ((u32) lane < p.k ? row.a : 0ull); /* the records in front of the tile: where a level of merged samples starts its output */
+    /* the records in front of the tile: where a level of merged samples starts its output, and a count table the tile's rows */
+    if (MODE == NWAY_DUPS || MODE == NWAY_TABLE) base = wave_sum ((u32) lane < p.k ? row.a : 0ull);
+    if (MODE == NWAY_PROBE) base = readlane_u64 (row.a, 0); /* the tile's first record of list 0 = its first row */
     const u32 rlo = (u32) row.a, rhi = (u32) (row.a >> 32);
     const u32 lo_lo = (u32) __builtin_amdgcn_readlane ((int) rlo, NWAY_MAX), lo_hi = (u32) __builtin_amdgcn_readlane ((int) rhi, NWAY_MAX);
     const u32 bk_lo = (u32) __builtin_amdgcn_readlane ((int) rlo, NWAY_MAX + 1), bk_hi = (u32) __builtin_amdgcn_readlane ((int) rhi, NWAY_MAX + 1);
@@ -1442,6 +1443,14 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
   bool pend = false;
   int it = 0;
   int tb = 0, tb1 = 1, tb2 = 2; /* tables of this tile, the next, the one after */
+  /* the list record k of this thread comes from (many lists: per lane; else the same for the whole wave slot) */
+  auto list_of = [&] (int k) -> u32 {
+#if GT4_KM > 8
+    return sh.rlist[tb][run_of (tb, (u32) (wid * RPT + k) * WAVE + (u32) lane)];
+#else
+    return uniform32 (sh.slot_run[tb][wid * RPT + k]);
+#endif
+  };
 #ifdef GT4_PROFILE_PHASES
   u64 ph[24];
   for (int i = 0; i < 24; i++) ph[i] = 0;
@@ -1921,8 +1930,12 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
         else if (MODE == NWAY_TABLE) { /* (counts go to the table, below) */ }
         else if (MODE == NWAY_PROBE) {
           /* a record of list 0 (the first run: its slots are the tile's first) leaves its index + 1 */
+          const u32 idx = (u32) (wid * RPT + k) * WAVE + (u32) lane;
+#if GT4_KM > 8
+          if (idx < sh.tab_len[tb][0]) {
+#else
           if (uniform32 (sh.slot_run[tb][wid * RPT + k]) == 0u) {
-            const u32 idx = (u32) (wid * RPT + k) * WAVE + (u32) lane;
+#endif
             sh.s.scnt[q] = idx + 1u;
             p.table_keys[out_base + idx] = key[k];
           }
@@ -1931,11 +1944,7 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
         else if (p.rule == 1u) atomicAdd (&sh.s.scnt[q], cnt[k]);
         else if (p.rule == 4u) atomicMax (&sh.s.scnt[q], cnt[k]);
         sh.s.skey[q] = key[k];
-#if GT4_KM > 8
-        reinterpret_cast<unsigned char *> (sh.live)[q] = MODE == NWAY_DUPS ? (unsigned char) (1u + sh.rlist[tb][run_of (tb, (u32) (wid * RPT + k) * WAVE + (u32) lane)]) : (unsigned char) 1;
-#else
-        reinterpret_cast<unsigned char *> (sh.live)[q] = MODE == NWAY_DUPS ? (unsigned char) (1u + uniform32 (sh.slot_run[tb][wid * RPT + k])) : (unsigned char) 1;
-#endif
+        reinterpret_cast<unsigned char *> (sh.live)[q] = MODE == NWAY_DUPS ? (unsigned char) (1u + list_of (k)) : (unsigned char) 1;
       }
     }
     PHASE_STAMP (9);
@@ -2091,7 +2100,7 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
       for (int k = 0; k < RPT; k++) {
         if (!(ba[k] >> 31)) continue;
         const u32 r = sh.s.scnt[nway_skew (pos[k])];
-        if (r) p.table_counts[(out_base + r - 1u) * p.table_cols + p.table_col[uniform32 (sh.slot_run[tb][wid * RPT + k])]] = p.rule == 7u ? p.count_override : cnt[k];
+        if (r) p.table_counts[(out_base + r - 1u) * p.table_cols + p.table_col[list_of (k)]] = p.rule == 7u ? p.count_override : cnt[k];
       }
     }
     if (MODE != NWAY_PROBE && has_pos) {
@@ -2171,7 +2180,7 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
 #pragma unroll
           for (int k = 0; k < RPT; k++) {
             if (!(ba[k] >> 31)) continue;
-            const u32 col = p.table_col[uniform32 (sh.slot_run[tb][wid * RPT + k])];
+            const u32 col = p.table_col[list_of (k)];
             const u64 row = out_base + sh.s.scnt[nway_skew (pos[k])];
             p.table_counts[row * p.table_cols + col] = cnt[k];
           }
@@ -2250,12 +2259,8 @@ hipError_t launch_nway_mode (hipStream_t s, int mode, int grid, const NwayParams
 #endif
   if (mode == NWAY_DUPS) return launch_nway<NWAY_DUPS> (s, grid, p, part, out, desc, ctl);
   if (mode == NWAY_COUNT) return launch_nway<NWAY_COUNT> (s, grid, p, part, out, desc, ctl);
-#if GT4_KM == 8
   if (mode == NWAY_TABLE) return launch_nway<NWAY_TABLE> (s, grid, p, part, out, desc, ctl);
   if (mode == NWAY_PROBE) return launch_nway<NWAY_PROBE> (s, grid, p, part, out, desc, ctl);
-#else
-  if (mode == NWAY_TABLE || mode == NWAY_PROBE) return hipErrorInvalidValue; /* (count tables of more than eight lists: by merges) */
-#endif
   return launch_nway<NWAY_UNION> (s, grid, p, part, out, desc, ctl);
 }
 
@@ -2267,12 +2272,8 @@ int nway_blocks_per_cu (int mode)
     hipError_t e;
     if (mode == NWAY_DUPS) e = hipOccupancyMaxActiveBlocksPerMultiprocessor (&n, k_nway_merge<NWAY_NT, nway_rpt (NWAY_DUPS), NWAY_NBF, NWAY_DUPS>, NWAY_NT, 0);
     else if (mode == NWAY_COUNT) e = hipOccupancyMaxActiveBlocksPerMultiprocessor (&n, k_nway_merge<NWAY_NT, nway_rpt (NWAY_COUNT), NWAY_NBF, NWAY_COUNT>, NWAY_NT, 0);
-#if GT4_KM == 8
     else if (mode == NWAY_TABLE) e = hipOccupancyMaxActiveBlocksPerMultiprocessor (&n, k_nway_merge<NWAY_NT, nway_rpt (NWAY_TABLE), NWAY_NBF, NWAY_TABLE>, NWAY_NT, 0);
     else if (mode == NWAY_PROBE) e = hipOccupancyMaxActiveBlocksPerMultiprocessor (&n, k_nway_merge<NWAY_NT, nway_rpt (NWAY_PROBE), NWAY_NBF, NWAY_PROBE>, NWAY_NT, 0);
-#else
-    else if (mode == NWAY_TABLE || mode == NWAY_PROBE) e = hipErrorInvalidValue;
-#endif
     else e = hipOccupancyMaxActiveBlocksPerMultiprocessor (&n, k_nway_merge<NWAY_NT, nway_rpt (NWAY_UNION), NWAY_NBF, NWAY_UNION>, NWAY_NT, 0);
     if (e != hipSuccess || n < 1) n = 1;
     const int by_regs = nway_waves_per_simd (NWAY_NT) * 4 / (NWAY_NT / 64);

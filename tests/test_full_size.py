@@ -262,7 +262,7 @@ def test_sort_and_fold_beyond_2_pow_32_words(ctx):
     lst.free()
 
 
-@pytest.mark.parametrize("dist", ["stride", "genomic"])
+@pytest.mark.parametrize("dist", ["stride", "genomic", "stride x 32"])
 def test_count_tables_at_bench_size(ctx, dist):
     """N3 at the size bench.py --workload table runs: six 1e8-entry k=25 lists (even lists share one key
     set).  The union table (4e8 rows x 6) and the table restricted to the keys of list 0, by the N-way tile
@@ -272,6 +272,9 @@ def test_count_tables_at_bench_size(ctx, dist):
     from genometester4_amd import capi
     import ctypes as C
     n, nl = 100_000_000, 6
+    wide = dist == "stride x 32"  # (round 5) 32 lists of 2e7: the 32-list instance of the kernel, one launch as well
+    if wide:
+        n, nl, dist = 20_000_000, 32, "stride"
     lists = []
     if dist == "genomic":  # (round 5) k-mer lists of mutated copies of one sequence: most keys in all six lists
         from genometester4_amd import synth
@@ -280,7 +283,7 @@ def test_count_tables_at_bench_size(ctx, dist):
     for j in range(nl if dist == "stride" else 0):
         lst = ctx.alloc(n, 25)
         shared = j % 2 == 0
-        ctx.generate_ex(lst, n, 7 if shared else 100 + j, 50 + j, 8, 16, 0 if shared else 1 + j)
+        ctx.generate_ex(lst, n, 7 if shared else 100 + j, 50 + j, 8, 64 if wide else 16, 0 if shared else 1 + j)
         lists.append(lst)
     rc, nw, tot, uni = ctx.union_multi(lists, 0, 4, 1)  # every key kept
     assert rc == 0
@@ -308,8 +311,10 @@ def test_count_tables_at_bench_size(ctx, dist):
         ctx.set_option("kway", kway)
         try:
             t = capi.CountTable()
+            calls = ctx.get_counter("kway_calls")
             assert capi.lib().gt4hip_union_table(ctx.h, arr, nl, C.byref(t)) == 0
             assert t.n_keys == nw
+            assert ctx.get_counter("kway_calls") == calls + kway, "one launch of the tile kernel with kway = 1, merges without"
             for first in (0, nw // 2, nw - W):
                 keys, counts = rows(t, first, W)
                 assert keys.tobytes() == uni.download_range(first, W)["key"].tobytes()

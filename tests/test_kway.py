@@ -349,7 +349,7 @@ def _check_table(ctx, lists, k=20, expect_kway=True):
     dev = [ctx.upload(x, k) for x in lists]
     before = ctx.get_counter("kway_calls")
     tk, tc = ctx.union_table(dev)
-    if expect_kway and 2 <= sum(len(x) > 0 for x in lists) <= 8:
+    if expect_kway and 2 <= sum(len(x) > 0 for x in lists) <= 32:
         assert ctx.get_counter("kway_calls") == before + 1
         assert ctx.last_table_was_ragged
         ck, cc = ctx.union_table(dev, compact=True)
@@ -372,7 +372,7 @@ def _check_table(ctx, lists, k=20, expect_kway=True):
         before = ctx.get_counter("kway_calls")
         pk, pc = ctx.union_table(dev, probe=True)
         pk2, pp = ctx.union_table(dev, probe=True, presence=True)
-        if expect_kway and 2 <= 1 + sum(len(x) > 0 for x in lists[1:]) <= 8:
+        if expect_kway and 2 <= 1 + sum(len(x) > 0 for x in lists[1:]) <= 32:
             assert ctx.get_counter("kway_calls") == before + 2
         assert pk.tobytes() == lists[0]["key"].tobytes() == pk2.tobytes()
         for j, x in enumerate(lists):
@@ -404,6 +404,20 @@ def test_count_table_by_the_tile_kernel(ctx, n_lists, universe):
     _check_table(ctx, _random_lists(rng, n_lists, universe))
 
 
+@pytest.mark.parametrize("n_lists", [9, 12, 17, 32])
+@pytest.mark.parametrize("universe", [1, 700, 40000, 1_500_000])
+def test_count_table_of_nine_to_thirty_two_lists_in_one_launch(ctx, n_lists, universe):
+    """glistquery's table over up to 32 lists (reference src/set-operations.c:131-183, :185-228): the 32-list instance of the
+    tile kernel, one launch, against numpy and against the table built by merges"""
+    rng = np.random.default_rng(131 * n_lists + universe)
+    lists = _random_lists(rng, n_lists, universe)
+    _check_table(ctx, lists, k=25)
+    if universe == 40000:  # empty members, a list twice, list 0 short
+        empty = U.make_records(np.zeros(0, dtype=np.uint64), np.zeros(0, dtype=np.uint32))
+        mixed = [lists[0][: len(lists[0]) // 7]] + [empty] + lists[1:-1] + [lists[1].copy()]
+        _check_table(ctx, mixed, k=25)
+
+
 def test_count_table_with_empty_members_identical_lists_and_more_than_eight(ctx):
     rng = np.random.default_rng(77)
     lists = _random_lists(rng, 5, 50000)
@@ -411,7 +425,13 @@ def test_count_table_with_empty_members_identical_lists_and_more_than_eight(ctx)
     _check_table(ctx, [lists[0], empty, lists[1], lists[2], empty, lists[3]])          # columns of empty lists stay 0
     _check_table(ctx, [lists[0], lists[0].copy(), lists[0].copy(), lists[1]])          # equal keys in several lists
     _check_table(ctx, [lists[0], empty], expect_kway=False)                            # one non-empty list: by merges
-    _check_table(ctx, _random_lists(rng, 11, 30000), expect_kway=False)                # more than eight: by merges
+    _check_table(ctx, _random_lists(rng, 11, 30000))                                   # more than eight: the 32-list instance of the kernel
+    ctx.set_option("kway_max", 8)
+    try:
+        _check_table(ctx, _random_lists(rng, 11, 30000), expect_kway=False)            # ... by merges when that is switched off
+    finally:
+        ctx.set_option("kway_max", 32)
+    _check_table(ctx, _random_lists(rng, 34, 9000), expect_kway=False)                 # more than 32: by merges
     # keys 0 and 2^64 - 1 (the all-ones filler of the bucket walks is a legal k = 32 key)
     edge = [U.make_records(np.array([0, 5, (1 << 64) - 1], dtype=np.uint64), np.array([3, 0, 7], dtype=np.uint32)),
             U.make_records(np.array([5, (1 << 63), (1 << 64) - 1], dtype=np.uint64), np.array([1, 2, 0], dtype=np.uint32)),
