@@ -629,7 +629,7 @@ def bench_table(args, ctx, capi):
             wall.append(time.perf_counter() - t0)
             tab.append(ctx.get_counter("table_us") / 1000.0)
     t_ms = statistics.mean(tab)
-    table_traffic, table_traffic_source = load_traffic("table", n)
+    table_traffic, table_traffic_source = load_traffic("table" if nl == 6 else "table%d" % nl, n)
     alg = 12 * nl * n + (8 + 4 * nl) * n_keys
     res = {"metric": "k-mers tabulated/sec (glistquery multi-list dump: per-key counts of %d lists), lists resident in HBM" % nl,
            "value": nl * n / statistics.mean(wall), "unit": "k-mers/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,

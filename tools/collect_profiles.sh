@@ -23,6 +23,7 @@ for SPEC in $WORKLOADS; do
   mkdir -p "$OUT"
   if [ "$W" = "intersect" ] && [ "$D" = "stride" ]; then BENCH="python3 $ROOT/bench.py"; PMCX="--no-union8"; else BENCH="python3 $ROOT/bench.py --workload $W --dist $D"; PMCX=""; fi
   if [ "$W" = "intersect" ] && [ "$D" != "stride" ]; then BENCH="$BENCH --no-union8"; fi
+  if [ "$W" = "table32" ]; then BENCH="python3 $ROOT/bench.py --workload table --nt-lists 32 --nt 20000000"; fi # (the count table of 32 lists: km32, one launch)
   cd "$ROOT"
   timeout 900 $BENCH --steps 10 --warmup 3 > "$OUT/bench.json" 2> "$OUT/bench.err"
   cd /tmp
