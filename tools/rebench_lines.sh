@@ -11,6 +11,7 @@ run union32_disjoint --workload union32 --dist disjoint
 run intersect8 --workload intersect8
 run sort --workload sort
 run table --workload table
+run table32 --workload table --nt-lists 32 --nt 20000000
 python3 - <<'PY'
 import json,glob
 for f in sorted(glob.glob("gpurun_out/r5final2/*.json")):

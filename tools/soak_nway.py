@@ -1,6 +1,8 @@
 """Randomised parity soak of the N-way tile kernel (union, count-only, count tables) against the CPU oracle
 (GPU box; not part of the test-suite).   python tools/soak_nway.py [seconds] [seed]
-Shapes the fixed-seed tests of tests/test_kway.py do not enumerate: 3 - 8 lists of very different lengths, uniform /
+Shapes the fixed-seed tests of tests/test_kway.py do not enumerate: 3 - 32 lists (round 5: more than eight through the
+32-list instance of the kernel in ONE pass, option kway_max = 33) of very different lengths, their count tables (all keys;
+the keys of list 0, counts and membership) against numpy, uniform /
 clustered / heavily shared keys, zero counts and counts near 2^32, every rule and cutoff, the tile kernel forced
 (option kway = 3), every fallback forced now and then (kway_vt 98 / 99), fuller tiles (kway_g)."""
 import os, sys, time
@@ -16,9 +18,10 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
 ctx = capi.Context(0)
 ctx.set_option("kway", 3)
-t0 = time.time(); n_cases = 0
+t0 = time.time(); n_cases = 0; n_tables = 0
 while time.time() - t0 < budget:
-    n_lists = int(rng.integers(3, 9))
+    n_lists = int(rng.integers(3, 9)) if rng.random() < 0.5 else int(rng.integers(9, 33))
+    ctx.set_option("kway_max", 33 if rng.random() < 0.8 else 32)  # (33: one pass whatever the keys; 32: the library probes and may take levels)
     universe = int(rng.choice([40, 5000, 70000, 400000, 1500000]))
     shape = str(rng.choice(["uniform", "clustered", "shared"]))
     if shape == "clustered":
@@ -47,10 +50,34 @@ while time.time() - t0 < budget:
         rc_c, n_c, t_c, _ = ctx.union_multi(dev, cutoff, rule, ovr, True)
         assert (n_c, t_c) == (n_o, t_o), ("count only", tag)
         out.free()
+    if sum(len(x) for x in lists) <= 3_000_000:  # the count tables (one launch up to 32 lists)
+        uni = np.unique(np.concatenate([x["key"] for x in lists]))
+        tk, tc = ctx.union_table(dev)
+        assert tk.tobytes() == uni.tobytes(), ("table keys", tag)
+        for j, x in enumerate(lists):
+            col = np.zeros(len(uni), dtype=np.uint32)
+            col[np.searchsorted(uni, x["key"])] = x["count"]
+            assert tc[:, j].tobytes() == col.tobytes(), ("table column", j, tag)
+        if len(lists[0]):
+            pk, pc = ctx.union_table(dev, probe=True)
+            _, pp = ctx.union_table(dev, probe=True, presence=True)
+            assert pk.tobytes() == lists[0]["key"].tobytes(), ("probe keys", tag)
+            for j, x in enumerate(lists):
+                if len(x):
+                    idx = np.searchsorted(x["key"], lists[0]["key"])
+                    idx[idx == len(x)] = 0
+                    hit = x["key"][idx] == lists[0]["key"]
+                    cnt = np.where(hit, x["count"][idx], 0).astype(np.uint32)
+                else:
+                    hit = np.zeros(len(lists[0]), dtype=bool)
+                    cnt = np.zeros(len(lists[0]), dtype=np.uint32)
+                assert pc[:, j].tobytes() == cnt.tobytes(), ("probe column", j, tag)
+                assert pp[:, j].tobytes() == hit.astype(np.uint32).tobytes(), ("membership column", j, tag)
+        n_tables += 1
     for d in dev:
         d.free()
     n_cases += 1
-ctx.set_option("kway_vt", 0); ctx.set_option("kway_g", 0)
-print("soak_nway: %d cases in %.0f s, seed %d: all equal to the oracle (kway_calls %d, splits %d, overflows %d)" % (
-    n_cases, time.time() - t0, seed, ctx.get_counter("kway_calls"), ctx.get_counter("kway_splits"), ctx.get_counter("kway_overflows")))
+ctx.set_option("kway_vt", 0); ctx.set_option("kway_g", 0); ctx.set_option("kway_max", 32)
+print("soak_nway: %d cases (%d with their three count tables) in %.0f s, seed %d: all equal to the oracle (kway_calls %d, splits %d, overflows %d)" % (
+    n_cases, n_tables, time.time() - t0, seed, ctx.get_counter("kway_calls"), ctx.get_counter("kway_splits"), ctx.get_counter("kway_overflows")))
 ctx.close()
