@@ -1024,7 +1024,11 @@ struct NwayShared {
   alignas (16) u32 live[LEAD ? 4 : (CAPS + 3) / 4]; /* one byte per position: a key was stored there */
   alignas (16) u32 lead[2][LEAD ? LW : 4]; /* LEAD: the positions that have a (kept) leader, tiles alternating */
   alignas (16) unsigned short wpre[LEAD && nway_staged (MODE) ? NT / WAVE : 1][LEAD && nway_staged (MODE) ? LW : 4]; /* LEAD: kept leaders in front of every bitmap word, per wavefront */
-  alignas (16) u32 stage[nway_staged (MODE) ? 3 * CAP + 4 + 3 * WAVE + 8 : 4]; /* the kept records, packed, written out during the NEXT tile (+ a trash row) */
+  /* the kept records, packed, written out during the NEXT tile (+ a trash row); the count tables: ROWW words of the
+   * tile's rows at a time (see table_rows) */
+  static constexpr int ROWW = 12288;
+  static constexpr int ROW_COLS_MAX = 384;  /* wider tables: rows straight to global memory, as before round 5 */
+  alignas (16) u32 stage[nway_staged (MODE) ? 3 * CAP + 4 + 3 * WAVE + 8 : ((MODE == NWAY_TABLE || MODE == NWAY_PROBE) ? ROWW + 4 : 4)];
   alignas (16) u32 wtot[NW], wmax[NW], wkept[NW];
   /* the tiles of this iteration, the next one (being fetched) and the one after (being described),
    * three deep: one 64-record wave slot per wave-instruction */
@@ -1450,6 +1454,31 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
 #else
     return uniform32 (sh.slot_run[tb][wid * RPT + k]);
 #endif
+  };
+  /* The count tables' rows leave through LDS (round 5): as many of the tile's rows as fit ROWW words are zeroed there, the
+   * records drop their counts in, and the rows go out whole, 16 bytes per lane -- instead of zeros stored to global memory
+   * and 4-byte stores scattered over them (32 columns: 67 GB written for 46 GB of table, half the rows went to HBM twice).
+   * row[k]: the tile's row record k belongs in (anything >= n_rows: none). */
+  auto table_rows = [&] (const u32 (&row)[RPT], const u32 (&val)[RPT], u32 n_rows, u64 first_row) {
+    const u32 cols = p.table_cols;
+    const u32 rb = (u32) Shared::ROWW / cols;
+    u32 col[RPT];
+#pragma unroll
+    for (int k = 0; k < RPT; k++) col[k] = p.table_col[list_of (k)];
+    for (u32 r0 = 0; r0 < n_rows; r0 += rb) {
+      const u32 nr = n_rows - r0 < rb ? n_rows - r0 : rb, words = nr * cols;
+      for (u32 c = 4u * (u32) tid; c < words; c += 4u * NT) *reinterpret_cast<u32x4 *> (&sh.stage[c]) = u32x4 { 0, 0, 0, 0 };
+      __syncthreads ();
+#pragma unroll
+      for (int k = 0; k < RPT; k++) {
+        const u32 rr = row[k] - r0;
+        if (rr < nr) sh.stage[rr * cols + col[k]] = val[k];
+      }
+      __syncthreads ();
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc ((void *) (p.table_counts + (first_row + r0) * cols), 0, (int) (4 * words), 0x00020000);
+      for (u32 c = (u32) tid; 4u * c < words; c += NT) __builtin_amdgcn_raw_buffer_store_b128 (*reinterpret_cast<const u32x4 *> (&sh.stage[4u * c]), rs, 16 * c, 0, 0);
+      if (r0 + rb < n_rows) __syncthreads (); /* (the next rows are zeroed where these lie) */
+    }
   };
 #ifdef GT4_PROFILE_PHASES
   u64 ph[24];
@@ -2094,8 +2123,17 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
       ocnt[i] = 0;
       kpre[i] = 0;
     }
-    if (MODE == NWAY_PROBE && has_rec) {
-      /* (behind B5: every record of list 0 has left its index) */
+    if (MODE == NWAY_PROBE && p.table_cols <= (u32) Shared::ROW_COLS_MAX) {
+      /* (behind B5: every record of list 0 has left its index + 1 where its key's records look) */
+      u32 row[RPT], val[RPT];
+#pragma unroll
+      for (int k = 0; k < RPT; k++) {
+        row[k] = has_rec && (ba[k] >> 31) ? sh.s.scnt[nway_skew (pos[k])] - 1u : 0xffffffffu; /* (0: list 0 does not hold the key) */
+        val[k] = p.rule == 7u ? p.count_override : cnt[k];
+      }
+      table_rows (row, val, uniform32 (sh.tab_len[tb][0]), out_base);
+    } else if (MODE == NWAY_PROBE && has_rec) {
+      /* (wide tables: the host has zeroed the table) */
 #pragma unroll
       for (int k = 0; k < RPT; k++) {
         if (!(ba[k] >> 31)) continue;
@@ -2150,12 +2188,11 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
         }
       }
       if (MODE == NWAY_TABLE) {
-        /* The tile's rows of the count matrix start as zeros: written here, 16 bytes per lane, instead of by a
-         * memset of the whole matrix in front of the launch (9.6 GB for the bench's table, a fifth of the call's
-         * traffic: most of it was overwritten again a moment later).  The records' own stores follow behind a
-         * wait for these and the barrier below, so they land on the zeros -- in this XCD's L2, where the two meet
-         * before the lines go to HBM. */
-        {
+        const bool via_lds = p.table_cols <= (u32) Shared::ROW_COLS_MAX; /* uniform */
+        /* Wide tables only: the tile's rows of the count matrix start as zeros, written here, 16 bytes per lane (round 4:
+         * instead of a memset of the whole matrix in front of the launch); the records' own stores follow behind a wait
+         * for these and the barrier below, so they land on the zeros. */
+        if (!via_lds) {
           const u64 words = (u64) tile_total * p.table_cols;
           const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc ((void *) (p.table_counts + out_base * p.table_cols), 0, (int) (4 * words), 0x00020000);
           for (u32 c = (u32) tid; 4ull * c < words; c += NT) __builtin_amdgcn_raw_buffer_store_b128 (u32x4 { 0, 0, 0, 0 }, zr, 16 * c, 0, 0);
@@ -2176,7 +2213,12 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
           }
         }
         __syncthreads ();
-        if (has_rec) {
+        if (via_lds) {
+          u32 row[RPT];
+#pragma unroll
+          for (int k = 0; k < RPT; k++) row[k] = has_rec && (ba[k] >> 31) ? sh.s.scnt[nway_skew (pos[k])] : 0xffffffffu;
+          table_rows (row, cnt, tile_total, out_base);
+        } else if (has_rec) {
 #pragma unroll
           for (int k = 0; k < RPT; k++) {
             if (!(ba[k] >> 31)) continue;
@@ -2579,7 +2621,9 @@ int nway_run (gt4hip_context *ctx, const gt4hip_list *const lists[], uint32_t k,
     if (l == 0 && table && probe) { /* rows = the records of list 0: the table exists before the launch */
       if ((rc = gt4hip_table_alloc (ctx, table, lists[0]->n_words, table->n_lists))) break;
       table->n_keys = lists[0]->n_words;
-      hipMemsetAsync (table->device_counts, 0, (size_t) table->n_keys * table->n_lists * 4, st);
+      /* (up to ROW_COLS_MAX columns every row leaves the kernel whole, zeros included: no memset -- round 5) */
+      if (table->n_lists > (uint32_t) NwayShared<NWAY_NT, nway_rpt (NWAY_PROBE), NWAY_NBF, NWAY_PROBE>::ROW_COLS_MAX)
+        hipMemsetAsync (table->device_counts, 0, (size_t) table->n_keys * table->n_lists * 4, st);
       lv.p.table_keys = (u64 *) table->device_keys;
       lv.p.table_counts = (u32 *) table->device_counts;
       lv.p.table_cols = table->n_lists;
