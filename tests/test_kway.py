@@ -432,6 +432,10 @@ def test_count_table_with_empty_members_identical_lists_and_more_than_eight(ctx)
     finally:
         ctx.set_option("kway_max", 32)
     _check_table(ctx, _random_lists(rng, 34, 9000), expect_kway=False)                 # more than 32: by merges
+    # 390 columns, three of them with a list: wider than a batch of rows in LDS is worth (384): rows zeroed in global
+    # memory and written by scattered stores, as before round 5 (the probe tables: zeroed by the host)
+    _check_table(ctx, [lists[0]] + [empty] * 200 + [lists[1]] + [empty] * 187 + [lists[2]])
+    _check_table(ctx, [lists[0]] + [empty] * 381 + [lists[1], lists[2]])              # 384 columns: the last width through LDS
     # keys 0 and 2^64 - 1 (the all-ones filler of the bucket walks is a legal k = 32 key)
     edge = [U.make_records(np.array([0, 5, (1 << 64) - 1], dtype=np.uint64), np.array([3, 0, 7], dtype=np.uint32)),
             U.make_records(np.array([5, (1 << 63), (1 << 64) - 1], dtype=np.uint64), np.array([1, 2, 0], dtype=np.uint32)),
