@@ -453,10 +453,17 @@ def test_count_table_of_clustered_keys(ctx):
         m = rng.random(len(keys)) < 0.5
         lists.append(U.make_records(keys[m], rng.integers(1, 9, size=int(m.sum()), dtype=np.uint32)))
     _check_table(ctx, lists, k=32)
+    # twelve lists of the same clustered keys: the 32-list instance of the kernel (round 5)
+    wide = []
+    for j in range(12):
+        m = rng.random(len(keys)) < 0.3
+        wide.append(U.make_records(keys[m], rng.integers(1, 9, size=int(m.sum()), dtype=np.uint32)))
+    _check_table(ctx, wide, k=32)
     for vt in (98, 99):
         ctx.set_option("kway_vt", vt)
         try:
             _check_table(ctx, lists[:4], k=32)
+            _check_table(ctx, wide[:10], k=32)
         finally:
             ctx.set_option("kway_vt", 0)
 
