@@ -1437,6 +1437,8 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
     if (tid < Shared::GSZ / 2 - Shared::GSZ / 2 / NT * NT) *reinterpret_cast<u32x4 *> (&sh.g ()[2 * (Shared::GSZ / 2 / NT * NT + tid)]) = u32x4 { ~0u, ~0u, ~0u, ~0u };
   };
   if (GT4_NWAY_FILL) fill_g ();
+  if (MODE == NWAY_TABLE || MODE == NWAY_PROBE) /* the row area of the count tables starts as zeros (see table_rows) */
+    for (int c = 4 * tid; c < Shared::ROWW + 4; c += 4 * NT) *reinterpret_cast<u32x4 *> (&sh.stage[c]) = u32x4 { 0, 0, 0, 0 };
   __syncthreads ();
   if (uniform32 (sh.hdr[0][0]) < ntl && (u32) (wid * RPT) < uniform32 (sh.hdr[0][2])) fetch (0);
 
@@ -1465,10 +1467,10 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
     u32 col[RPT];
 #pragma unroll
     for (int k = 0; k < RPT; k++) col[k] = p.table_col[list_of (k)];
+    /* (the row area is all zeros here: zeroed once in front of the first tile, and every thread zeroes the 16 bytes it has
+     * just sent out -- no zeroing pass and no barrier in front of the records' stores) */
     for (u32 r0 = 0; r0 < n_rows; r0 += rb) {
       const u32 nr = n_rows - r0 < rb ? n_rows - r0 : rb, words = nr * cols;
-      for (u32 c = 4u * (u32) tid; c < words; c += 4u * NT) *reinterpret_cast<u32x4 *> (&sh.stage[c]) = u32x4 { 0, 0, 0, 0 };
-      __syncthreads ();
 #pragma unroll
       for (int k = 0; k < RPT; k++) {
         const u32 rr = row[k] - r0;
@@ -1476,8 +1478,12 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
       }
       __syncthreads ();
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc ((void *) (p.table_counts + (first_row + r0) * cols), 0, (int) (4 * words), 0x00020000);
-      for (u32 c = (u32) tid; 4u * c < words; c += NT) __builtin_amdgcn_raw_buffer_store_b128 (*reinterpret_cast<const u32x4 *> (&sh.stage[4u * c]), rs, 16 * c, 0, 0);
-      if (r0 + rb < n_rows) __syncthreads (); /* (the next rows are zeroed where these lie) */
+      for (u32 c = (u32) tid; 4u * c < words; c += NT) {
+        u32x4 *const q = reinterpret_cast<u32x4 *> (&sh.stage[4u * c]);
+        __builtin_amdgcn_raw_buffer_store_b128 (*q, rs, 16 * c, 0, 0);
+        *q = u32x4 { 0, 0, 0, 0 };
+      }
+      if (r0 + rb < n_rows) __syncthreads (); /* (the next rows' counts go where these lay) */
     }
   };
 #ifdef GT4_PROFILE_PHASES
@@ -2217,17 +2223,19 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
           u32 row[RPT];
 #pragma unroll
           for (int k = 0; k < RPT; k++) row[k] = has_rec && (ba[k] >> 31) ? sh.s.scnt[nway_skew (pos[k])] : 0xffffffffu;
-          table_rows (row, cnt, tile_total, out_base);
-        } else if (has_rec) {
+          table_rows (row, cnt, tile_total, out_base); /* (its barrier stands behind every thread's look at its rows) */
+        } else {
+          if (has_rec) {
 #pragma unroll
-          for (int k = 0; k < RPT; k++) {
-            if (!(ba[k] >> 31)) continue;
-            const u32 col = p.table_col[list_of (k)];
-            const u64 row = out_base + sh.s.scnt[nway_skew (pos[k])];
-            p.table_counts[row * p.table_cols + col] = cnt[k];
+            for (int k = 0; k < RPT; k++) {
+              if (!(ba[k] >> 31)) continue;
+              const u32 col = p.table_col[list_of (k)];
+              const u64 row = out_base + sh.s.scnt[nway_skew (pos[k])];
+              p.table_counts[row * p.table_cols + col] = cnt[k];
+            }
           }
+          __syncthreads (); /* (the rows lie where the next tile's counts are zeroed) */
         }
-        __syncthreads (); /* (the rows lie where the next tile's counts are zeroed) */
       }
     }
     } /* (!LEAD) */
