@@ -946,6 +946,9 @@ __global__ __launch_bounds__ (1024) void k_nway_tile_bases (const u32 *__restric
 #ifndef GT4_NWAY_SVPRIO
 #define GT4_NWAY_SVPRIO 3
 #endif
+#ifndef GT4_NWAY_ROWW
+#define GT4_NWAY_ROWW 14336 /* words of the count tables' row area in LDS (56 KB: 159 of 160 KB with it; 12288: 1 - 2 % slower, 10240: 2 - 3 %) */
+#endif
 /* Round 4: the per-tile work that does not depend on the number of records is 58 % of a tile (time per tile against
  * samples per tile: 14.1 ns + 0.42 ns x G on 256 CUs, profiles/round4/r4_nway_experiments.log), part of it
  * instructions every one of the sixteen wavefronts executes.  Three cuts, each A/B-measured (31.4 -> 30.1 ms together;
@@ -1026,7 +1029,7 @@ struct NwayShared {
   alignas (16) unsigned short wpre[LEAD && nway_staged (MODE) ? NT / WAVE : 1][LEAD && nway_staged (MODE) ? LW : 4]; /* LEAD: kept leaders in front of every bitmap word, per wavefront */
   /* the kept records, packed, written out during the NEXT tile (+ a trash row); the count tables: ROWW words of the
    * tile's rows at a time (see table_rows) */
-  static constexpr int ROWW = 12288;
+  static constexpr int ROWW = GT4_NWAY_ROWW;
   static constexpr int ROW_COLS_MAX = 384;  /* wider tables: rows straight to global memory, as before round 5 */
   alignas (16) u32 stage[nway_staged (MODE) ? 3 * CAP + 4 + 3 * WAVE + 8 : ((MODE == NWAY_TABLE || MODE == NWAY_PROBE) ? ROWW + 4 : 4)];
   alignas (16) u32 wtot[NW], wmax[NW], wkept[NW];
