@@ -207,7 +207,7 @@ int gt4hip_intersect_multi (gt4hip_context *ctx, const gt4hip_list *const lists[
 /* Per-key count table of an N-way union: for every distinct key ascending, counts[j] = count in
  * list j or 0 (what gt4_union hands to its callback, src/set-operations.c:161-179).  Up to 32 non-empty lists:
  * one launch of the N-way tile kernel (a ragged table, see below; nine and more lists: its 32-list instance -- 32 lists of
- * 2e7 entries, 3.4e8 rows: 15 ms against 540 ms by merges, profiles/round5); more than 32, option "kway_max" = 8 beyond
+ * 2e7 entries, 3.4e8 rows: 13.6 ms against 540 ms by merges, profiles/round5); more than 32, option "kway_max" = 8 beyond
  * eight, or a ragged table that does not fit the device: by merges -- the N-way union gives the keys, and each column is
  * one more streaming merge of the key list with list j (rule SECOND keeps list j's count, absent keys get 0).
  * keys_out: n_keys u64; counts_out: n_keys * n_lists u32, row-major.  Both are device buffers
