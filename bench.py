@@ -171,13 +171,13 @@ def cpu_baseline(ctx, capi, a, b, k, sample_records, ops, cutoff):
 
 
 def csrc_sha16():
-    """What the replayed PMC traffic is tied to: a hash over the device sources (csrc/*.hip, *.h) as they lie in
+    """What the replayed PMC traffic is tied to: a hash over the device sources and their build flags (csrc/*.hip, *.h, Makefile) as they lie in
     the tree -- the GPU box has no .git.  tools/summarize_profiles.py records the same value with the passes."""
     import glob
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "genometester4_amd", "csrc")
-    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h"))):
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h")) + glob.glob(os.path.join(d, "Makefile"))):
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
     return h.hexdigest()[:16]

@@ -7,7 +7,8 @@ NAME=$1; shift
 SRC=gt4hip_kernels.hip
 if [ "$1" = "-f" ]; then SRC=$2; shift; shift; fi
 cd "$(dirname "$0")/../genometester4_amd/csrc"
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-value -mllvm -amdgpu-atomic-optimizer-strategy=None "$@" -c $SRC -o /tmp/${SRC%.hip}.$NAME.o
+SCHED=""; if [ "$SRC" = "gt4hip_kernels.hip" ]; then SCHED="-mllvm -amdgpu-sched-strategy=iterative-ilp"; fi  # (= the Makefile's KERNELS_SCHED)
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-value -mllvm -amdgpu-atomic-optimizer-strategy=None $SCHED "$@" -c $SRC -o /tmp/${SRC%.hip}.$NAME.o
 OBJS=""
 for f in gt4hip_kernels gt4hip_nway gt4hip_sort gt4hip_api gt4hip_io gt4hip_comm; do
   if [ "$f.hip" = "$SRC" ]; then OBJS="$OBJS /tmp/$f.$NAME.o"; else OBJS="$OBJS $f.hip.o"; fi

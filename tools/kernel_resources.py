@@ -13,8 +13,12 @@ CSRC = os.path.join(ROOT, "genometester4_amd", "csrc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]  # = csrc/Makefile's HIPFLAGS
 
 
+PER_SOURCE = {"gt4hip_kernels.hip": ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]}  # = csrc/Makefile's KERNELS_SCHED
+
+
 def table(source="gt4hip_kernels.hip", extra=()):
     """[{name, vgpr, sgpr, vspill, sspill, scratch, lds, occ}] for every kernel of csrc/<source>"""
+    extra = list(PER_SOURCE.get(source, [])) + list(extra)
     r = subprocess.run(["hipcc"] + FLAGS + list(extra) + ["-Rpass-analysis=kernel-resource-usage", "--cuda-device-only", "-c", os.path.join(CSRC, source), "-o", "/dev/null"],
                        capture_output=True, text=True, cwd=CSRC)
     blocks = re.split(r"remark: Function Name: ", r.stderr)[1:]

@@ -21,7 +21,7 @@ def csrc_sha16():
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "genometester4_amd", "csrc")
-    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h"))):
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h")) + glob.glob(os.path.join(d, "Makefile"))):
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
