@@ -7,7 +7,9 @@ NAME=$1; shift
 SRC=gt4hip_kernels.hip
 if [ "$1" = "-f" ]; then SRC=$2; shift; shift; fi
 cd "$(dirname "$0")/../genometester4_amd/csrc"
-SCHED=""; if [ "$SRC" = "gt4hip_kernels.hip" ]; then SCHED="-mllvm -amdgpu-sched-strategy=iterative-ilp"; fi  # (= the Makefile's KERNELS_SCHED)
+SCHED=""; if [ "$SRC" = "gt4hip_kernels.hip" ]; then SCHED="-mllvm -amdgpu-sched-strategy=iterative-ilp"; fi
+if [ "$SRC" = "gt4hip_nway.hip" ]; then SCHED="-mllvm -amdgpu-sched-strategy=iterative-maxocc"; fi  # (= the Makefile's KERNELS_SCHED / NWAY_SCHED; GT4_NO_SCHED=1: neither)
+if [ -n "$GT4_NO_SCHED" ]; then SCHED=""; fi
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-value -mllvm -amdgpu-atomic-optimizer-strategy=None $SCHED "$@" -c $SRC -o /tmp/${SRC%.hip}.$NAME.o
 OBJS=""
 for f in gt4hip_kernels gt4hip_nway gt4hip_sort gt4hip_api gt4hip_io gt4hip_comm; do

@@ -13,7 +13,8 @@ CSRC = os.path.join(ROOT, "genometester4_amd", "csrc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]  # = csrc/Makefile's HIPFLAGS
 
 
-PER_SOURCE = {"gt4hip_kernels.hip": ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]}  # = csrc/Makefile's KERNELS_SCHED
+PER_SOURCE = {"gt4hip_kernels.hip": ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"],      # = csrc/Makefile's KERNELS_SCHED
+              "gt4hip_nway.hip": ["-mllvm", "-amdgpu-sched-strategy=iterative-maxocc"]}      # ... NWAY_SCHED
 
 
 def table(source="gt4hip_kernels.hip", extra=()):
