@@ -387,6 +387,17 @@ __device__ __forceinline__ u64 resolve_offset (u32 *agg, u64 *carry, u64 tile, i
   return (c & ~CARRY_READY) + back + dpp_wave_sum_u32 (mine ? (a & ~AGG_READY) : 0u);
 }
 
+/* Cache-policy bits of the merge kernels' streaming buffer loads and stores (1 sc0, 2 nt, 16 sc1): every record is
+ * read once and written once, and says so -- NON-TEMPORAL both ways.  Measured (profiles/round5/r5_cache_policy.log,
+ * three alternating runs each): the headline intersection 10.93 -> 10.81 ms per launch, the 8-way union 28.23 -> 27.85,
+ * config 2 23.34 -> 23.18; sc1 (write-through, line dropped from L2) stores cost config 2 10 %. */
+#ifndef GT4_STORE_AUX
+#define GT4_STORE_AUX 2
+#endif
+#ifndef GT4_LOAD_AUX
+#define GT4_LOAD_AUX 2
+#endif
+
 /* Tile write-out: `tot` packed records from an LDS staging slot (16-byte aligned) to the output
  * list at record offset `excl`, as 16-byte buffer stores (dword alignment suffices; the
  * range-checked descriptor drops the dwords past the last record of the partial last chunk). */
@@ -397,7 +408,7 @@ __device__ __forceinline__ void write_out_tile (u32 *out_rec, u64 excl, u32 tot,
   const u32 chunks = (3 * tot + 3) >> 2;
   for (u32 c = (u32) tid; c < chunks; c += NT) {
     const u32x4 w = *reinterpret_cast<const u32x4 *> (slot + 4 * c);
-    __builtin_amdgcn_raw_buffer_store_b128 (w, r, 16 * c, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128 (w, r, 16 * c, 0, GT4_STORE_AUX);
   }
 }
 
@@ -417,7 +428,7 @@ __device__ __forceinline__ void write_out_fixed (u32 *out_rec, u64 excl_bytes, u
     const u32 c = (u32) k * NT + (u32) tid;
     const u32 cr = c < chunks ? c : chunks - 1u;
     const u32x4 w = *reinterpret_cast<const u32x4 *> (slot + 4 * cr);
-    __builtin_amdgcn_raw_buffer_store_b128 (w, r, 16 * c, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128 (w, r, 16 * c, 0, GT4_STORE_AUX);
   }
 }
 

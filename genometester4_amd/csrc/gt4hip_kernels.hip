@@ -613,8 +613,8 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
       const u32 q0 = (u32) jj * NT + (u32) wid * WAVE; /* first chunk of this wavefront */
       const u32 q = q0 + (u32) lane;
       /* all-A and straddling wavefronts read the A range (lanes past it get zeros), all-B ones the B range */
-      if (q0 < cA) pre[jj] = __builtin_amdgcn_raw_buffer_load_b128 (ra, 16 * q, 0, 0);
-      else pre[jj] = __builtin_amdgcn_raw_buffer_load_b128 (rb, 16 * (q - cA), 0, 0);
+      if (q0 < cA) pre[jj] = __builtin_amdgcn_raw_buffer_load_b128 (ra, 16 * q, 0, GT4_LOAD_AUX);
+      else pre[jj] = __builtin_amdgcn_raw_buffer_load_b128 (rb, 16 * (q - cA), 0, GT4_LOAD_AUX);
     }
     if (j == NLOAD4) {
       /* the one wave-instruction per tile that straddles the two ranges also needs its B half; the

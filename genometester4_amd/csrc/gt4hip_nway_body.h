@@ -1406,7 +1406,7 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
       const u64 addr = uniform64 (sh.slot_addr[tb][chunk]);
       const u32 c = uniform32 (sh.slot_cnt[tb][chunk]);
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc ((void *) addr, 0, (int) (12 * c), 0x00020000);
-      pre[k] = __builtin_amdgcn_raw_buffer_load_b96 (rs, 12 * lane, 0, 0);
+      pre[k] = __builtin_amdgcn_raw_buffer_load_b96 (rs, 12 * lane, 0, GT4_LOAD_AUX);
     }
   };
 #endif
@@ -1483,7 +1483,7 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc ((void *) (p.table_counts + (first_row + r0) * cols), 0, (int) (4 * words), 0x00020000);
       for (u32 c = (u32) tid; 4u * c < words; c += NT) {
         u32x4 *const q = reinterpret_cast<u32x4 *> (&sh.stage[4u * c]);
-        __builtin_amdgcn_raw_buffer_store_b128 (*q, rs, 16 * c, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128 (*q, rs, 16 * c, 0, GT4_STORE_AUX);
         *q = u32x4 { 0, 0, 0, 0 };
       }
       if (r0 + rb < n_rows) __syncthreads (); /* (the next rows' counts go where these lay) */
@@ -2002,7 +2002,7 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
           w[u] = *reinterpret_cast<const u32x4 *> (sh.stage + 4 * (c < chunks ? c : chunks - 1u));
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++) __builtin_amdgcn_raw_buffer_store_b128 (w[u], r, 16 * (c0 + (u32) u * WAVE + (u32) lane), 0, 0);
+        for (int u = 0; u < 4; u++) __builtin_amdgcn_raw_buffer_store_b128 (w[u], r, 16 * (c0 + (u32) u * WAVE + (u32) lane), 0, GT4_STORE_AUX);
       }
       wo_done = true;
     };
