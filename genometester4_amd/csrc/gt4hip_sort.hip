@@ -139,6 +139,13 @@ __global__ __launch_bounds__ (RADIX_MAX_DIGITS) void k_radix_bases (u64 *__restr
  *   4. one thread per digit looks back over the earlier tiles' states (RADIX_LOOK per round trip) until it
  *      meets a PREFIX; the tile's own PREFIX is published;
  *   5. the tile leaves LDS in digit order: runs of one digit go to consecutive addresses. */
+/* (cache-policy switches of the words' streaming load and scattered store, as in gt4hip_device.h) */
+#ifndef GT4_SORT_LOAD_AUX
+#define GT4_SORT_LOAD_AUX 0
+#endif
+#ifndef GT4_SORT_STORE_NT
+#define GT4_SORT_STORE_NT 0
+#endif
 template <int B>
 __global__ __launch_bounds__ (RADIX_NT, GT4_RADIX_WAVES) void k_radix_scatter (const u64 *__restrict__ in, u64 *__restrict__ out, u64 n, u32 pass, u32 shift, const u64 *__restrict__ gbase,
                                                                               u64 *__restrict__ state, u32 *__restrict__ ticket, u32 *__restrict__ err, u32 spin_limit)
@@ -165,7 +172,7 @@ __global__ __launch_bounds__ (RADIX_NT, GT4_RADIX_WAVES) void k_radix_scatter (c
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc ((void *) (in + base), 0, (int) (8 * nv), 0x00020000);
 #pragma unroll
     for (int r = 0; r < RADIX_ITEMS; r++) {
-      const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64 (rs, 8 * lane, 8 * WAVE * (wid * RADIX_ITEMS + r), 0);
+      const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64 (rs, 8 * lane, 8 * WAVE * (wid * RADIX_ITEMS + r), GT4_SORT_LOAD_AUX);
       key[r] = (u64) v.x | ((u64) v.y << 32);
     }
   }
@@ -270,7 +277,11 @@ __global__ __launch_bounds__ (RADIX_NT, GT4_RADIX_WAVES) void k_radix_scatter (c
     const u32 q = (u32) r * RADIX_NT + (u32) tid;
     if (q < nv) {
       const u64 k = keys[q];
+#if GT4_SORT_STORE_NT
+      __builtin_nontemporal_store (k, &out[gofs[(u32) (k >> shift) & (u32) (ND - 1)] + q]);
+#else
       out[gofs[(u32) (k >> shift) & (u32) (ND - 1)] + q] = k;
+#endif
     }
   }
 }
