@@ -946,6 +946,9 @@ __global__ __launch_bounds__ (1024) void k_nway_tile_bases (const u32 *__restric
 #ifndef GT4_NWAY_SVPRIO
 #define GT4_NWAY_SVPRIO 3
 #endif
+#ifndef GT4_TABLE_STORE_AUX
+#define GT4_TABLE_STORE_AUX 0 /* cache policy of the count tables' row stores (see gt4hip_device.h) */
+#endif
 #ifndef GT4_NWAY_ROWW
 #define GT4_NWAY_ROWW 14336 /* words of the count tables' row area in LDS (56 KB: 159 of 160 KB with it; 12288: 1 - 2 % slower, 10240: 2 - 3 %) */
 #endif
@@ -1406,7 +1409,9 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
       const u64 addr = uniform64 (sh.slot_addr[tb][chunk]);
       const u32 c = uniform32 (sh.slot_cnt[tb][chunk]);
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc ((void *) addr, 0, (int) (12 * c), 0x00020000);
-      pre[k] = __builtin_amdgcn_raw_buffer_load_b96 (rs, 12 * lane, 0, GT4_LOAD_AUX);
+      /* (non-temporal where the union streams its records; the count tables' launches measured 9 % SLOWER with it -- 6.2
+       * against 5.7 ms on six lists -- and keep plain loads: profiles/round5/r5_cache_policy.log) */
+      pre[k] = __builtin_amdgcn_raw_buffer_load_b96 (rs, 12 * lane, 0, (MODE == NWAY_TABLE || MODE == NWAY_PROBE) ? 0 : GT4_LOAD_AUX);
     }
   };
 #endif
@@ -1483,7 +1488,7 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc ((void *) (p.table_counts + (first_row + r0) * cols), 0, (int) (4 * words), 0x00020000);
       for (u32 c = (u32) tid; 4u * c < words; c += NT) {
         u32x4 *const q = reinterpret_cast<u32x4 *> (&sh.stage[4u * c]);
-        __builtin_amdgcn_raw_buffer_store_b128 (*q, rs, 16 * c, 0, GT4_STORE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128 (*q, rs, 16 * c, 0, GT4_TABLE_STORE_AUX);
         *q = u32x4 { 0, 0, 0, 0 };
       }
       if (r0 + rb < n_rows) __syncthreads (); /* (the next rows' counts go where these lay) */
