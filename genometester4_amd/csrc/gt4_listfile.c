@@ -92,8 +92,20 @@ int gt4_listfile_open (const char *path, unsigned int major_version, GT4ListFile
   } else {
     memcpy (&h, map, avail);
   }
-  const uint64_t need = h.list_start + h.n_words * (uint64_t) (h.word_bytes + h.count_bytes);
-  if (size < need) {
+  /* The reference's own test (src/word-map.c:211-215) multiplies in wrapping 64-bit arithmetic by the FILE's
+   * word_bytes + count_bytes (minor > 2) while every reader -- its own included, src/word-map.h:89-99 -- strides 12:
+   * a header with n_words = 2^40 and 0 + 0 bytes per record, or with n_words = 2^64 / 12 + 1, passes it and is then
+   * read far beyond the mapping.  Here: the reference's test first (same message, same number, where it fires), then
+   * the bound that actually protects the readers, by division: list_start inside the file and n_words records of 12
+   * bytes behind it. */
+  const uint64_t ref_need = h.list_start + h.n_words * (uint64_t) (h.word_bytes + h.count_bytes);
+  const int fits = h.list_start <= size && h.n_words <= (size - h.list_start) / 12u;
+  if (size < ref_need || !fits) {
+    uint64_t need = ref_need;
+    if (size >= ref_need) { /* (the reference would have gone on: say what the readers need, saturating) */
+      need = h.n_words > (UINT64_MAX - h.list_start) / 12u ? UINT64_MAX : h.list_start + 12u * h.n_words;
+      if (h.list_start > size && need < h.list_start) need = h.list_start;
+    }
     fprintf (stderr, "gt4_word_map_new: file size too small (%llu, should be at least %llu)\n", (unsigned long long) size,
              (unsigned long long) need);
     munmap ((void *) map, size);
