@@ -78,6 +78,35 @@ def test_malformed_first_file_is_an_error_not_a_crash(workdir):
         assert err.endswith("Stopping...\n")
 
 
+def _hostile_cases():
+    import hostile_headers
+    return hostile_headers.cases()
+
+
+@pytest.mark.parametrize("position", ["first", "second", "third of three"])
+@pytest.mark.parametrize("name,blob,message", _hostile_cases(), ids=[c[0] for c in _hostile_cases()])
+def test_hostile_headers_are_refused_without_a_signal(name, blob, message, position, workdir):
+    """Headers that pass (or wrap) the reference's size test while the readers stride 12 -- the reference segfaults on
+    several (`/root/reference/src/word-map.c:211-215`); here: the size diagnostic, exit code 1, nothing written
+    (Missing 4; the same files run under ASan + UBSan in tests/test_host_sanitizers.py)."""
+    import hostile_headers
+    path = os.path.join(workdir, name)
+    with open(path, "wb") as f:
+        f.write(blob)
+    with open(os.path.join(workdir, "h_good.list"), "wb") as f:
+        f.write(hostile_headers.good_list())
+    try:
+        argv = {"first": [name, "h_good.list", "-u"], "second": ["h_good.list", name, "-u"],
+                "third of three": ["h_good.list", "h_good.list", name, "-u"]}[position]
+        rc, out, err, files = _run(argv + ["-o", "hostile"], workdir)
+        assert rc == 1, (rc, err)  # (a signal would be a negative return code)
+        assert message in err and "Error: File %s is invalid or corrupted\n" % name in err, err
+        assert err.endswith("Stopping...\n") and not files and out == ""
+    finally:
+        os.remove(path)
+        os.remove(os.path.join(workdir, "h_good.list"))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", OK_CASES, ids=lambda c: c["id"])
 def test_stream_debug_and_header_variants_match_reference(case, workdir):

@@ -126,3 +126,29 @@ def test_budget_that_cannot_be_met_is_an_error(binaries, workdir):
     rc, out, err, files = _run(binaries["asan"], ["A8.list", "B8.list", "-u", "-o", "tiny"], workdir, {"GT4HIP_GPUS": "2", "GT4HIP_STUB_DEVICES": "2", "GT4HIP_HBM_LIMIT": "12"})
     _clean(err)
     assert rc == 1 and "cannot be cut into key-range chunks" in err and not files
+
+
+def test_hostile_headers_under_asan(binaries, workdir):
+    """VERDICT round 5, Missing 4: headers whose n_words x record bytes passes or wraps the reference's size test
+    (`/root/reference/src/word-map.c:211-215`) -- n_words = 2^40 with 0-byte records, 2^64 / 12 + 1, all ones,
+    list_start beyond the file, truncated headers, GT4I twins.  The host used to segfault in gt4_listfile_key_at
+    (csrc/gt4_shard.c) on the first two; every one must now be refused with the size diagnostic and exit code 1, in
+    every position and in the chunked path, with no sanitizer report."""
+    import hostile_headers
+    with open(os.path.join(workdir, "h_good.list"), "wb") as f:
+        f.write(hostile_headers.good_list())
+    try:
+        for name, blob, message in hostile_headers.cases():
+            with open(os.path.join(workdir, name), "wb") as f:
+                f.write(blob)
+            try:
+                for argv in ([name, "h_good.list", "-u"], ["h_good.list", name, "-i", "--count_only"], ["h_good.list", "h_good.list", name, "-u"]):
+                    for env in ({"GT4HIP_GPUS": "1"}, {"GT4HIP_GPUS": "2", "GT4HIP_STUB_DEVICES": "2", "GT4HIP_HBM_LIMIT": "1024"}):
+                        rc, out, err, files = _run(binaries["asan"], argv, workdir, env, timeout=60)
+                        _clean(err)
+                        assert rc == 1, (name, argv, rc, err[-500:])
+                        assert message in err and err.endswith("Stopping...\n") and not files, (name, err)
+            finally:
+                os.remove(os.path.join(workdir, name))
+    finally:
+        os.remove(os.path.join(workdir, "h_good.list"))
