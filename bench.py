@@ -228,9 +228,7 @@ def multi_roofline(ctx, kind, n_in_local, n_out_local, device_ms, kernel_ms, one
     t_ms = kernel_ms if one_pass and kernel_ms > 0 else device_ms
     achieved = alg / (t_ms * 1e-3) / 1e9
     if one_pass:
-        sub = os.environ.get("GT4HIP_KWAY_SUB", "0") != "0"
-        kernel = ("k_nway_sub<NWAY_UNION> (wave-private sub-tiles; one pass over up to eight lists per launch)" if sub
-                  else "k_nway_merge<1024, 4, 1, NWAY_UNION> (one pass over up to eight lists per launch)")
+        kernel = "k_nway_merge<1024, 4, 1, NWAY_UNION> (one pass over up to eight lists per launch)"
         if MULTI[kind]["lists"] > 8:
             kernel = "km32::k_nway_merge<1024, 4, 1, NWAY_UNION> (one pass over up to 32 lists per launch: runs end to end in the tile, samples every 64 records)"
     elif levels:

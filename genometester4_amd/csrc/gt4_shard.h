@@ -7,8 +7,7 @@
  * disk that scripts/MakeUnion.pl:31-95 drives, and for big inputs the reference's reliance on
  * mmap paging (src/utils.c:35-64) / 3 KiB read()s (src/word-list-stream.c:85-125).
  */
-#ifndef GT4_SHARD_H
-#define GT4_SHARD_H
+#pragma once
 
 #include <stdint.h>
 
@@ -59,5 +58,3 @@ int gt4_shard_run (const GT4ShardJob *job, GT4ShardResult *res);
 /* Index of the first record of a mapped list / index file with key >= `key` (host binary search). */
 uint64_t gt4_listfile_lower_bound (const GT4ListFile *lf, uint64_t key);
 uint64_t gt4_listfile_key_at (const GT4ListFile *lf, uint64_t idx);
-
-#endif

@@ -91,10 +91,6 @@ extern "C" int gt4hip_create (int device, gt4hip_context **out)
     const char *e = getenv ("GT4HIP_DYNAMIC"); /* diagnostic: the whole test-suite through the other dealing */
     ctx->dynamic = e ? atoi (e) : 0; /* 0: automatic */
   }
-  {
-    const char *e = getenv ("GT4HIP_KWAY_SUB"); /* diagnostic: A/B of the two tile kernels without touching the caller */
-    ctx->kway_sub = e ? atoi (e) : 0; /* (round 5: k_nway_sub loses the A/B -- profiles/round5/r5_nsub_ab.log; k_nway_merge stays) */
-  }
   ctx->kway_max = 32;
   ctx->kway_enabled = 1; /* N-way unions of three lists or more take the one-pass tile kernel (gt4hip_nway.hip); option "kway": 0 the pairwise tree, 2 also two lists */
   snprintf (ctx->info, sizeof ctx->info, "%s|%s|%d|%zu", prop.name, prop.gcnArchName, prop.multiProcessorCount, prop.totalGlobalMem);
@@ -185,7 +181,6 @@ extern "C" int gt4hip_set_option (gt4hip_context *ctx, const char *name, int64_t
   else if (!strcmp (name, "scan_group")) ctx->scan_group = (int) value;
   else if (!strcmp (name, "dynamic")) ctx->dynamic = (int) value;
   else if (!strcmp (name, "kway")) ctx->kway_enabled = (int) value;
-  else if (!strcmp (name, "kway_sub")) ctx->kway_sub = (int) value;
   else if (!strcmp (name, "kway_max")) ctx->kway_max = value == 8 ? 8 : (value == 33 ? 33 : 32);
   else if (!strcmp (name, "kway_g")) ctx->kway_g = value;
   else if (!strcmp (name, "kway_vt")) ctx->kway_vt = value;
@@ -698,7 +693,7 @@ static int run_pair (gt4hip_context *ctx, const uint32_t *A, uint64_t nA, const 
   float ms = 0;
   if (hipEventElapsedTime (&ms, ctx->ev[1], ctx->ev[2]) == hipSuccess) run->merge_ms = ms;
   if (hipEventElapsedTime (&ms, ctx->ev[0], ctx->ev[3]) == hipSuccess) run->device_ms = ms;
-#ifdef GT4_PROFILE_PHASES
+PROF (
   {
     static const char *names[8] = { "p0 wait+lds", "B0", "ring+fetch issue", "p1 rank", "B1", "p2 scan/publish", "B2+out+B3+scatter", "housekeeping" };
     unsigned long long tot = 0;
@@ -709,7 +704,7 @@ static int run_pair (gt4hip_context *ctx, const uint32_t *A, uint64_t nA, const 
     const unsigned long long *rs = ctx->ctl_host->resolve_stats;
     if (rs[0]) fprintf (stderr, "[resolve] sampled %llu avg spins %.2f first-look agg-not-ready %.1f%% carry-not-ready %.1f%% | [scanner] rows %llu polling rounds %llu rows complete at batch load %llu\n", rs[0], (double) rs[1] / rs[0], 100.0 * rs[3] / rs[0], 100.0 * rs[4] / rs[0], rs[7], rs[5], rs[6]);
   }
-#endif
+)
   if (ctx->ctl_host->error) {
     const unsigned flags = ctx->ctl_host->error;
     if (!two_pass && !count_only && !(flags & 2u)) {

@@ -120,20 +120,13 @@ __device__ __forceinline__ void publish_u64 (u64 *p, u64 v) { __hip_atomic_store
 __device__ __forceinline__ u32 peek_u32 (u32 *p) { return __hip_atomic_load (p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ u64 peek_u64 (u64 *p) { return __hip_atomic_load (p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-#ifdef GT4_PROFILE_PHASES
-#ifndef GT4_STAMP_TID
-#define GT4_STAMP_TID 0
-#endif
-/* one asm statement with its own wait, fenced from the scheduler (cdna_hip_programming.md section 7, In-kernel stamps) */
-#define PHASE_STAMP(i) do { __builtin_amdgcn_sched_barrier (0); u64 t_; asm volatile ("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier (0); if (tid == GT4_STAMP_TID) { ph[i] += t_ - t_last; } t_last = t_; } while (0)
-#else
-#define PHASE_STAMP(i) do { } while (0)
-#endif
+/* (diagnostics build, `make prof`: PROF (...) and GT4_PROFILE_PHASES are in gt4hip_internal.h)
+ * one asm statement with its own wait, fenced from the scheduler (cdna_hip_programming.md section 7, In-kernel stamps) */
+#define GT4_STAMP_TID GT4_PROFILE_PHASES
+#define PHASE_STAMP(i) PROF (do { __builtin_amdgcn_sched_barrier (0); u64 t_; asm volatile ("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier (0); if (tid == GT4_STAMP_TID) { ph[i] += t_ - t_last; } t_last = t_; } while (0))
 
 constexpr u32 SPIN_LIMIT = 1u << 22; /* bounded: ~seconds; sets ctl->error instead of hanging */
-#ifndef GT4_SCAN_ROWS
 #define GT4_SCAN_ROWS 16
-#endif
 constexpr int SCAN_ROWS = GT4_SCAN_ROWS;        /* rows of 64 tiles a scanner wavefront keeps in flight */
 
 /* The scanner: one wavefront per stream.  Loads SCAN_ROWS x 64 tile counts at once (so that its
@@ -163,13 +156,13 @@ __device__ void scanner_wave (u32 *agg, u64 *carry_out, u64 num_tiles, PairContr
     load_batch (w, r0 + SCAN_ROWS);
     int done = 0;
     u32 spins = 0;
-#ifdef GT4_PROFILE_PHASES
+PROF (
     u64 st_rounds = 0, st_first = 0;
-#endif
+)
     for (;;) {
-#ifdef GT4_PROFILE_PHASES
+PROF (
       const int done_before = done;
-#endif
+)
       /* retire, in order, every row that is complete */
 #pragma unroll
       for (int j = 0; j < SCAN_ROWS; j++) {
@@ -179,7 +172,7 @@ __device__ void scanner_wave (u32 *agg, u64 *carry_out, u64 num_tiles, PairContr
           done++;
         }
       }
-#ifdef GT4_PROFILE_PHASES
+PROF (
       st_rounds++;
       if (spins == 0) st_first += (u64) (done - done_before);
       if (done >= n && lane == 0) {
@@ -187,7 +180,7 @@ __device__ void scanner_wave (u32 *agg, u64 *carry_out, u64 num_tiles, PairContr
         atomicAdd (&ctl->resolve_stats[6], st_first);
         atomicAdd (&ctl->resolve_stats[7], (u64) n);
       }
-#endif
+)
       if (done >= n) break;
       /* somebody else gave up (the host reruns the call on the two-pass path): give up at this look too */
       if ((spins & 63u) == 63u && peek_u32 (&ctl->error)) spins = spin_limit;
@@ -317,9 +310,8 @@ __device__ __forceinline__ void scanner_part (u32 *agg, u64 *rowsum, u64 *carry_
  * many rows behind the workers without anybody waiting for it -- with one staging area (the
  * any-combination pair kernel, the N-way kernel) the chain's round trip otherwise bounds the time per
  * tile (measured: the N-way kernel stripped of all its ranking and output still took 21.6 of 30 ms). */
-#ifndef GT4_RESOLVE_LOOKBACK
-#define GT4_RESOLVE_LOOKBACK 0 /* per kernel file: the pair kernels take 3 (-u -d -c 3: 24.14 -> 23.48 ms); the N-way kernel's service wavefront loses 9 % to the extra loads and keeps 0 */
-#endif
+/* GT4_RESOLVE_LOOKBACK: defined by the including kernel file -- the pair kernels take 3 (-u -d -c 3: 24.14 -> 23.48 ms); the
+ * N-way kernel's service wavefront loses 9 % to the extra loads and takes 0 */
 constexpr int RESOLVE_LOOKBACK = GT4_RESOLVE_LOOKBACK;
 
 __device__ __forceinline__ u64 resolve_offset (u32 *agg, u64 *carry, u64 tile, int lane, u32 a, u64 c, PairControl *ctl, u32 spin_limit)
@@ -330,9 +322,9 @@ __device__ __forceinline__ u64 resolve_offset (u32 *agg, u64 *carry, u64 tile, i
   u64 *const wc = &carry[row];
   const bool mine = (u32) lane < pos;
   u32 spins = 0;
-#ifdef GT4_PROFILE_PHASES
+PROF (
   const bool agg_ok0 = __all (!mine || (a & AGG_READY) != 0), carry_ok0 = (c & CARRY_READY) != 0;
-#endif
+)
   u64 back = 0; /* counts of the complete rows between the carry used and this row */
   for (;;) {
     const bool own_ok = __all (!mine || (a & AGG_READY) != 0);
@@ -376,14 +368,14 @@ __device__ __forceinline__ u64 resolve_offset (u32 *agg, u64 *carry, u64 tile, i
     if (mine && !(a & AGG_READY)) a = peek_u32 (wa);
     if (!(c & CARRY_READY)) c = peek_u64 (wc);
   }
-#ifdef GT4_PROFILE_PHASES
+PROF (
   if (lane == 0 && (tile & 63) == 17) { /* sample 1 in 64 so that the statistics do not perturb the run */
     atomicAdd (&ctl->resolve_stats[0], 1ull);
     atomicAdd (&ctl->resolve_stats[1], (u64) spins);
     atomicAdd (&ctl->resolve_stats[3], agg_ok0 ? 0ull : 1ull);
     atomicAdd (&ctl->resolve_stats[4], carry_ok0 ? 0ull : 1ull);
   }
-#endif
+)
   return (c & ~CARRY_READY) + back + dpp_wave_sum_u32 (mine ? (a & ~AGG_READY) : 0u);
 }
 
@@ -391,12 +383,8 @@ __device__ __forceinline__ u64 resolve_offset (u32 *agg, u64 *carry, u64 tile, i
  * read once and written once, and says so -- NON-TEMPORAL both ways.  Measured (profiles/round5/r5_cache_policy.log,
  * three alternating runs each): the headline intersection 10.93 -> 10.81 ms per launch, the 8-way union 28.23 -> 27.85,
  * config 2 23.34 -> 23.18; sc1 (write-through, line dropped from L2) stores cost config 2 10 %. */
-#ifndef GT4_STORE_AUX
 #define GT4_STORE_AUX 2
-#endif
-#ifndef GT4_LOAD_AUX
 #define GT4_LOAD_AUX 2
-#endif
 
 /* Tile write-out: `tot` packed records from an LDS staging slot (16-byte aligned) to the output
  * list at record offset `excl`, as 16-byte buffer stores (dword alignment suffices; the

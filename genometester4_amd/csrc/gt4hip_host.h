@@ -52,7 +52,6 @@ struct gt4hip_context {
   size_t kway_need_bytes;
   uint64_t kway_splits;      /* counter "kway_splits": tiles cut in two by the last N-way call */
   int kway_enabled;          /* option "kway": 0 = always the pairwise tree, 1 = the one-pass kernel unless the keys are clustered, 2 = always, also for two lists, 3 = always (three lists and more) */
-  int kway_sub;              /* option "kway_sub": 1 unions and counts take k_nway_sub (wave-private sub-tiles: round 5's structural experiment, 40 % slower), 0 (default) k_nway_merge */
   int kway_max;              /* option "kway_max": lists per launch of the tile kernel, 32 (default: unless the lists share most keys), 8, or 33 (= 32 whatever the keys) */
   uint64_t kway_width;       /* counter "kway_width": lists per launch the last N-way union took (8 or 32) */
   uint64_t kway_shared_x100; /* counter "kway_shared_x100": 100 x the mean number of lists a probed key lies in (last union of more than eight lists) */

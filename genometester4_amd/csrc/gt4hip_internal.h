@@ -5,6 +5,15 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+/* The one compile-time switch of the device code: the diagnostics build (`make prof`, -DGT4_PROFILE_PHASES=<thread whose
+ * phases are stamped>) keeps what PROF (...) encloses -- phase stamps, scanner and resolve statistics; the product build
+ * drops it. */
+#ifdef GT4_PROFILE_PHASES
+#define PROF(...) __VA_ARGS__
+#else
+#define PROF(...)
+#endif
+
 namespace gt4 {
 
 /* Internal rule code on top of the reference's enum Rules (src/glistcompare.c:45-54):

@@ -19,23 +19,12 @@
  *   K3 k_scan_*       tile-count scan for the two-pass fallback.
  *   K0 k_generate     synthetic ascending lists written straight into HBM (bench only).
  */
-#ifndef GT4_RESOLVE_LOOKBACK
 #define GT4_RESOLVE_LOOKBACK 3
-#endif
 #include "gt4hip_device.h"
 
-#ifndef GT4_NARROW
-#define GT4_NARROW 1
-#endif
-#ifndef GT4_IPT_UNION
 #define GT4_IPT_UNION 4 /* 6 (one staging slot written out late) measured 3 % slower than 4 with two slots */
-#endif
-#ifndef GT4_IPT_INTERSECT
 #define GT4_IPT_INTERSECT 6
-#endif
-#ifndef GT4_IPT_INTERSECT_SMALL
 #define GT4_IPT_INTERSECT_SMALL 4 /* positions per thread of the 512-thread intersection (experiments: 6) */
-#endif
 
 namespace gt4 {
 
@@ -486,10 +475,7 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
    * addresses and masks derived from it are recomputed where they are used (a few VALU each) instead of living in
    * registers across the whole loop, hoisted by the compiler -- which had two to six of them in scratch memory.
    * tools/kernel_resources.py / tests/test_kernel_resources.py: no instantiation may spill a vector register. */
-#ifndef GT4_OPAQUE_ALL
-#define GT4_OPAQUE_ALL 0
-#endif
-  constexpr bool OPAQUE_TID = GT4_OPAQUE_ALL == 2 || (OPS == 0 && (GT4_OPAQUE_ALL == 1 || !(FAST == 1 && (OPSET == 3 || OPSET == 5) && MODE != MODE_COUNT)));
+  constexpr bool OPAQUE_TID = OPS == 0 && !(FAST == 1 && (OPSET == 3 || OPSET == 5) && MODE != MODE_COUNT);
   int tid = threadIdx.x, lane = tid & (WAVE - 1); /* (not const: OPAQUE_TID) */
   const int wid = __builtin_amdgcn_readfirstlane (tid / WAVE); /* wave-uniform: scalar branches on it */
   static_assert (OPSET == 0 || OPS == 0, "a compile-time stream set belongs to the any-combination kernel");
@@ -634,11 +620,11 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
   };
 
   if (cur < ntl) fetch (tr);
-#ifdef GT4_PROFILE_PHASES
+PROF (
   u64 ph[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
   u64 t_last;
   asm volatile ("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_last) :: "memory");
-#endif
+)
   /* DEFER: the LAG tiles whose output is staged in LDS but not yet written: their numbers (past[])
    * and record counts are remembered: a queue shifted once per iteration with static indices only (entry 0 =
    * oldest = staged LAG iterations ago, in slot it % LAG) -- indexing it by it % LAG instead turns
@@ -771,7 +757,7 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
      * only the final test reaches the scalar unit */
     bool narrow = false;
     u32 base_lo = 0;
-    if (GT4_NARROW && OPS == 2 && MODE != MODE_COUNT && na && nb) { /* (the intersection: 11.30 -> 11.11 ms; the scalar-bound kernels lose 2-3 % to the test itself) */
+    if (OPS == 2 && MODE != MODE_COUNT && na && nb) { /* (the intersection: 11.30 -> 11.11 ms; the scalar-bound kernels lose 2-3 % to the test itself) */
       const u32 la = 3 * (na - 1), lb = OB + 3 * (nb - 1);
       const u64 a_min = (u64) lds32[0] | ((u64) lds32[1] << 32), a_max = (u64) lds32[la] | ((u64) lds32[la + 1] << 32);
       const u64 b_min = (u64) lds32[OB] | ((u64) lds32[OB + 1] << 32), b_max = (u64) lds32[lb] | ((u64) lds32[lb + 1] << 32);
@@ -1073,10 +1059,10 @@ k_pair_merge (const u32 *__restrict__ A, u64 nA, const u32 *__restrict__ B, u64 
       r_nn = r_cur == 0 ? 2 : r_cur - 1; /* 0 1 2 -> the slot before r_nxt */
     }
   }
-#ifdef GT4_PROFILE_PHASES
+PROF (
   if (tid == GT4_STAMP_TID)
     for (int i = 0; i < 8; i++) atomicAdd (&ctl->phase_cycles[i], ph[i]);
-#endif
+)
 
   if (GDEFER && it >= 1) {
     /* drain: the last tile's streams are still staged */

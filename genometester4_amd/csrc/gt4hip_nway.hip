@@ -60,6 +60,7 @@
  *      k_nway_tile_bases,
  *      k_nway_padded_bases
  */
+#define GT4_RESOLVE_LOOKBACK 0
 #include "gt4hip_device.h"
 #include "gt4hip_host.h"
 
@@ -69,11 +70,14 @@
 
 #define GT4_KM 8
 #define GT4_KM_NS km8
+#define GT4_KM_ROWS "gt4hip_nway_rows8.h"
 #include "gt4hip_nway_body.h"
 #undef GT4_KM
 #undef GT4_KM_NS
+#undef GT4_KM_ROWS
 #define GT4_KM 32
 #define GT4_KM_NS km32
+#define GT4_KM_ROWS "gt4hip_nway_rows32.h"
 #include "gt4hip_nway_body.h"
 #undef GT4_KM
 #undef GT4_KM_NS

@@ -26,6 +26,7 @@
  * kernel per pass, words scattered 8 bytes at a time) took 100.6 ms, rocprim::radix_sort_keys 40.5 ms
  * (profiles/round3/r3_sort_experiments.log).
  */
+#define GT4_RESOLVE_LOOKBACK 0 /* (no chained scan of tile totals here) */
 #include "gt4hip_device.h"
 #include "gt4hip_host.h"
 
@@ -45,26 +46,15 @@ __device__ __forceinline__ u64 readlane_u64 (u64 v, int l)
 
 /* ---- radix sort: one histogram kernel for all passes, then one scatter kernel per pass */
 
-#ifndef GT4_RADIX_NT
 #define GT4_RADIX_NT 512
-#endif
-#ifndef GT4_RADIX_ITEMS
 #define GT4_RADIX_ITEMS 16
-#endif
 constexpr int RADIX_NT = GT4_RADIX_NT;        /* threads per tile */
 constexpr int RADIX_ITEMS = GT4_RADIX_ITEMS;  /* words per thread */
 constexpr int RADIX_TILE = RADIX_NT * RADIX_ITEMS;
 constexpr int RADIX_NW = RADIX_NT / WAVE;
 constexpr int RADIX_MAX_PASSES = 8;
-#ifndef GT4_RADIX_WAVES
 #define GT4_RADIX_WAVES 4 /* wavefronts per SIMD the scatter kernel's registers must leave room for: two workgroups per CU */
-#endif
-#ifndef GT4_RADIX_NINE
-#define GT4_RADIX_NINE 1 /* 0: eight bits in every pass */
-#endif
-#ifndef GT4_RADIX_LOOK
 #define GT4_RADIX_LOOK 4
-#endif
 constexpr int RADIX_LOOK = GT4_RADIX_LOOK; /* earlier tiles inspected per round trip of the look-back */
 constexpr int HIST_NT = 256;
 constexpr int HIST_ITEMS = 16;
@@ -140,12 +130,6 @@ __global__ __launch_bounds__ (RADIX_MAX_DIGITS) void k_radix_bases (u64 *__restr
  *      meets a PREFIX; the tile's own PREFIX is published;
  *   5. the tile leaves LDS in digit order: runs of one digit go to consecutive addresses. */
 /* (cache-policy switches of the words' streaming load and scattered store, as in gt4hip_device.h) */
-#ifndef GT4_SORT_LOAD_AUX
-#define GT4_SORT_LOAD_AUX 0
-#endif
-#ifndef GT4_SORT_STORE_NT
-#define GT4_SORT_STORE_NT 0
-#endif
 template <int B>
 __global__ __launch_bounds__ (RADIX_NT, GT4_RADIX_WAVES) void k_radix_scatter (const u64 *__restrict__ in, u64 *__restrict__ out, u64 n, u32 pass, u32 shift, const u64 *__restrict__ gbase,
                                                                               u64 *__restrict__ state, u32 *__restrict__ ticket, u32 *__restrict__ err, u32 spin_limit)
@@ -172,7 +156,7 @@ __global__ __launch_bounds__ (RADIX_NT, GT4_RADIX_WAVES) void k_radix_scatter (c
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc ((void *) (in + base), 0, (int) (8 * nv), 0x00020000);
 #pragma unroll
     for (int r = 0; r < RADIX_ITEMS; r++) {
-      const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64 (rs, 8 * lane, 8 * WAVE * (wid * RADIX_ITEMS + r), GT4_SORT_LOAD_AUX);
+      const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64 (rs, 8 * lane, 8 * WAVE * (wid * RADIX_ITEMS + r), 0);
       key[r] = (u64) v.x | ((u64) v.y << 32);
     }
   }
@@ -277,11 +261,7 @@ __global__ __launch_bounds__ (RADIX_NT, GT4_RADIX_WAVES) void k_radix_scatter (c
     const u32 q = (u32) r * RADIX_NT + (u32) tid;
     if (q < nv) {
       const u64 k = keys[q];
-#if GT4_SORT_STORE_NT
-      __builtin_nontemporal_store (k, &out[gofs[(u32) (k >> shift) & (u32) (ND - 1)] + q]);
-#else
-      out[gofs[(u32) (k >> shift) & (u32) (ND - 1)] + q] = k;
-#endif
+      out[gofs[(u32) (k >> shift) & (u32) (ND - 1)] + q] = k; /* (plain: non-temporal scattered stores measured slower, profiles/round5/r5_cache_policy.log) */
     }
   }
 }
@@ -461,7 +441,7 @@ static int radix_sort_device (gt4hip_context *ctx, u64 *words, u64 *tmp, uint64_
    * (k = 25: 50 bits = 9 + 9 + 8 + 8 + 8 + 8, six passes instead of seven) */
   RadixPlan plan;
   memset (&plan, 0, sizeof plan);
-  plan.passes = GT4_RADIX_NINE ? (bits + 8) / 9 : (bits + 7) / 8;
+  plan.passes = (bits + 8) / 9; /* digits of nine bits as far as they go, eight for the rest */
   {
     const uint32_t nine = bits > 8 * plan.passes ? bits - 8 * plan.passes : 0;
     uint32_t at = 0;

@@ -335,8 +335,6 @@ int gt4hip_synchronize (gt4hip_context *ctx);
  *                      counter "kway_declined") / always by the tile kernel, two-list unions of the N-way
  *                      entry points too / always by the tile kernel (three lists and more); count tables
  *                      follow the same switch (and are never declined).
- *                      "kway_sub" = 1: unions and counts by k_nway_sub (wave-private sub-tiles, round 5: exact, slower;
- *                      0, the default: k_nway_merge);
  *                      "kway_g": samples per tile of its first partition attempt; "kway_vt" (tests):
  *                      97 tile boundaries by searches over whole brackets, 98 every tile bucketed by
  *                      its pivot run, 99 every tile on the search path

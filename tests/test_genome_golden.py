@@ -115,8 +115,7 @@ def test_library_paths_on_genomic_keys(lists):
             if len(files) != 8 or not ops & 1:
                 continue
             g = run["files"]["g_%d_union.list" % k]
-            for name, opts in (("library's choice", {"kway": 1, "kway_sub": 0}), ("tile kernel", {"kway": 3, "kway_sub": 0}),
-                               ("sub-tile kernel", {"kway": 3, "kway_sub": 1}), ("tree", {"kway": 0, "kway_sub": 0})):
+            for name, opts in (("library's choice", {"kway": 1}), ("tile kernel", {"kway": 3}), ("tree", {"kway": 0})):
                 for o, v in opts.items():
                     ctx.set_option(o, v)
                 declined = ctx.get_counter("kway_declined")

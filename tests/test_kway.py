@@ -13,14 +13,11 @@ import oracle_lib as O
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=[0, 1], ids=["k_nway_merge", "k_nway_sub"])
-def ctx(request):
-    """every test twice: the tile kernel of the product (k_nway_merge) and round 5's wave-private sub-tile kernel
-    (k_nway_sub, option "kway_sub" = 1: slower, kept as a measured alternative -- it must stay exact)"""
+@pytest.fixture(scope="module")
+def ctx():
     from genometester4_amd import capi
     c = capi.Context(0)
     c.set_option("kway", 3)  # the tile kernel whatever the keys (1, the default, hands clustered keys to the tree)
-    c.set_option("kway_sub", request.param)
     yield c
     c.close()
 

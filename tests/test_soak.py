@@ -28,6 +28,3 @@ def test_pair_kernels_soak():
 def test_nway_kernels_soak():
     print(_soak("soak_nway.py", 20, 502))
 
-
-def test_nway_sub_tile_kernel_soak():
-    print(_soak("soak_nway.py", 15, 503, {"GT4HIP_KWAY_SUB": "1"}))
