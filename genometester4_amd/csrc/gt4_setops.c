@@ -7,6 +7,7 @@
 #include "gt4_set_operations.h"
 
 #include <errno.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -220,32 +221,52 @@ static unsigned int iter_load (GT4HipWordSListIter *it)
  * out are remembered by the iterator's ADDRESS instead. */
 #define ITER_SLOTS 64
 static struct { GT4HipWordSListIter *it; void *block; } g_iter_blocks[ITER_SLOTS];
+static pthread_mutex_t g_iter_lock = PTHREAD_MUTEX_INITIALIZER; /* (iterators on different lists may be walked by different threads) */
 
-static void iter_forget (GT4HipWordSListIter *it, int free_block)
+/* A walk restarted at this ADDRESS: the block of the walk before goes (freed here). */
+static void iter_forget_address (GT4HipWordSListIter *it)
 {
+  pthread_mutex_lock (&g_iter_lock);
   for (int i = 0; i < ITER_SLOTS; i++)
     if (g_iter_blocks[i].it == it) {
-      if (free_block) free (g_iter_blocks[i].block);
+      free (g_iter_blocks[i].block);
       g_iter_blocks[i].it = NULL;
       g_iter_blocks[i].block = NULL;
     }
+  pthread_mutex_unlock (&g_iter_lock);
+}
+
+/* A block released by its owner -- who may be a COPY of the iterator it was handed to: entries go by the block, not by
+ * the address, so that the original address does not free it a second time on its next walk. */
+static void iter_forget_block (void *block)
+{
+  if (!block) return;
+  pthread_mutex_lock (&g_iter_lock);
+  for (int i = 0; i < ITER_SLOTS; i++)
+    if (g_iter_blocks[i].block == block) {
+      g_iter_blocks[i].it = NULL;
+      g_iter_blocks[i].block = NULL;
+    }
+  pthread_mutex_unlock (&g_iter_lock);
 }
 
 static void iter_remember (GT4HipWordSListIter *it, void *block)
 {
+  pthread_mutex_lock (&g_iter_lock);
   for (int i = 0; i < ITER_SLOTS; i++)
     if (!g_iter_blocks[i].it) {
       g_iter_blocks[i].it = it;
       g_iter_blocks[i].block = block;
-      return;
+      break;
     }
-  /* (more than ITER_SLOTS live iterators with blocks: the oldest idiom applies -- release them) */
+  /* (more than ITER_SLOTS live iterators with blocks: those beyond must be released by their owners) */
+  pthread_mutex_unlock (&g_iter_lock);
 }
 
 unsigned int gt4_hip_word_slist_get_first_word (GT4HipWordList *list, GT4HipWordSListIter *it)
 {
   if (!list || !it) return 0;
-  iter_forget (it, 1); /* a walk restarted on this iterator: its block of the walk before goes */
+  iter_forget_address (it); /* a walk restarted on this iterator: its block of the walk before goes */
   memset (it, 0, sizeof *it);
   it->list = list;
   it->num_words = list->num_words;
@@ -268,7 +289,7 @@ unsigned int gt4_hip_word_slist_get_next_word (GT4HipWordSListIter *it)
 void gt4_hip_word_slist_iter_release (GT4HipWordSListIter *it)
 {
   if (!it) return;
-  iter_forget (it, 0);
+  iter_forget_block (it->block);
   free (it->block);
   it->block = NULL;
   it->block_count = 0;

@@ -942,7 +942,7 @@ static int union_multi_kway (gt4hip_context *ctx, const std::vector<const gt4hip
     ctx->kway_shared_x100 = (uint64_t) (100.0 * m);
     if (m > 5.0) W = 8; /* keys that many lists share: levels of eight-way merges fold them step by step */
   }
-  ctx->kway_width = (uint64_t) W;
+  ctx->kway_width = cur.size () <= 8 ? 8u : (uint64_t) W; /* (up to eight lists take the eight-list instance of the kernel) */
   while (cur.size () > W && !rc) {
     std::vector<const gt4hip_list *> next;
     std::vector<gt4hip_list *> next_owned;

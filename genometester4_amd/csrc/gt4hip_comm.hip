@@ -157,9 +157,16 @@ extern "C" int gt4hip_comm_allgather_u64 (gt4hip_comm *c, const uint64_t *mine, 
   if (!r) return gt4hip_fail (ctx, GT4HIP_ECOMM, "%s", g_comm_err);
   HIPCHK (ctx, hipSetDevice (ctx->device));
   const size_t cap = 8 + 8 * (size_t) c->n_ranks; /* room for the widest exchange */
-  if (!c->tot_dev) {
-    HIPCHK (ctx, hipMalloc ((void **) &c->tot_dev, cap * 8));
-    HIPCHK (ctx, hipHostMalloc ((void **) &c->tot_host, cap * 8, hipHostMallocDefault));
+  if (!c->tot_dev) { /* (both or neither: a half-made pair must not survive a failed call) */
+    unsigned long long *dev = NULL, *host = NULL;
+    HIPCHK (ctx, hipMalloc ((void **) &dev, cap * 8));
+    const hipError_t eh = hipHostMalloc ((void **) &host, cap * 8, hipHostMallocDefault);
+    if (eh != hipSuccess) {
+      hipFree (dev);
+      return gt4hip_fail (ctx, GT4HIP_ENOMEM, "totals all-gather: pinned buffer: %s", hipGetErrorString (eh));
+    }
+    c->tot_dev = dev;
+    c->tot_host = host;
   }
   for (uint32_t i = 0; i < n; i++) c->tot_host[i] = mine[i];
   HIPCHK (ctx, hipMemcpyAsync (c->tot_dev, c->tot_host, (size_t) n * 8, hipMemcpyHostToDevice, ctx->stream));

@@ -283,6 +283,26 @@ int nway_run (gt4hip_context *ctx, const gt4hip_list *const lists[], uint32_t k,
       }
       /* a tile would overflow LDS: fewer samples per tile, down to the number that cannot overflow */
       ctx->kway_overflows++;
+      if (merged) {
+        /* The cuts come from the merged samples of the level above, whose launch is not read back on its own (see
+         * below).  If a bounded wait gave up there (a shared device) the samples are incomplete and the partition built
+         * on them is garbage: that is not a capacity problem -- the tree redoes the call, as a give-up in the last
+         * launch does. */
+        e = hipMemcpyAsync (ctx->ctl_host, ctx->ctl, sizeof (PairControl), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize (st);
+        if (e != hipSuccess) {
+          rc = gt4hip_fail (ctx, GT4HIP_EHIP, "N-way partition failed: %s", hipGetErrorString (e));
+          break;
+        }
+        if (ctx->ctl_host->error) {
+          const unsigned flags = ctx->ctl_host->error;
+          gt4hip_list_free (merged);
+          cleanup ();
+          if (flags & 2u) return gt4hip_fail (ctx, GT4HIP_EINTERNAL, "N-way merge kernel reported error flags 0x%x", flags);
+          ctx->single_pass_fallbacks++;
+          return GT4HIP_OK; /* *used = 0 */
+        }
+      }
       if (G <= g_sure) {
         rc = gt4hip_fail (ctx, GT4HIP_EINTERNAL, "N-way partition: a tile exceeds the capacity at %u samples per tile", G);
         break;

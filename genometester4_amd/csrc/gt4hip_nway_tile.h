@@ -256,6 +256,7 @@ k_nway_merge (NwayParams p, const u64 *__restrict__ part, u32 *__restrict__ out,
     const u64 nz = __builtin_amdgcn_ballot_w64 (len != 0u);
     const u32 rank = __builtin_amdgcn_mbcnt_hi ((u32) (nz >> 32), __builtin_amdgcn_mbcnt_lo ((u32) nz, 0u));
     u32 *const hm32 = reinterpret_cast<u32 *> (&sh.hmask[tb][0]);
+    static_assert (Shared::NHM == 2 * WAVE, "two stretch masks per lane are zeroed and scanned");
     hm32[2 * lane] = 0;                /* (the stretches' masks; 2 x 64 = NHM of them) */
     hm32[2 * (lane + WAVE)] = 0;
     asm volatile ("" ::: "memory");
