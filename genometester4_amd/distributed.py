@@ -62,12 +62,13 @@ def exchange_totals(n_words: int, total_count: int, device=None, group=None) -> 
     return [(int(r[0]), int(r[1]) | (int(r[2]) << 32)) for r in rows]
 
 
-def gatherv_records(local, counts: Sequence[int], root: int = 0, group=None):
+def gatherv_records(local, counts: Sequence[int], root: int = 0, group=None, out=None):
     """Gathers per-rank record payloads of different lengths on `root`.
 
     `local`: 1-D int32 tensor holding this rank's packed records (3 words per record) on the
     device the backend communicates from.  `counts[r]`: records of rank r (from exchange_totals).
-    Returns the concatenated int32 tensor on root (rank order = key order), None elsewhere."""
+    Returns the concatenated int32 tensor on root (rank order = key order; `out` if the root passes
+    one of at least 3 x sum(counts) words -- its own extent may already lie there), None elsewhere."""
     import torch
     import torch.distributed as dist
     rank = dist.get_rank(group)
@@ -79,7 +80,11 @@ def gatherv_records(local, counts: Sequence[int], root: int = 0, group=None):
                 w.wait()
         return None
     total = sum(counts)
-    out = torch.empty(3 * total, dtype=torch.int32, device=local.device)
+    if out is None:
+        out = torch.empty(3 * total, dtype=torch.int32, device=local.device)
+    else:
+        assert out.dtype == torch.int32 and out.numel() >= 3 * total
+        out = out[: 3 * total]
     offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
     ops = []
     for r in range(world):
@@ -87,7 +92,8 @@ def gatherv_records(local, counts: Sequence[int], root: int = 0, group=None):
             continue
         dst = out[3 * offs[r]: 3 * offs[r + 1]]
         if r == root:
-            dst.copy_(local)
+            if dst.data_ptr() != local.data_ptr():
+                dst.copy_(local)
         else:
             ops.append(dist.P2POp(dist.irecv, dst, r, group=group))
     if ops:
@@ -133,6 +139,25 @@ def sharded_nway(lists_host: Sequence[np.ndarray], word_length: int,
     return sum(t[0] for t in totals), sum(t[1] for t in totals) & 0xFFFFFFFFFFFFFFFF, tensor_to_records(gathered)
 
 
+class _DeviceWords:
+    """int32 view of device memory for torch (the CUDA array interface: no copy)"""
+
+    def __init__(self, ptr, n_words32):
+        self.__cuda_array_interface__ = {"shape": (int(n_words32),), "typestr": "<i4", "data": (int(ptr), False), "version": 3}
+
+
+def list_as_tensor(lst, n_records, host=False):
+    """The first n_records packed records of a device list as a 1-D int32 tensor: a zero-copy view of the list's HBM
+    (backend "nccl" = RCCL), or -- host=True, the CPU backend of the one-device test hook -- a host copy."""
+    import torch
+    if host:
+        rec = lst.download_range(0, n_records) if n_records else np.empty(0, dtype=RECORD_DTYPE)
+        return torch.from_numpy(np.ascontiguousarray(rec).view(np.int32).copy())
+    if not n_records:
+        return torch.empty(0, dtype=torch.int32, device="cuda")
+    return torch.as_tensor(_DeviceWords(lst.device_ptr, 3 * n_records), device="cuda")
+
+
 class DeviceShards:
     """Key-range sharded N-way operations on lists that are RESIDENT in this rank's HBM.
 
@@ -141,19 +166,54 @@ class DeviceShards:
     and the payload is gathered from that buffer over RCCL by the C ABI (`gt4hip_comm_gatherv`:
     grouped ncclSend / ncclRecv) -- the same entry point the C command-line tool uses.  The
     communicator id is made by rank 0 (`capi.comm_unique_id`) and handed over by the caller
-    (`torch.distributed.broadcast_object_list`, a file, MPI ...); `comm_id=None` means a world of one.
-    """
+    (`torch.distributed.broadcast_object_list`, a file, MPI ...); `comm_id=None` means no communicator
+    of the library's own: the exchanges then go over `torch.distributed`.
 
-    def __init__(self, ctx, rank=0, world=1, comm_id=None):
+    WHICH exchange path the ranks take is decided ONCE, collectively, here: `agree(ok) -> bool`
+    is a logical AND over the ranks (one all_reduce); the communicator is kept only if every rank made it and
+    one trial all-gather went through everywhere.  After that nothing is caught: a failure inside a step
+    propagates (a rank that silently changed paths would leave the others inside a different collective).
+    `gather_via` -- "rccl" (gt4hip_comm_gatherv) or "torch" (gatherv_records over torch.distributed) -- is only
+    ever changed by the caller, on all ranks at once (`use_torch_gather`)."""
+
+    def __init__(self, ctx, rank=0, world=1, comm_id=None, agree=None):
         self.ctx, self.rank, self.world = ctx, rank, world
-        self.comm = ctx.comm_create(comm_id, world, rank) if (comm_id is not None) else None
+        self.comm = None
+        self.comm_error = None
         self.last_ms = {}
+        if comm_id is not None:
+            ok = True
+            try:
+                self.comm = ctx.comm_create(comm_id, world, rank)
+            except Exception as e:
+                ok, self.comm_error = False, "communicator: %s" % e
+            if agree is not None:
+                ok = agree(ok)
+            if ok and world > 1:
+                try:
+                    ctx.comm_allgather_totals(self.comm, world, 1, 1)
+                except Exception as e:
+                    ok, self.comm_error = False, "trial all-gather: %s" % e
+                if agree is not None:
+                    ok = agree(ok)
+            if not ok:
+                if self.comm_error is None:
+                    self.comm_error = "another rank could not use the communicator"
+                self.close()
+        self.gather_via = "rccl" if self.comm is not None else "torch"
+        self.gather_note = None
+        self.host_tensors = False  # torch path: tensors on the host (backend gloo: the one-device test hook)
 
     def close(self):
         if self.comm is not None:
             from . import capi
             capi.comm_destroy(self.comm)
             self.comm = None
+
+    def use_torch_gather(self, why):
+        """every rank, together: the payload goes through torch.distributed from here on"""
+        self.gather_via = "torch"
+        self.gather_note = why
 
     def plan(self, lists, sampled=True):
         """The shards' first keys for a job over `lists` (all ranks hold the same lists and get the same cuts):
@@ -182,6 +242,38 @@ class DeviceShards:
         last = lst.lower_bound(cuts[g + 1]) if g + 1 < self.world else lst.n_words
         return lst.slice(first, last - first)
 
+    def gather(self, local, counts, root, gathered):
+        """The payload to `root`: over RCCL through the C ABI, or over torch.distributed (gatherv_records on views of
+        the lists' HBM).  Returns the gathered device list on root (None elsewhere; None on root too when the tensors
+        had to go through the host: the one-device test hook)."""
+        import os
+        hook = os.environ.get("GT4_BENCH_BREAK_GATHER", "")
+        if self.gather_via == "rccl":
+            if hook in ("1", "2") and self.rank == self.world - 1:  # test hook: the C gather fails on ONE rank, before it enters the collective
+                raise RuntimeError("gt4hip_comm_gatherv: injected failure (GT4_BENCH_BREAK_GATHER)")
+            if self.comm is None:
+                raise RuntimeError("no RCCL communicator")
+            self.ctx.comm_gatherv(self.comm, local, counts, root, gathered if self.rank == root else None)
+            return gathered if self.rank == root else None
+        if hook == "2":
+            raise RuntimeError("gatherv_records: injected failure (GT4_BENCH_BREAK_GATHER=2)")
+        if hook == "3" and self.rank == self.world - 1:
+            import time
+            time.sleep(10 ** 6)  # test hook: a rank that never arrives
+        mine = list_as_tensor(local, counts[self.rank], host=self.host_tensors)
+        out_t = None
+        if self.rank == root and not self.host_tensors:
+            out_t = list_as_tensor(gathered, sum(counts))
+        res = gatherv_records(mine, counts, root=root, out=out_t)
+        if self.rank != root:
+            return None
+        if self.host_tensors:
+            self.host_gathered_words = int(res.numel())
+            return None
+        from . import capi
+        capi.lib().gt4hip_list_set_n_words(gathered.h, sum(counts))
+        return gathered
+
     def run(self, shards, op, totals_exchange, root=0, out=None, gathered=None, gather=True):
         """`op(shards, out) -> (n_words, total_count, device list)` on this rank's shards, then the
         totals all-gather (`totals_exchange(n, total) -> [(n, total)] by rank`) and the gatherv.
@@ -192,23 +284,18 @@ class DeviceShards:
         t1 = time.perf_counter()
         if self.world == 1:
             totals = [(n, total)]
-        elif self.comm is not None and not getattr(self, "_no_c_allgather", False):
+        elif self.comm is not None:
             # over RCCL through the C ABI: one all-gather on the library's stream, one synchronisation (round 5; the
-            # torch.distributed form below costs a Python collective and a device-to-host copy per step)
-            try:
-                totals = self.ctx.comm_allgather_totals(self.comm, self.world, n, total)
-            except Exception:  # (the same code on every rank: all of them take the other form from here on)
-                self._no_c_allgather = True
-                totals = totals_exchange(n, total)
+            # torch.distributed form costs a Python collective and a device-to-host copy per step)
+            totals = self.ctx.comm_allgather_totals(self.comm, self.world, n, total)
         else:
             totals = totals_exchange(n, total)
         res = local
-        if gather and self.comm is not None:
+        if gather and self.world > 1:
             counts = [t[0] for t in totals]
-            if self.rank == root and gathered is None:
+            if self.rank == root and gathered is None and not self.host_tensors:
                 gathered = self.ctx.alloc(max(1, sum(counts)), local.word_length)
-            self.ctx.comm_gatherv(self.comm, local, counts, root, gathered if self.rank == root else None)
-            res = gathered if self.rank == root else None
+            res = self.gather(local, counts, root, gathered)
         t2 = time.perf_counter()
         self.last_ms = {"merge": (t1 - t0) * 1e3, "exchange_and_gather": (t2 - t1) * 1e3}
         return sum(t[0] for t in totals), sum(t[1] for t in totals) & 0xFFFFFFFFFFFFFFFF, res, totals

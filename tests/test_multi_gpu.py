@@ -36,7 +36,8 @@ def _free_port():
     return p
 
 
-def _bench(n_ranks, args, env_extra=None):
+def _bench_raw(n_ranks, args, env_extra=None):
+    """-> (exit code, the ONE JSON line of stdout, stderr)"""
     env = dict(os.environ, **(env_extra or {}))
     if n_ranks == 1:
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + args
@@ -44,14 +45,21 @@ def _bench(n_ranks, args, env_extra=None):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks), "--master-addr", "127.0.0.1",
                "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(n_ranks)] + args
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
-    assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, p.stdout[-2000:]
-    return json.loads(lines[0])
+    assert len(lines) == 1, (p.stdout[-2000:], p.stderr[-2000:])
+    if n_ranks == 1:
+        assert p.stdout.strip() == lines[0], "stdout carries the line and nothing else: " + p.stdout[-500:]
+    return p.returncode, json.loads(lines[0]), p.stderr
+
+
+def _bench(n_ranks, args, env_extra=None):
+    rc, line, err = _bench_raw(n_ranks, args, env_extra)
+    assert rc == 0, err[-3000:]
+    return line
 
 
 SMALL_PAIR = ["--workload", "intersect", "--entries", "6000000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-union8"]
-SMALL_BOTH = ["--entries", "6000000", "--entries8", "1500000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+SMALL_BOTH = ["--entries", "6000000", "--entries8", "1500000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras"]
 SMALL_UNION = ["--workload", "union8", "--entries8", "1500000", "--steps", "2", "--warmup", "1"]
 
 
@@ -91,7 +99,7 @@ def test_two_ranks_on_one_device_default_line():
 def test_eight_ranks_on_one_device_default_line():
     """the driver's N = 8 command with all eight ranks on device 0 (gloo): the totals of one GPU, every record in
     exactly one shard, empty shards included (equal-width ranges of a clustered list leave ranks without records)"""
-    small = ["--entries", "1600000", "--entries8", "400000", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
+    small = ["--entries", "1600000", "--entries8", "400000", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-extras"]
     one = _bench(1, small)
     eight = _bench(8, small, {"GT4_BENCH_ONE_DEVICE": "1"})
     assert eight["scaling"] == "strong" and eight["n_gpus"] == 8 and eight["self_check"] == "ok"
@@ -203,3 +211,54 @@ def test_two_gpus_default_line_over_rccl():
     two = _bench(2, SMALL_BOTH)
     assert two["self_check"] == "ok" and two["union8"]["self_check"] == "ok" and two["union8"]["gathered_bytes"] > 0
     assert (two["union8"]["output_records"], two["union8"]["output_total_count"]) == (one["union8"]["output_records"], one["union8"]["output_total_count"])
+
+
+def test_default_line_at_one_gpu_carries_config2_the_projection_and_the_file_to_file_run():
+    """VERDICT round 5, next 2 b: what only the builder's own runs showed is in the driver's line -- BASELINE configs[2] on the
+    same resident pair (verified against the reference binary), the eight shards of the union one after another, the
+    C command-line tool file -> file against the reference binary (byte-identical outputs), file-writing CPU leg = median of 3"""
+    r = _bench(1, ["--entries", "6000000", "--entries8", "1500000", "--steps", "2", "--warmup", "1", "--cpu-sample", "4000000", "--e2e-n", "1000000"])
+    assert r["self_check"] == "ok" and r["verified"] is True
+    assert "median of 3" in r["cpu_baseline"]["file_writing"]["sample"]
+    c2 = r["c2"]
+    assert "error" not in c2 and c2["verified"] is True and c2["roofline"]["frac"] > 0 and set(c2["output_records"]) == {"union", "diff1"}
+    e = r["e2e"]
+    assert "error" not in e and e["verified"] is True and [x["flags"] for x in e["runs"]] == ["-i", "-u -i -d"]
+    assert all(x["byte_identical"] and x["gpu_s"] > 0 and x["reference_s"] > 0 for x in e["runs"]) and e["runs"][1]["output_files"] == 3
+    pr = r["shard_projection"]
+    assert pr["shards"] == 8 and pr["outputs_add_up"] and len(pr["projection"][0]["per_shard"]) == 8 and pr["projected_speedup"] > 0
+    assert r["union8"]["self_check"] == "ok" and "error" not in r["union8"]
+
+
+SMALL_GATHER = ["--entries", "3000000", "--entries8", "800000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+
+
+@pytest.mark.parametrize("ranks", [2, 8])
+def test_a_gather_that_fails_at_first_contact_falls_back_on_every_rank(ranks):
+    """GT4_BENCH_BREAK_GATHER=1: the C gather raises on ONE rank before it enters the collective; one all_reduce makes the
+    verdict common, all ranks switch to torch.distributed's send / recv together, the line says so"""
+    one = _bench(1, SMALL_GATHER + ["--no-extras"])
+    r = _bench(ranks, SMALL_GATHER, {"GT4_BENCH_ONE_DEVICE": "1", "GT4_BENCH_BREAK_GATHER": "1"})
+    assert r["self_check"] == "ok" and r["config"]["output_records"] == one["config"]["output_records"]["intrsec"]
+    u = r["union8"]
+    assert u["self_check"] == "ok" and "error" not in u and u["merge_only"] > 0 and u["value_with_gather"] > 0
+    assert "torch.distributed" in u["gather_path"] and "first contact" in u["gather_note"] and u["gathered_bytes"] > 0
+    assert (u["output_records"], u["output_total_count"]) == (one["union8"]["output_records"], one["union8"]["output_total_count"])
+
+
+@pytest.mark.parametrize("ranks", [2, 8])
+def test_a_gather_that_fails_on_both_paths_costs_only_its_own_number(ranks):
+    """GT4_BENCH_BREAK_GATHER=2: the intersection line and merge_only are there, union8 carries the error, exit code 0"""
+    r = _bench(ranks, SMALL_GATHER, {"GT4_BENCH_ONE_DEVICE": "1", "GT4_BENCH_BREAK_GATHER": "2"})
+    assert r["self_check"] == "ok" and r["value"] > 0
+    u = r["union8"]
+    assert "both paths" in u["error"] and u["merge_only"] > 0 and u["self_check"] == "ok" and u["gathered_bytes"] == 0
+
+
+def test_a_gather_that_hangs_is_cut_off_with_the_line_printed():
+    """GT4_BENCH_BREAK_GATHER=3: one rank never arrives in the gather.  The leg's wall-clock guard prints the line as far
+    as the run got -- the intersection and the union's merge_only -- and every rank leaves with exit code 4: no hang"""
+    rc, r, err = _bench_raw(2, SMALL_GATHER + ["--leg-timeout", "20"], {"GT4_BENCH_ONE_DEVICE": "1", "GT4_BENCH_BREAK_GATHER": "3"})
+    assert rc != 0 and "TIMEOUT" in err
+    assert r["self_check"] == "ok" and r["value"] > 0
+    assert "wall-clock bound" in r["union8"]["error"] and r["union8"]["merge_only"] > 0
