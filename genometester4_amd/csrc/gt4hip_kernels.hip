@@ -276,7 +276,10 @@ __device__ __forceinline__ void scatter_stream (Shared &sh, u32 *dst32, const Pa
 {
   constexpr int NW = NT / WAVE;
   const StreamCoef c = make_coef<S> (p);
-  constexpr bool A_ONLY = (OPS == 2 && S == 1) || (OPS == 4 && S == 2); /* intersection / first complement alone: only A records are kept */
+  /* the intersection and the first complement keep A records only, in every kernel: a pair is evaluated at its A record
+   * (its B partner is KIND_SKIP) and a key that only B holds belongs to neither -- their slots need no look at the other
+   * list's kept records (round 6: the any-combination kernel spent two prefix lookups per record on a term that is 0) */
+  constexpr bool A_ONLY = S == 1 || S == 2;
   const u32 pna = A_ONLY ? 0u : kept_before (sh.kmask[S], sh.cpre[S], nbs); /* nbs: tile position of the first B record */
 #pragma unroll
   for (int k = 0; k < IPT; k++) {
