@@ -77,7 +77,9 @@ enum {
   GT4_LISTFILE_EOPEN = 1,    /* cannot open / map                                   */
   GT4_LISTFILE_EMAGIC = 2,   /* invalid file tag (src/word-map.c:181)               */
   GT4_LISTFILE_EVERSION = 3, /* incompatible major version (src/word-map.c:185)     */
-  GT4_LISTFILE_ESIZE = 4     /* file size too small (src/word-map.c:211-215)        */
+  GT4_LISTFILE_ESIZE = 4     /* file size too small (src/word-map.c:211-215) -- and headers that pass that test while
+                              * the records cannot lie in the file at stride 12: list_start > size or
+                              * n_words > (size - list_start) / 12, checked by division (the reference's product wraps) */
 };
 
 /* Reads the 4-byte tag of a file (glistcompare's format sniff, src/glistcompare.c:256-263).

@@ -12,7 +12,7 @@ if not p:
 acc = collections.OrderedDict()
 for row in csv.DictReader(open(p[0])):
     name = row["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").replace("gt4::", "").replace("km8::", "").replace("km32::", "").split("(")[0]
-    if not (name.startswith("k_pair_merge") or name.startswith("k_nway_merge") or name.startswith("k_nway_sub")): continue
+    if not (name.startswith("k_pair_merge") or name.startswith("k_nway_merge")): continue
     key = (row["Dispatch_Id"], name)
     acc.setdefault(key, {}).setdefault(row["Counter_Name"], 0.0)
     acc[key][row["Counter_Name"]] += float(row["Counter_Value"])
