@@ -1,6 +1,7 @@
-"""A 60-second slice of the randomised parity soaks in the driver-run suite: the pair
-kernels (all rules, cutoffs, output combinations, both single- and two-pass; tools/soak.py) and the N-way tile
-kernels (modes, bucket paths, split tiles, both tile kernels; tools/soak_nway.py), every case against the CPU oracle.
+"""A slice (12 + 10 seconds: the driver's GPU suite has a wall clock) of the randomised parity soaks in the driver-run
+suite: the pair kernels (all rules, cutoffs, output combinations, both single- and two-pass;
+tools/soak.py) and the N-way tile kernel (modes, bucket paths, split tiles; tools/soak_nway.py), every case against the
+CPU oracle.  `python tools/soak.py <seconds> <seed>` runs them for as long as one likes.
 Reference: src/glistcompare.c:433-489, :545-591, :605-717, :843-905."""
 import os
 import subprocess
@@ -22,9 +23,9 @@ def _soak(tool, seconds, seed, env=None):
 
 
 def test_pair_kernels_soak():
-    print(_soak("soak.py", 25, 501))
+    print(_soak("soak.py", 12, 501))
 
 
 def test_nway_kernels_soak():
-    print(_soak("soak_nway.py", 20, 502))
+    print(_soak("soak_nway.py", 10, 502))
 
