@@ -21,7 +21,7 @@ for SPEC in $WORKLOADS; do
   if [ "$D" != "stride" ]; then NAME=${W}_$D; fi
   OUT=$ROOT/gpurun_out/prof_$TAG/$NAME
   mkdir -p "$OUT"
-  if [ "$W" = "intersect" ] && [ "$D" = "stride" ]; then BENCH="python3 $ROOT/bench.py"; PMCX="--no-union8"; else BENCH="python3 $ROOT/bench.py --workload $W --dist $D"; PMCX=""; fi
+  if [ "$W" = "intersect" ] && [ "$D" = "stride" ]; then BENCH="python3 $ROOT/bench.py"; PMCX="--no-union8 --no-extras"; else BENCH="python3 $ROOT/bench.py --workload $W --dist $D"; PMCX=""; fi
   if [ "$W" = "intersect" ] && [ "$D" != "stride" ]; then BENCH="$BENCH --no-union8"; fi
   if [ "$W" = "table32" ]; then BENCH="python3 $ROOT/bench.py --workload table --nt-lists 32 --nt 20000000"; fi # (the count table of 32 lists: km32, one launch)
   cd "$ROOT"

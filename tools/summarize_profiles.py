@@ -11,7 +11,7 @@ import csv, glob, json, os, sys
 
 src, tag = sys.argv[1], sys.argv[2]
 workload = sys.argv[3] if len(sys.argv) > 3 else "intersect"
-ROUND = os.environ.get("GT4_ROUND", "round5")
+ROUND = os.environ.get("GT4_ROUND", "round6")
 dst = os.path.join(src, "summary")
 os.makedirs(dst, exist_ok=True)
 
