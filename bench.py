@@ -8,16 +8,23 @@ A "step" is one complete two-list intersection (merge-path partition + merge ker
 read-back) over synthetic sorted lists that are already resident in HBM.  Workload at N=1 is
 BASELINE.json configs[1]: two 2x10^9-entry k=25 lists (~24 GB each), `glistcompare -i`.  With N>1 the
 default is the SAME job (`"scaling": "strong"`): every rank keeps its key range of the one pair
-(gt4hip_shard_first_key; the set operations are key-local), merges it, and the per-shard
+(cut at keys sampled from the lists, gt4hip_shard_cuts; the set operations are key-local), merges it, and the per-shard
 (n_words, total_count) header totals are all-gathered over RCCL inside every step.  `--scaling weak`
 gives every GPU an independent pair instead (no exchange; a reference line, not the metric's job).
 
 The default line also carries a `"union8"` record -- BASELINE configs[3], the 8-way union of eight
-5x10^8-entry lists as ONE job sharded by key range over the ranks: `value_with_gather` (RCCL gatherv of
-the payload to rank 0 inside the step) and `merge_only` (what the shards sustain when every rank writes
-its own extent, the C host's default); BASELINE's ">= 6x at 8 GPUs" refers to `merge_only`.  Every
-line checks its job totals against the closed forms of the generator (|A n B| = n / 2, 5 n distinct keys
-of the eight lists) and the totals committed for the default sizes, and exits 3 on a mismatch.
+5x10^8-entry lists as ONE job sharded by key range over the ranks: `merge_only` (what the shards sustain when every
+rank keeps / writes its own extent, the C host's default; measured FIRST) and `value_with_gather` (the gatherv of the
+payload to rank 0 inside the step: gt4hip_comm_gatherv over RCCL, or -- if that fails on any rank at first contact -- on
+every rank together torch.distributed's send / recv; `gather_path` says which).  north_star asks for a final gatherv AND
+for >= 6x at 8 GPUs; the two exclude each other, so both numbers are reported.  At N = 1 the line
+further embeds `"c2"` (BASELINE configs[2] on the same resident pair, verified against the reference binary),
+`"shard_projection"` (the union's eight key-range shards timed one after another: what 8 GPUs would make of them) and
+`"e2e"` (the C command-line tool file -> file against the reference binary on a 2 x 2e8 sample in /dev/shm, outputs
+byte-compared).  Nothing can lose the line: a leg that raises leaves an "error" in its record, a leg that exceeds
+--leg-timeout makes rank 0 print the line as far as the run got and every rank exit 4; stdout carries the one JSON line
+and nothing else.  Every line checks its job totals against the closed forms of the generator (|A n B| = n / 2, 5 n
+distinct keys of the eight lists) and the totals committed for the default sizes, and exits 3 on a mismatch.
 
 `--dist` chooses the key distribution of the synthetic lists (genometester4_amd/synth.py): stride
 (default; one key per stride of the key space), iid, clustered, genomic.
@@ -1258,7 +1265,7 @@ def main():
                         "self_check": u["self_check"],
                         "note": "north_star asks for >= 6x at 8 GPUs on the 8-way union AND for a final gatherv: merge_only (every rank keeps / writes its own "
                                 "extent) is what can scale; value_with_gather moves 7/8 of the result into rank 0 over xGMI inside the step and is bound by "
-                                "the root's inbound links (DESIGN.md section 5 states the conflict); both are reported"}
+                                "the root's inbound links (DESIGN.md section 6 states the conflict); both are reported"}
                     if u["config"]["gather_error"]:
                         res["union8"]["error"] = u["config"]["gather_error"]
                     if "shard_projection" in u:

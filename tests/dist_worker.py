@@ -63,6 +63,51 @@ def main():
     if rank == 0:
         exp = torch.cat([torch.arange(3 * c, dtype=torch.int32) + 1000 * r for r, c in enumerate(counts)])
         ok &= bool(torch.equal(out, exp))
+    # the same into a buffer of the root's in which its own extent already lies (rank 0 of a sharded job merges straight
+    # into the gathered list: no copy of its own records)
+    total = sum(counts)
+    if rank == 0:
+        buf = torch.full((3 * total + 5,), -1, dtype=torch.int32)
+        buf[: 3 * counts[0]] = local
+        out2 = D.gatherv_records(buf[: 3 * counts[0]], counts, root=0, out=buf)
+        ok &= bool(out2.data_ptr() == buf.data_ptr() and torch.equal(out2, exp) and int(buf[3 * total]) == -1)
+    else:
+        D.gatherv_records(local, counts, root=0)
+    # which exchange path DeviceShards takes is agreed on ONCE: a communicator that ONE rank cannot make
+    # (or whose trial all-gather fails on one rank) is dropped on EVERY rank; nothing is caught after that
+
+    def agree(flag):
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(int(t.item()))
+
+    class StubCtx:
+        def __init__(self, fail_create, fail_trial):
+            self.fail_create, self.fail_trial, self.made = fail_create, fail_trial, 0
+
+        def comm_create(self, comm_id, n, r):
+            if self.fail_create:
+                raise RuntimeError("injected: no communicator on this rank")
+            self.made += 1
+            return object()
+
+        def comm_allgather_totals(self, comm, w, n, t):
+            if self.fail_trial:
+                raise RuntimeError("injected: trial all-gather")
+            return [(n, t)] * w
+
+    import genometester4_amd.capi as capi_mod
+    destroyed = []
+    real_destroy = capi_mod.comm_destroy
+    capi_mod.comm_destroy = lambda c: destroyed.append(c)
+    try:
+        for fail_create, fail_trial, want in ((False, False, "rccl"), (rank == world - 1, False, "torch"), (False, rank == 0, "torch")):
+            sh = D.DeviceShards(StubCtx(fail_create, fail_trial), rank, world, b"x" * 128, agree=agree)
+            ok &= sh.gather_via == want and (sh.comm is not None) == (want == "rccl")
+            if want == "torch":
+                ok &= sh.comm_error is not None
+    finally:
+        capi_mod.comm_destroy = real_destroy
     bounds = D.key_range_bounds(25, world)
     ok &= bounds[0] == 0 and bounds[-1] == 1 << 64 and all(a < b for a, b in zip(bounds, bounds[1:]))
     dist.barrier()
