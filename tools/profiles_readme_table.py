@@ -2,7 +2,7 @@
 summaries, traffic records).   python tools/profiles_readme_table.py [round5]"""
 import csv, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RND = sys.argv[1] if len(sys.argv) > 1 else "round5"
+RND = sys.argv[1] if len(sys.argv) > 1 else "round6"
 R = os.path.join(ROOT, "profiles", RND)
 TAG = "r%sfinal" % RND[-1]
 ORDER = [("intersect", "intersect (default line; config 1, 2 x 2e9 k=25, -i)", None), ("c2", "c2 (config 2, -u -d -c 3)", None),
