@@ -120,9 +120,10 @@ def test_sampled_splitters_balance_the_shards(dist):
     loads = [x["shard_input_records"] for x in r["config"]["per_rank"]]
     mean = sum(loads) / 8.0
     assert max(loads) <= 1.05 * mean and min(loads) >= 0.95 * mean, loads
-    e = _bench(8, args + ["--splitters", "equal"], {"GT4_BENCH_ONE_DEVICE": "1"})
-    assert e["self_check"] == "ok"
-    assert (e["config"]["output_records"], e["config"]["output_total_count"]) == (r["config"]["output_records"], r["config"]["output_total_count"])
+    if dist == "clustered":  # (one more eight-rank run: equal-width ranges give the same union)
+        e = _bench(8, args + ["--splitters", "equal"], {"GT4_BENCH_ONE_DEVICE": "1"})
+        assert e["self_check"] == "ok"
+        assert (e["config"]["output_records"], e["config"]["output_total_count"]) == (r["config"]["output_records"], r["config"]["output_total_count"])
 
 
 def test_projection_from_one_gpu_adds_up():

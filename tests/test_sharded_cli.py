@@ -55,9 +55,9 @@ def _check(case, cwd, env_extra):
         assert data == bytes(OUTPUTS["%s/%s" % (case["id"], name)]), "%s differs from the reference output" % name
 
 
-# (every edge / tree case and every second of the others: the whole set runs in one piece in tests/test_cli.py and through
+# (every edge / tree / multi case and every third of the others: the whole set runs in one piece in tests/test_cli.py and through
 # 1-KiB chunks under the sanitizers in tests/test_host_sanitizers.py; the driver's GPU suite has a wall clock)
-@pytest.mark.parametrize("case", [c for i, c in enumerate(GPU_CASES) if c["id"].startswith(("edge_", "tree_", "multi_")) or i % 2 == 0], ids=lambda c: c["id"])
+@pytest.mark.parametrize("case", [c for i, c in enumerate(GPU_CASES) if c["id"].startswith(("edge_", "tree_", "multi_")) or i % 3 == 0], ids=lambda c: c["id"])
 def test_chunked_run_reproduces_reference(case, workdir):
     _check(case, workdir, MODES["chunks"])
 
