@@ -263,3 +263,31 @@ def test_a_gather_that_hangs_is_cut_off_with_the_line_printed():
     assert rc != 0 and "TIMEOUT" in err
     assert r["self_check"] == "ok" and r["value"] > 0
     assert "wall-clock bound" in r["union8"]["error"] and r["union8"]["merge_only"] > 0
+
+
+def test_device_lists_as_torch_tensors_without_a_copy():
+    """the fall-back of the payload gather (torch.distributed send / recv) works on VIEWS of the lists' HBM
+    (distributed.list_as_tensor: the CUDA array interface): what torch sees is what the list holds, and a write through
+    the view lands in the list"""
+    import numpy as np
+    import torch
+    from genometester4_amd import capi, distributed as D
+    from genometester4_amd.listio import RECORD_DTYPE, make_records
+    ctx = capi.Context(0)
+    try:
+        rng = np.random.default_rng(5)
+        keys = np.unique(rng.integers(0, 1 << 50, size=20000, dtype=np.uint64))
+        rec = make_records(keys, rng.integers(1, 9, size=len(keys), dtype=np.uint32))
+        lst = ctx.upload(rec, 25)
+        t = D.list_as_tensor(lst, len(rec))
+        assert t.is_cuda and t.dtype == torch.int32 and t.numel() == 3 * len(rec) and t.data_ptr() == lst.device_ptr
+        assert t.cpu().numpy().view(RECORD_DTYPE).tobytes() == rec.tobytes()
+        dst = ctx.alloc(len(rec), 25)
+        D.list_as_tensor(dst, len(rec)).copy_(t)
+        torch.cuda.synchronize()
+        assert dst.download_range(0, len(rec)).tobytes() == rec.tobytes()
+        assert D.list_as_tensor(lst, 0).numel() == 0
+        h = D.list_as_tensor(lst, 100, host=True)
+        assert not h.is_cuda and h.numpy().view(RECORD_DTYPE).tobytes() == rec[:100].tobytes()
+    finally:
+        ctx.close()
