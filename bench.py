@@ -137,11 +137,18 @@ class Guard:
                 leg, dl = self.leg, self.deadline
             if dl is not None and time.monotonic() > dl:
                 why = "leg '%s' exceeded its wall-clock bound on rank %d" % (leg, self.rank)
-                log("TIMEOUT: " + why)
-                if self.rank == 0:
-                    emit(partial_line(why))
-                sys.stdout.flush()
-                os._exit(4)
+                try:
+                    log("TIMEOUT: " + why)
+                    if self.rank == 0:
+                        for _ in range(3):  # (the main thread may be writing into the records this very moment)
+                            try:
+                                emit(partial_line(why))
+                                break
+                            except RuntimeError:
+                                time.sleep(0.05)
+                    sys.stdout.flush()
+                finally:
+                    os._exit(4)
 
 
 class _NoGuard:
