@@ -108,6 +108,28 @@ def test_hostile_headers_are_refused_without_a_signal(name, blob, message, posit
 
 
 @pytest.mark.gpu
+def test_hostile_headers_are_refused_on_the_gpu_box_too(workdir):
+    """the same fifteen files where a device IS there (the driver's suite): refused before any device work, nothing
+    written, and a well-formed pair in the same directory still runs"""
+    import hostile_headers
+    with open(os.path.join(workdir, "h_good.list"), "wb") as f:
+        f.write(hostile_headers.good_list())
+    try:
+        for name, blob, message in _hostile_cases():
+            with open(os.path.join(workdir, name), "wb") as f:
+                f.write(blob)
+            try:
+                rc, out, err, files = _run(["h_good.list", name, "-u", "-i", "-o", "hostile"], workdir)
+                assert rc == 1 and message in err and not files, (name, rc, err)
+            finally:
+                os.remove(os.path.join(workdir, name))
+        rc, out, err, files = _run(["h_good.list", "h_good.list", "-i", "--count_only"], workdir)
+        assert rc == 0 and "NUnique\t8" in out, (rc, out, err)
+    finally:
+        os.remove(os.path.join(workdir, "h_good.list"))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case", OK_CASES, ids=lambda c: c["id"])
 def test_stream_debug_and_header_variants_match_reference(case, workdir):
     _check(case, workdir)
