@@ -259,7 +259,7 @@ def test_a_gather_that_fails_on_both_paths_costs_only_its_own_number(ranks):
 def test_a_gather_that_hangs_is_cut_off_with_the_line_printed():
     """GT4_BENCH_BREAK_GATHER=3: one rank never arrives in the gather.  The leg's wall-clock guard prints the line as far
     as the run got -- the intersection and the union's merge_only -- and every rank leaves with exit code 4: no hang"""
-    rc, r, err = _bench_raw(2, SMALL_GATHER + ["--leg-timeout", "12"], {"GT4_BENCH_ONE_DEVICE": "1", "GT4_BENCH_BREAK_GATHER": "3"})
+    rc, r, err = _bench_raw(2, SMALL_GATHER + ["--leg-timeout", "25"], {"GT4_BENCH_ONE_DEVICE": "1", "GT4_BENCH_BREAK_GATHER": "3"})
     assert rc != 0 and "TIMEOUT" in err
     assert r["self_check"] == "ok" and r["value"] > 0
     assert "wall-clock bound" in r["union8"]["error"] and r["union8"]["merge_only"] > 0
