@@ -304,7 +304,7 @@ def e2e_leg(args, ctx, a, b):
     for exe in (cli, ref):
         if not (os.path.exists(exe) and os.access(exe, os.X_OK)):
             raise RuntimeError("%s is not there" % os.path.relpath(exe, ROOT))
-    shm = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > (1 << 30) else None
     m_a = min(args.e2e_n, a.n_words)
     free = shutil.disk_usage(shm or tempfile.gettempdir()).free
     while m_a > 1_000_000 and 12 * 2 * m_a * 8 > free:  # inputs + both tools' three outputs, with room to spare
