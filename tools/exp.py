@@ -24,7 +24,7 @@ drivers.)
         count tables of six lists by the N-way tile kernel (kway 1) and by merges (kway 0)
 
 Environment: SCAN_GROUP, DYNAMIC, SPIN_LIMIT, KWAY_G, KWAY_VT, GRID, GEOM0, GEOM1, TWO_PASS set the library's options;
-GT4HIP_LIB selects a variant library (tools/build_variant.sh, tools/run_variants.sh).
+GT4HIP_LIB selects another build of the library (e.g. `make -C genometester4_amd/csrc prof`: libgt4hip_prof.so).
 """
 import argparse
 import os
